@@ -1,0 +1,178 @@
+/*
+ * sagen.h — C ABI of the MI355X-native (gfx950) spatialaudiogen inference path.
+ *
+ * The reference (pedro-morgado/spatialaudiogen, TF1/Python) has no FFI; its de-facto operator
+ * boundary for this path is Python.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference repo).  The shared library
+ * libsagen_hip.so implements this header with hand-written HIP kernels; there is NO CPU
+ * implementation of it — every compute entry point fails with SAGEN_ERR_HIP when no gfx950
+ * device is present.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes only.  All data pointers are DEVICE pointers to fp32 unless the
+ *    name ends in _h.  Tensors are NHWC exactly as the TF1 graph lays them out.
+ *  - `stream` is a hipStream_t passed as void*.  Every launch is asynchronous on that stream; no
+ *    entry point synchronises, allocates or frees device memory.  The caller owns all memory
+ *    (weights, inputs, outputs, workspace) — e.g. torch tensors' data_ptr().
+ *  - return value: 0 (SAGEN_OK) or a negative sagen_status; sagen_last_error() returns a
+ *    thread-local message for the last failure.  No exceptions / aborts cross the ABI.
+ *  - one sagen_ctx per (device, stream) pair in flight; contexts are independent.
+ */
+#ifndef SAGEN_H
+#define SAGEN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGEN_VERSION 100   /* 0.1.0 */
+
+typedef enum {
+    SAGEN_OK = 0,
+    SAGEN_ERR_NULL = -1,         /* null pointer argument */
+    SAGEN_ERR_SHAPE = -2,        /* bad / inconsistent shape */
+    SAGEN_ERR_UNSUPPORTED = -3,  /* configuration the HIP path does not implement */
+    SAGEN_ERR_WEIGHTS = -4,      /* missing / misnamed / mis-shaped variable at bind */
+    SAGEN_ERR_WORKSPACE = -5,    /* workspace too small or not bound */
+    SAGEN_ERR_HIP = -6           /* HIP runtime error (no device, launch failure, ...) */
+} sagen_status;
+
+/* encoder bit mask (reference definitions.py:1-4; model.py:47-51) */
+#define SAGEN_ENC_AUDIO 1
+#define SAGEN_ENC_VIDEO 2
+#define SAGEN_ENC_FLOW  4
+
+/* separation mode (reference definitions.py:6-8) */
+#define SAGEN_SEP_NONE      0   /* 'none'      : model.py:274-280 */
+#define SAGEN_SEP_FREQ_MASK 1   /* 'unet_mask' : model.py:282-348 */
+
+/* Mirrors SptAudioGen.__init__ + SptAudioGenParams (model.py:10-60) and the batch size the
+ * caller fixes at graph-build time (deploy.py:50, eval.py:44, train.py:38). */
+typedef struct {
+    int32_t batch;            /* windows per forward call (BN statistics are per call) */
+    int32_t encoders;         /* SAGEN_ENC_* mask; AUDIO is mandatory (model.py:207) */
+    int32_t separation;       /* SAGEN_SEP_* */
+    int32_t num_sep_tracks;   /* params.sep_num_tracks (32) */
+    int32_t n_loc_units;      /* len(params.loc_fc_units) (2) */
+    int32_t loc_units[4];     /* params.loc_fc_units ([512,512]) */
+    int32_t ambi_order;       /* 1 */
+    int32_t audio_rate;       /* 48000 */
+    int32_t video_rate;       /* 10 */
+    float   context;          /* 1.0 s */
+    float   sample_duration;  /* 0.1 s */
+    float   fft_window;       /* 0.025 s -> wind_size 1024 */
+} sagen_config;
+
+/* One TF variable: name is the checkpoint key, data is a device pointer in the TF
+ * layout (conv HWIO, conv2d_transpose [kh,kw,Cout,Cin], FC [in,out], vectors [C]). */
+typedef struct {
+    const char*  name;
+    const float* data;
+    int32_t      ndim;
+    int64_t      shape[4];
+} sagen_tensor;
+
+typedef struct sagen_ctx sagen_ctx;
+
+int  sagen_version(void);
+const char* sagen_last_error(void);
+
+/* ---- model-level: replaces SptAudioGen.inference_ops (model.py:356-434), as called at
+ *      deploy.py:77,141 / eval.py:90,145 ------------------------------------------------- */
+int    sagen_create(sagen_ctx** out, const sagen_config* cfg);
+void   sagen_destroy(sagen_ctx* ctx);
+/* bytes of scratch the caller must provide (activations + packed weights); fixed per ctx */
+size_t sagen_workspace_bytes(const sagen_ctx* ctx);
+/* number of variables the configuration expects, and the i-th expected name/shape */
+int    sagen_num_variables(const sagen_ctx* ctx);
+int    sagen_variable_spec(const sagen_ctx* ctx, int i, const char** name, int32_t* ndim, int64_t shape[4]);
+/* Borrow the variables (replaces tf.train.Saver.restore, deploy.py:79-87) and repack them into
+ * the kernels' layouts inside `workspace`.  Tensors must stay alive only until the stream
+ * reaches the end of this call's work; workspace must stay alive and untouched by the caller
+ * for the life of the ctx. */
+int    sagen_bind_weights(sagen_ctx* ctx, const sagen_tensor* tensors, int n,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* audio [B, snd_size] (=[B,52799,1]); video/flow [B,224,448,3] (=[B,1,224,448,3]) or NULL;
+ * ambi_yzx [B, snd_dur, 3] (channels Y,Z,X = ACN 1,2,3). */
+int    sagen_forward(sagen_ctx* ctx, const float* audio, const float* video, const float* flow,
+                     float* ambi_yzx, void* stream);
+/* deploy.py:143-152: out[b, n, :] = [mono[b, snd_contx/2 + n], ambi_yzx[b, n, 0..2]] -> [B,snd_dur,4] WYZX */
+int    sagen_assemble_wyzx(const float* audio, const float* ambi_yzx, float* out_wyzx,
+                           int batch, int snd_size, int snd_contx, int snd_dur, void* stream);
+/* named intermediate of the last forward (device pointer inside the workspace) for parity tests:
+ * "mag", "stft", "audio_encoder/conv1".."conv5", "<enc>_encoder/conv5_2", "bottleneck",
+ * "localization/coeffs", "separation/deconv1" (needed rows only). Returns dims in shape[4]. */
+int    sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float** data,
+                              int32_t* ndim, int64_t shape[4], int64_t* pixel_stride);
+
+/* ---- op-level (unit-testable; same conventions) ----------------------------------------- */
+
+/* myutils.stft (myutils.py:119-147) fused with the crop + tf.abs of audio_encoder_ops
+ * (model.py:166-178): hop = wind/4, periodic Hann, 1024-pt FFT.
+ * mag [B, f1-f0, 1024] magnitudes of frames [f0,f1); spec [B, c1-c0, 513, 2] (re,im) of frames
+ * [c0,c1) (bins 0..512; the rest is the Hermitian mirror).  Either output may be NULL. */
+int sagen_stft_mag(const float* audio, int batch, int n_samples, int f0, int f1, float* mag,
+                   int c0, int c1, float* spec, void* stream);
+
+/* tfw.conv_2d (core.py:156-220) = tf.nn.convolution NHWC/HWIO + (bias | nothing) + optional ReLU.
+ * padding: 0 = VALID, 1 = SAME (TF asymmetric).  Batch-norm is NOT applied here: pass bn_stats
+ * (>= sagen_bn_stats_floats(...) floats) to receive per-channel partial sums of the raw output and
+ * call sagen_bn_finalize; the consumer applies scale/shift (+ReLU) via in_scale/in_shift.
+ * in_scale/in_shift [Cin] (nullable): input is relu(x*scale+shift) before padding.
+ * scratch: >= sagen_conv2d_scratch_bytes(...) bytes for the repacked filter (and, for cin == 3, the
+ * zero-bordered 4-channel copy of the input).  Supported cin: a power of two >= 4; 3; or 1 with
+ * padding VALID, kw % 4 == 0 and sw % 4 == 0 (the spectrogram conv). */
+size_t sagen_conv2d_scratch_bytes(int batch, int h, int w, int kh, int kw, int cin, int cout);
+size_t sagen_bn_stats_floats(int batch, int hout, int wout, int cout);
+int sagen_conv2d(const float* x, int batch, int h, int w, int cin,
+                 const float* w_hwio, int kh, int kw, int cout, int sh, int sw, int padding,
+                 const float* bias, int relu, const float* in_scale, const float* in_shift,
+                 float* y, float* bn_stats, void* scratch, size_t scratch_bytes, void* stream);
+
+/* contrib batch_norm in training mode (core.py:6,209-210; eps 1e-3, biased variance):
+ * turns the partial sums into scale = gamma/sqrt(var+eps), shift = beta - mean*scale. */
+int sagen_bn_finalize(const float* bn_stats, int batch, int hout, int wout, int cout,
+                      const float* gamma, const float* beta, float eps,
+                      float* scale, float* shift, void* stream);
+/* y = relu(x*scale + shift (+ residual)) elementwise over [n_pixels, C] (resnet.py:221,235) */
+int sagen_bn_apply_relu(const float* x, const float* scale, const float* shift,
+                        const float* residual, float* y, int64_t n_pixels, int c, void* stream);
+/* tf.nn.max_pool 3x3 s2 'SAME' (resnet.py:135) of relu(x*scale+shift) (scale NULL = identity) */
+int sagen_maxpool3x3s2(const float* x, const float* scale, const float* shift, float* y,
+                       int batch, int h, int w, int c, void* stream);
+
+/* tfw.fully_connected (core.py:43-93): y[M,N] = act(x[M,K] @ w[K,N] + b). */
+size_t sagen_fc_scratch_bytes(int m, int k, int n);
+int sagen_fc(const float* x, int m, int k, const float* w_kn, int n, const float* bias, int relu,
+             float* y, void* scratch, size_t scratch_bytes, void* stream);
+
+/* tfw.deconv_2d (core.py:96-153) = tf.nn.conv2d_transpose VALID, w [kh,kw,Cout,Cin], + bias
+ * (+ReLU).  y [B, h*sh+kh-sh, w*sw+kw-sw, cout]. */
+size_t sagen_deconv2d_scratch_bytes(int kh, int kw, int cin, int cout, int sh, int sw);
+int sagen_deconv2d(const float* x, int batch, int h, int w, int cin,
+                   const float* w_hwoi, int kh, int kw, int cout, int sh, int sw,
+                   const float* bias, int relu, float* y,
+                   void* scratch, size_t scratch_bytes, void* stream);
+
+/* separation tail + decoder (model.py:326-347, myutils.istft myutils.py:181-211, model.py:421-434):
+ * dmask  [B, 28, 1024, ntracks] : deconv1 output rows 43:71 (pre-sigmoid), NHWC
+ * spec   [B, 28, 513, 2]        : STFT frames 89:117 (bins 0..512)
+ * coeffs [B, 3, 3, ntracks+1]   : localization output (step, out-channel, track | bias)
+ * ambi_yzx [B, 4800, 3].  scratch >= sagen_mask_istft_mix_scratch_bytes(batch). */
+size_t sagen_mask_istft_mix_scratch_bytes(int batch);
+int sagen_mask_istft_mix(const float* dmask, const float* spec, const float* coeffs, int batch,
+                         int ntracks, float* ambi_yzx, void* scratch, size_t scratch_bytes, void* stream);
+
+/* AmbiDecoder.decode('projection') + RMS map (pyutils/ambisonics/decoder.py:24-28,
+ * distance.py:41-52; SH matrix common.py:151-178, order 1 ACN/SN3D):
+ * ambi_wyzx [T,4]; sh [P,4] device matrix; rms [P] = sqrt(mean_t (ambi . sh[p])^2).
+ * The rms buffer must hold P + 24 floats (the tail is used for the 4x4 second-moment matrix). */
+int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, float* rms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGEN_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of libsagen_hip.so (include/sagen.h).  There is no CPU fallback: a missing
+library or a failing call raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libsagen_hip.so')
+
+SAGEN_ENC_AUDIO, SAGEN_ENC_VIDEO, SAGEN_ENC_FLOW = 1, 2, 4
+SAGEN_SEP_NONE, SAGEN_SEP_FREQ_MASK = 0, 1
+
+
+class SagenError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'sagen error %d: %s' % (code, msg))
+        self.code = code
+
+
+class SagenConfig(C.Structure):
+    _fields_ = [('batch', C.c_int32), ('encoders', C.c_int32), ('separation', C.c_int32),
+                ('num_sep_tracks', C.c_int32), ('n_loc_units', C.c_int32), ('loc_units', C.c_int32 * 4),
+                ('ambi_order', C.c_int32), ('audio_rate', C.c_int32), ('video_rate', C.c_int32),
+                ('context', C.c_float), ('sample_duration', C.c_float), ('fft_window', C.c_float)]
+
+
+class SagenTensor(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.c_void_p), ('ndim', C.c_int32), ('shape', C.c_int64 * 4)]
+
+
+# every symbol include/sagen.h declares: name -> (restype, argtypes)
+_P, _I, _F, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+SIGNATURES = {
+    'sagen_version': (C.c_int, []),
+    'sagen_last_error': (C.c_char_p, []),
+    'sagen_create': (C.c_int, [C.POINTER(_P), C.POINTER(SagenConfig)]),
+    'sagen_destroy': (None, [_P]),
+    'sagen_workspace_bytes': (_SZ, [_P]),
+    'sagen_num_variables': (C.c_int, [_P]),
+    'sagen_variable_spec': (C.c_int, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    'sagen_bind_weights': (C.c_int, [_P, C.POINTER(SagenTensor), _I, _P, _SZ, _P]),
+    'sagen_forward': (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    'sagen_assemble_wyzx': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'sagen_get_intermediate': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64)]),
+    'sagen_stft_mag': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'sagen_conv2d_scratch_bytes': (_SZ, [_I] * 7),
+    'sagen_bn_stats_floats': (_SZ, [_I] * 4),
+    'sagen_conv2d': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    'sagen_bn_finalize': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P]),
+    'sagen_bn_apply_relu': (C.c_int, [_P, _P, _P, _P, _P, _I64, _I, _P]),
+    'sagen_maxpool3x3s2': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'sagen_fc_scratch_bytes': (_SZ, [_I] * 3),
+    'sagen_fc': (C.c_int, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _SZ, _P]),
+    'sagen_deconv2d_scratch_bytes': (_SZ, [_I] * 6),
+    'sagen_deconv2d': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _SZ, _P]),
+    'sagen_mask_istft_mix_scratch_bytes': (_SZ, [_I]),
+    'sagen_mask_istft_mix': (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    'sagen_power_map': (C.c_int, [_P, _I64, _P, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('%s is missing: build the HIP extension first '
+                               '(python -m spatialaudiogen_amd.build). There is no CPU fallback.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SagenError(rc, lib().sagen_last_error().decode())
+    return rc

@@ -1,0 +1,73 @@
+"""Build libsagen_hip.so (hand-written HIP, gfx950 only) in-tree with hipcc.
+
+    python -m spatialaudiogen_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to csrc/build/ (git-ignored); the shared library
+lands next to this file so it travels with the source tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(HERE, 'libsagen_hip.so')
+SOURCES = ['igemm.hip', 'elementwise.hip', 'fft.hip', 'model.hip', 'api.hip']
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'kernels.h'),
+           os.path.join(HERE, '..', 'include', 'sagen.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + HEADERS):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (s, r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        for err in ex.map(compile_one, jobs):
+            if verbose and err.strip():
+                print(err)
+    objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stderr)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,269 @@
+// extern "C" surface of libsagen_hip.so (include/sagen.h).  Thin: argument checking, error codes,
+// no exceptions across the boundary.
+#include "kernels.h"
+#include <new>
+
+struct sagen_ctx;
+int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg);
+int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* workspace, size_t workspace_bytes, hipStream_t s);
+int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
+void sagen_destroy_impl(sagen_ctx* c);
+size_t sagen_workspace_bytes_impl(const sagen_ctx* c);
+int sagen_num_variables_impl(const sagen_ctx* c);
+int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32_t* ndim, int64_t shape[4]);
+int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
+                                int64_t* pixel_stride);
+
+namespace sagen {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(SAGEN_ERR_WORKSPACE, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(SAGEN_ERR_SHAPE, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(SAGEN_ERR_SHAPE, "internal error");
+    }
+}
+
+static size_t pk_bytes(long N, long K) { return align_up((size_t)N * ((K + 15) / 16 * 16) * sizeof(float), 256); }
+
+}  // namespace sagen
+
+using namespace sagen;
+
+extern "C" {
+
+int sagen_version(void) { return SAGEN_VERSION; }
+const char* sagen_last_error(void) { return err_buf(); }
+
+int sagen_create(sagen_ctx** out, const sagen_config* cfg) {
+    return guarded([&] { return sagen_create_impl(out, cfg); });
+}
+void sagen_destroy(sagen_ctx* ctx) { sagen_destroy_impl(ctx); }
+size_t sagen_workspace_bytes(const sagen_ctx* ctx) { return ctx ? sagen_workspace_bytes_impl(ctx) : 0; }
+int sagen_num_variables(const sagen_ctx* ctx) { return ctx ? sagen_num_variables_impl(ctx) : fail(SAGEN_ERR_NULL, "null ctx"); }
+int sagen_variable_spec(const sagen_ctx* ctx, int i, const char** name, int32_t* ndim, int64_t shape[4]) {
+    if (!ctx || !name || !ndim || !shape) return fail(SAGEN_ERR_NULL, "sagen_variable_spec: null argument");
+    return sagen_variable_spec_impl(ctx, i, name, ndim, shape);
+}
+int sagen_bind_weights(sagen_ctx* ctx, const sagen_tensor* tensors, int n, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    return guarded([&] { return sagen_bind_impl(ctx, tensors, n, workspace, workspace_bytes, (hipStream_t)stream); });
+}
+int sagen_forward(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {
+    return guarded([&] { return sagen_forward_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
+}
+int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
+                           int64_t* pixel_stride) {
+    if (!ctx || !name || !data || !ndim || !shape || !pixel_stride) return fail(SAGEN_ERR_NULL, "sagen_get_intermediate: null argument");
+    return guarded([&] { return sagen_get_intermediate_impl(ctx, name, data, ndim, shape, pixel_stride); });
+}
+
+int sagen_assemble_wyzx(const float* audio, const float* ambi_yzx, float* out_wyzx, int batch, int snd_size, int snd_contx,
+                        int snd_dur, void* stream) {
+    if (!audio || !ambi_yzx || !out_wyzx) return fail(SAGEN_ERR_NULL, "sagen_assemble_wyzx: null argument");
+    if (batch <= 0 || snd_contx / 2 + snd_dur > snd_size) return fail(SAGEN_ERR_SHAPE, "sagen_assemble_wyzx: bad sizes");
+    return assemble_wyzx_launch(audio, ambi_yzx, out_wyzx, batch, snd_size, snd_contx, snd_dur, (hipStream_t)stream);
+}
+
+int sagen_stft_mag(const float* audio, int batch, int n_samples, int f0, int f1, float* mag, int c0, int c1, float* spec,
+                   void* stream) {
+    if (!audio || (!mag && !spec)) return fail(SAGEN_ERR_NULL, "sagen_stft_mag: null argument");
+    if (batch <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_stft_mag: batch=%d", batch);
+    return stft_launch(audio, batch, n_samples, f0, f1, mag, c0, c1, spec, (hipStream_t)stream);
+}
+
+size_t sagen_conv2d_scratch_bytes(int batch, int h, int w, int kh, int kw, int cin, int cout) {
+    if (cin == 3) return pk_bytes(cout, (long)kh * kw * 4) + align_up((size_t)batch * (h + kh) * (w + kw) * 4 * sizeof(float), 256);
+    return pk_bytes(cout, (long)kh * kw * cin);
+}
+
+size_t sagen_bn_stats_floats(int batch, int hout, int wout, int cout) {
+    return (size_t)cdiv((long)batch * hout * wout, 32) * 2 * cout;     // covers every tile height
+}
+
+int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* w_hwio, int kh, int kw, int cout, int sh,
+                 int sw, int padding, const float* bias, int relu, const float* in_scale, const float* in_shift, float* y,
+                 float* bn_stats, void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream;
+        if (!x || !w_hwio || !y || !scratch) return fail(SAGEN_ERR_NULL, "sagen_conv2d: null argument");
+        if (batch <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || cout <= 0)
+            return fail(SAGEN_ERR_SHAPE, "sagen_conv2d: bad dimensions");
+        if ((in_scale == nullptr) != (in_shift == nullptr)) return fail(SAGEN_ERR_NULL, "sagen_conv2d: in_scale/in_shift must come together");
+        if (scratch_bytes < sagen_conv2d_scratch_bytes(batch, h, w, kh, kw, cin, cout))
+            return fail(SAGEN_ERR_WORKSPACE, "sagen_conv2d: scratch too small");
+        int Hout, Wout, pt = 0, pb = 0, pl = 0, pr = 0;
+        if (padding == 1) {
+            Hout = cdiv(h, sh); Wout = cdiv(w, sw);
+            const int th = std::max((Hout - 1) * sh + kh - h, 0), tw = std::max((Wout - 1) * sw + kw - w, 0);
+            pt = th / 2; pb = th - pt; pl = tw / 2; pr = tw - pl;
+        } else if (padding == 0) {
+            if (h < kh || w < kw) return fail(SAGEN_ERR_SHAPE, "sagen_conv2d: VALID conv larger than input");
+            Hout = (h - kh) / sh + 1; Wout = (w - kw) / sw + 1;
+        } else {
+            return fail(SAGEN_ERR_SHAPE, "sagen_conv2d: padding must be 0 (VALID) or 1 (SAME)");
+        }
+        float* wp = (float*)scratch;
+        IgemmDesc d;
+        d.y = y; d.bias = bias; d.relu_out = relu; d.in_scale = in_scale; d.in_shift = in_shift; d.stats = bn_stats;
+        d.M = batch * Hout * Wout; d.N = cout; d.Cout = cout;
+        d.Hg = Hout; d.Wg = Wout; d.Hlim = Hout; d.Wlim = Wout;
+        d.ldy = cout; d.y_rstride = (long)Wout * cout; d.y_bstride = (long)Hout * Wout * cout;
+        d.in_sh = sh; d.in_sw = sw; d.w = wp;
+        int rc;
+        if (cin == 1) {
+            if (padding != 0 || kw % 4 || sw % 4 || in_scale)
+                return fail(SAGEN_ERR_UNSUPPORTED, "sagen_conv2d: cin=1 needs VALID padding, kw%%4==0, sw%%4==0, no input BN");
+            d.x = x; d.Hin = h; d.Win = w; d.Cin = kw; d.ldx = 1; d.x_bstride = (long)h * w;
+            d.ntaps = kh; d.TW = 1; d.tap_sh = 1; d.tap_sw = 0; d.log2Cin = ilog2_exact(kw);
+            if (kh > 1 && d.log2Cin < 0) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_conv2d: cin=1 needs power-of-two kw");
+            d.K = kh * kw; d.Kpad = (d.K + 15) / 16 * 16;
+            rc = pack_conv_launch(w_hwio, kh, kw, kw, cout, wp, cout, d.Kpad, s);
+        } else if (cin == 3) {
+            if (in_scale) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_conv2d: cin=3 does not take an input BN");
+            float* xp = (float*)((char*)scratch + pk_bytes(cout, (long)kh * kw * 4));
+            rc = pad_nhwc3to4_launch(x, xp, batch, h, w, pt, pb, pl, pr, s);
+            if (rc) return rc;
+            d.x = xp; d.Hin = h + pt + pb; d.Win = w + pl + pr; d.Cin = 4; d.ldx = 4; d.x_bstride = (long)d.Hin * d.Win * 4;
+            d.ntaps = kh * kw; d.TW = kw; d.log2Cin = 2;
+            d.K = kh * kw * 4; d.Kpad = (d.K + 15) / 16 * 16;
+            rc = pack_conv_launch(w_hwio, kh * kw, 3, 4, cout, wp, cout, d.Kpad, s);
+        } else {
+            if (cin % 4 || (kh * kw > 1 && ilog2_exact(cin) < 2))
+                return fail(SAGEN_ERR_UNSUPPORTED, "sagen_conv2d: cin=%d (supported: 1, 3, powers of two >= 4; any multiple of 4 for 1x1)", cin);
+            d.x = x; d.Hin = h; d.Win = w; d.Cin = cin; d.ldx = cin; d.x_bstride = (long)h * w * cin;
+            d.ntaps = kh * kw; d.TW = kw; d.tap_h0 = -pt; d.tap_w0 = -pl; d.log2Cin = ilog2_exact(cin);
+            d.K = kh * kw * cin; d.Kpad = (d.K + 15) / 16 * 16;
+            rc = pack_conv_launch(w_hwio, kh * kw, cin, cin, cout, wp, cout, d.Kpad, s);
+        }
+        if (rc) return rc;
+        return igemm_launch(d, TILE_AUTO, s);
+    });
+}
+
+int sagen_bn_finalize(const float* bn_stats, int batch, int hout, int wout, int cout, const float* gamma, const float* beta,
+                      float eps, float* scale, float* shift, void* stream) {
+    if (!bn_stats || !gamma || !beta || !scale || !shift) return fail(SAGEN_ERR_NULL, "sagen_bn_finalize: null argument");
+    IgemmDesc d;
+    d.M = batch * hout * wout; d.N = cout;
+    const int tiles = igemm_grid_m(d, TILE_AUTO);
+    return bn_finalize_launch(bn_stats, tiles, (long)d.M, cout, gamma, beta, eps, scale, shift, (hipStream_t)stream);
+}
+
+int sagen_bn_apply_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                        int64_t n_pixels, int c, void* stream) {
+    if (!x || !y) return fail(SAGEN_ERR_NULL, "sagen_bn_apply_relu: null argument");
+    if ((scale == nullptr) != (shift == nullptr)) return fail(SAGEN_ERR_NULL, "sagen_bn_apply_relu: scale/shift must come together");
+    if (n_pixels <= 0 || c <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_bn_apply_relu: bad sizes");
+    return bn_apply_relu_launch(x, scale, shift, residual, y, n_pixels, c, (hipStream_t)stream);
+}
+
+int sagen_maxpool3x3s2(const float* x, const float* scale, const float* shift, float* y, int batch, int h, int w, int c,
+                       void* stream) {
+    if (!x || !y) return fail(SAGEN_ERR_NULL, "sagen_maxpool3x3s2: null argument");
+    if (batch <= 0 || h <= 0 || w <= 0 || c <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_maxpool3x3s2: bad sizes");
+    return maxpool3x3s2_launch(x, scale, shift, y, batch, h, w, c, (hipStream_t)stream);
+}
+
+size_t sagen_fc_scratch_bytes(int m, int k, int n) {
+    return pk_bytes(n, k) + align_up((size_t)64 * m * n * sizeof(float), 256);
+}
+
+int sagen_fc(const float* x, int m, int k, const float* w_kn, int n, const float* bias, int relu, float* y, void* scratch,
+             size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream;
+        if (!x || !w_kn || !y || !scratch) return fail(SAGEN_ERR_NULL, "sagen_fc: null argument");
+        if (m <= 0 || k <= 0 || n <= 0 || k % 4) return fail(SAGEN_ERR_SHAPE, "sagen_fc: bad sizes (k must be a multiple of 4)");
+        if (scratch_bytes < sagen_fc_scratch_bytes(m, k, n)) return fail(SAGEN_ERR_WORKSPACE, "sagen_fc: scratch too small");
+        float* wp = (float*)scratch;
+        float* ws = (float*)((char*)scratch + pk_bytes(n, k));
+        IgemmDesc d;
+        d.x = x; d.w = wp; d.y = y;
+        d.M = m; d.N = n; d.K = k; d.Kpad = (k + 15) / 16 * 16; d.Cin = k; d.ldx = k; d.x_bstride = k;
+        d.Cout = n; d.ldy = n; d.y_rstride = n; d.y_bstride = n;
+        int rc = pack_conv_launch(w_kn, 1, k, k, n, wp, n, d.Kpad, s);
+        if (rc) return rc;
+        // low-parallelism rows: split K so the weight stream is spread over the chip
+        IgemmTile tile = igemm_pick_tile(d);
+        const int bm = tile == TILE_32x128 ? 32 : 64, bn = tile == TILE_32x128 ? 128 : 64;
+        const long blocks = (long)cdiv(m, bm) * cdiv(n, bn);
+        int sk = 1;
+        if (blocks < 384 && d.Kpad / 16 >= 16) sk = (int)std::min<long>({(512 + blocks - 1) / blocks, (long)d.Kpad / 16 / 8, 64L});
+        if (sk > 1) {
+            d.splitk = sk; d.splitk_ws = ws;
+            rc = igemm_launch(d, tile, s);
+            if (rc) return rc;
+            return splitk_reduce_launch(ws, sk, m, n, bias, relu, y, n, 1, s);
+        }
+        d.bias = bias; d.relu_out = relu;
+        return igemm_launch(d, tile, s);
+    });
+}
+
+size_t sagen_deconv2d_scratch_bytes(int kh, int kw, int cin, int cout, int sh, int sw) {
+    return pk_bytes((long)sh * sw * cout, (long)cdiv(kh, sh) * cdiv(kw, sw) * cin);
+}
+
+int sagen_deconv2d(const float* x, int batch, int h, int w, int cin, const float* w_hwoi, int kh, int kw, int cout, int sh,
+                   int sw, const float* bias, int relu, float* y, void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream;
+        if (!x || !w_hwoi || !y || !scratch) return fail(SAGEN_ERR_NULL, "sagen_deconv2d: null argument");
+        if (batch <= 0 || h <= 0 || w <= 0 || kh < sh || kw < sw || sh <= 0 || sw <= 0 || cout <= 0)
+            return fail(SAGEN_ERR_SHAPE, "sagen_deconv2d: bad dimensions (kernel must be >= stride)");
+        if (ilog2_exact(cin) < 2) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_deconv2d: cin=%d must be a power of two >= 4", cin);
+        if (scratch_bytes < sagen_deconv2d_scratch_bytes(kh, kw, cin, cout, sh, sw))
+            return fail(SAGEN_ERR_WORKSPACE, "sagen_deconv2d: scratch too small");
+        const int Hout = h * sh + kh - sh, Wout = w * sw + kw - sw;
+        const int nth = cdiv(kh, sh), ntw = cdiv(kw, sw);
+        IgemmDesc d;
+        d.x = x; d.w = (float*)scratch; d.y = y; d.bias = bias; d.relu_out = relu;
+        d.Hg = cdiv(Hout, sh); d.Wg = cdiv(Wout, sw);
+        d.M = batch * d.Hg * d.Wg; d.N = sh * sw * cout; d.K = nth * ntw * cin; d.Kpad = (d.K + 15) / 16 * 16;
+        d.Hin = h; d.Win = w; d.Cin = cin; d.ldx = cin; d.x_bstride = (long)h * w * cin;
+        d.ntaps = nth * ntw; d.TW = ntw; d.tap_sh = -1; d.tap_sw = -1; d.log2Cin = ilog2_exact(cin);
+        d.dsh = sh; d.dsw = sw; d.Cout = cout; d.Hlim = Hout; d.Wlim = Wout;
+        d.ldy = cout; d.y_rstride = (long)Wout * cout; d.y_bstride = (long)Hout * Wout * cout;
+        int rc = pack_deconv_launch(w_hwoi, kh, kw, cout, cin, sh, sw, (float*)scratch, d.N, d.Kpad, s);
+        if (rc) return rc;
+        return igemm_launch(d, TILE_AUTO, s);
+    });
+}
+
+size_t sagen_mask_istft_mix_scratch_bytes(int batch) { return mask_istft_scratch_bytes(batch); }
+
+int sagen_mask_istft_mix(const float* dmask, const float* spec, const float* coeffs, int batch, int ntracks, float* ambi_yzx,
+                         void* scratch, size_t scratch_bytes, void* stream) {
+    if (!dmask || !spec || !coeffs || !ambi_yzx || !scratch) return fail(SAGEN_ERR_NULL, "sagen_mask_istft_mix: null argument");
+    if (batch <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_mask_istft_mix: batch=%d", batch);
+    if (scratch_bytes < mask_istft_scratch_bytes(batch)) return fail(SAGEN_ERR_WORKSPACE, "sagen_mask_istft_mix: scratch too small");
+    return mask_istft_mix_launch(dmask, 28L * 1024 * ntracks, 0, spec, coeffs, batch, ntracks, ambi_yzx, (float*)scratch,
+                                 (hipStream_t)stream);
+}
+
+int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, float* rms, void* stream) {
+    if (!ambi_wyzx || !sh || !rms) return fail(SAGEN_ERR_NULL, "sagen_power_map: null argument");
+    if (t <= 0 || p <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_power_map: bad sizes");
+    return power_map_launch(ambi_wyzx, t, sh, p, rms, (hipStream_t)stream);
+}
+
+}  // extern "C"

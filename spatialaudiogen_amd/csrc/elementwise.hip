@@ -1,0 +1,260 @@
+// HBM-bound kernels of the path: batch-norm statistics finalisation, BN+ReLU(+residual),
+// BN+ReLU+max-pool, input padding, ambisonic power map, output assembly.  All are
+// 16-byte-per-lane coalesced NHWC streams (channels innermost, C % 4 == 0).
+#include "kernels.h"
+
+namespace sagen {
+
+// -----------------------------------------------------------------------------------------
+// contrib batch_norm, training mode (core.py:6,209-210): per-tile partial (sum, sumsq) ->
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale; biased variance.
+// One 64-lane wave per channel; fp64 accumulation of the fp32 partials.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ stats, int n_tiles, double inv_count,
+                                                         int C, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = lane; t < n_tiles; t += 64) {
+        s += (double)stats[((long)t * 2 + 0) * C + c];
+        q += (double)stats[((long)t * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
+    }
+    if (lane == 0) {
+        const double mean = s * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double sc = (double)gamma[c] / sqrt(var + (double)eps);
+        scale[c] = (float)sc;
+        shift[c] = (float)((double)beta[c] - mean * sc);
+    }
+}
+
+int bn_finalize_launch(const float* stats, int n_tiles, long count, int C, const float* gamma, const float* beta,
+                       float eps, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, stats, n_tiles, 1.0 / (double)count, C, gamma, beta,
+                       eps, scale, shift);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// y = relu(x*scale[c] + shift[c] (+ residual))   (resnet.py:221,235)
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
+                                                            const float4* __restrict__ shift,
+                                                            const float4* __restrict__ res, float4* __restrict__ y,
+                                                            long n4, int C4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        float4 v = x[i];
+        if (scale) {
+            const float4 sc = scale[c], sh = shift[c];
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        }
+        if (res) {
+            const float4 r = res[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        y[i] = v;
+    }
+}
+
+int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                         long n_pixels, int C, hipStream_t s) {
+    if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "bn_apply_relu: C=%d must be a multiple of 4", C);
+    const long n4 = n_pixels * (C / 4);
+    const int grid = (int)std::min<long>(cdiv(n4, 256), 256L * 16);
+    hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, s, (const float4*)x, (const float4*)scale,
+                       (const float4*)shift, (const float4*)residual, (float4*)y, n4, C / 4);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// tf.nn.max_pool(x,[1,3,3,1],[1,2,2,1],'SAME') (resnet.py:135) of relu(bn(x)); TF SAME pads
+// (0 before, 1 after) for even H/W -> window rows 2*ho .. 2*ho+2 clipped at the border (-inf pad).
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
+                                                           const float4* __restrict__ shift, float4* __restrict__ y,
+                                                           int B, int H, int W, int C4, int Ho, int Wo, int pt, int pl) {
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) { sc = scale[c]; sh = shift[c]; }
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int h = ho * 2 + dy - pt;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int w = wo * 2 + dx - pl;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float4 v = x[(((long)b * H + h) * W + w) * C4 + c];
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        if (scale) {   // relu commutes with max
+            m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f);
+        }
+        y[i] = m;
+    }
+}
+
+int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, float* y, int B, int H, int W, int C,
+                        hipStream_t s) {
+    if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool: C=%d must be a multiple of 4", C);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
+    const long total = (long)B * Ho * Wo * (C / 4);
+    const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, (const float4*)x, (const float4*)scale,
+                       (const float4*)shift, (float4*)y, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// [B,H,W,3] -> [B,H+pt+pb,W+pl+pr,4] with zero border and zero 4th channel: the 7x7/2 SAME conv of
+// ResNet18 (resnet.py:133) then runs as a VALID conv over 16-byte pixels.
+__global__ __launch_bounds__(256) void pad_nhwc3to4_kernel(const float* __restrict__ x, float4* __restrict__ y, int B, int H,
+                                                           int W, int Hp, int Wp, int pt, int pl) {
+    const long total = (long)B * Hp * Wp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i;
+        const int w = (int)(p % Wp) - pl; p /= Wp;
+        const int h = (int)(p % Hp) - pt;
+        const int b = (int)(p / Hp);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            const float* src = x + (((long)b * H + h) * W + w) * 3;
+            v.x = src[0]; v.y = src[1]; v.z = src[2];
+        }
+        y[i] = v;
+    }
+}
+
+int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s) {
+    const int Hp = H + pt + pb, Wp = W + pl + pr;
+    const long total = (long)B * Hp * Wp;
+    const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
+    hipLaunchKernelGGL(pad_nhwc3to4_kernel, dim3(grid), dim3(256), 0, s, x, (float4*)y, B, H, W, Hp, Wp, pt, pl);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// deploy.py:143-152: [mono[b, snd_contx/2 + n] | Y Z X]
+__global__ __launch_bounds__(256) void assemble_wyzx_kernel(const float* __restrict__ audio, const float* __restrict__ yzx,
+                                                            float4* __restrict__ out, int B, int snd_size, int ss,
+                                                            int snd_dur) {
+    const long total = (long)B * snd_dur;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / snd_dur), n = (int)(i - (long)b * snd_dur);
+        const float* p = yzx + i * 3;
+        out[i] = make_float4(audio[(long)b * snd_size + ss + n], p[0], p[1], p[2]);
+    }
+}
+
+int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size, int snd_contx,
+                         int snd_dur, hipStream_t s) {
+    const long total = (long)B * snd_dur;
+    hipLaunchKernelGGL(assemble_wyzx_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, audio, yzx, (float4*)out, B,
+                       snd_size, snd_contx / 2, snd_dur);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// NO_SEPARATION (model.py:274-280, 430): x_sep = mono crop; one track
+__global__ __launch_bounds__(256) void nosep_mix_kernel(const float* __restrict__ audio, const float* __restrict__ coeffs,
+                                                        float* __restrict__ out, int B, int snd_size, int ss, int snd_dur,
+                                                        int num_out) {
+    const long total = (long)B * snd_dur * num_out;
+    const int step_len = snd_dur / 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int o = (int)(i % num_out);
+        long p = i / num_out;
+        const int n = (int)(p % snd_dur);
+        const int b = (int)(p / snd_dur);
+        const float* cf = coeffs + (((long)b * 3 + n / step_len) * num_out + o) * 2;   // [B,3,o,(w,bias)]
+        out[i] = fmaf(cf[0], audio[(long)b * snd_size + ss + n], cf[1]);
+    }
+}
+
+int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B, int snd_size, int snd_contx,
+                     int snd_dur, int num_out, hipStream_t s) {
+    const long total = (long)B * snd_dur * num_out;
+    hipLaunchKernelGGL(nosep_mix_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, audio, coeffs, out, B, snd_size,
+                       snd_contx / 2, snd_dur, num_out);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// Ambisonic power map (decoder.py:24-28 'projection', distance.py:41-52):
+// rms[p] = sqrt(mean_t (sum_c ambi[t,c] * sh[p,c])^2).  Expanded as the 4x4 second-moment matrix
+// S = sum_t ambi^T ambi (one wavefront-reduced pass over the audio, DPP/shuffle tree), then
+// rms[p] = sqrt(sh[p] S sh[p]^T / T) — the audio is read exactly once whatever the mesh size.
+__global__ __launch_bounds__(256) void power_moments_kernel(const float4* __restrict__ ambi, long T, double* __restrict__ S) {
+    float m[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m[k] = 0.f;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < T; t += (long)gridDim.x * 256) {
+        const float4 a = ambi[t];
+        m[0] += a.x * a.x; m[1] += a.x * a.y; m[2] += a.x * a.z; m[3] += a.x * a.w;
+        m[4] += a.y * a.y; m[5] += a.y * a.z; m[6] += a.y * a.w;
+        m[7] += a.z * a.z; m[8] += a.z * a.w; m[9] += a.w * a.w;
+    }
+    __shared__ float red[4][10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        float v = m[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const double v = (double)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(&S[threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void power_map_kernel(const double* __restrict__ S, double inv_T, const float4* __restrict__ sh,
+                                                        int P, float* __restrict__ rms) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float4 y = sh[p];
+    const double v[4] = {y.x, y.y, y.z, y.w};
+    const double s[4][4] = {{S[0], S[1], S[2], S[3]}, {S[1], S[4], S[5], S[6]}, {S[2], S[5], S[7], S[8]}, {S[3], S[6], S[8], S[9]}};
+    double e = 0.0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) e += v[i] * s[i][j] * v[j];
+    rms[p] = (float)sqrt(fmax(e, 0.0) * inv_T);
+}
+
+// scratch for the moments lives at the head of rms' caller-provided buffer? No: keep it explicit.
+int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s) {
+    // 10 doubles of scratch are taken from a static per-device buffer allocated lazily would break
+    // the "no allocation" rule; instead the caller's rms buffer must hold P floats + 32 extra floats
+    // (documented in sagen.h): the moments are accumulated in rms[P .. P+20).
+    double* S = reinterpret_cast<double*>(rms + ((P + 1) / 2) * 2);
+    SAGEN_HIP_CHECK(hipMemsetAsync(S, 0, 10 * sizeof(double), s));
+    const int grid = (int)std::min<long>(cdiv(T, 256), 1024L);
+    hipLaunchKernelGGL(power_moments_kernel, dim3(grid), dim3(256), 0, s, (const float4*)ambi, T, S);
+    SAGEN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(power_map_kernel, dim3(cdiv(P, 256)), dim3(256), 0, s, S, 1.0 / (double)T, (const float4*)sh, P, rms);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+}  // namespace sagen

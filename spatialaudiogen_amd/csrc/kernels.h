@@ -1,0 +1,97 @@
+// Launcher declarations of every HIP kernel family of the path (gfx950).
+#pragma once
+#include "common.h"
+
+namespace sagen {
+
+// -----------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on fp32 MFMA (igemm.hip).  One kernel serves every contraction of
+// the path: VALID/SAME convs, 1x1 strided shortcuts, FCs, and conv2d_transpose written as a
+// stride-1 conv with a depth-to-space epilogue.
+//
+//   out[m, n] = sum_k A[m, k] * Wp[n, k],   m = (b, a, bb) over the output GRID,
+//   k = (tap, c):  A[m,k] = f(x[b, a*in_sh + dh(tap), bb*in_sw + dw(tap), c])  (0 outside),
+//   f = identity or relu(v*in_scale[c] + in_shift[c]) (previous layer's batch-norm),
+//   n = (ry, rx, o): stored at y[b, a*dsh + ry, bb*dsw + rx, o] (+bias[o], optional ReLU).
+// -----------------------------------------------------------------------------------------
+struct IgemmDesc {
+    const float* x = nullptr;         // input, channel offset already applied
+    const float* w = nullptr;         // packed filter [Npad][Kpad], k contiguous, zero padded
+    float* y = nullptr;               // output, channel / row offset already applied
+    const float* bias = nullptr;      // [Cout] or null
+    const float* in_scale = nullptr;  // [Cin] or null
+    const float* in_shift = nullptr;
+    float* stats = nullptr;           // [gridM][2][N] per-tile (sum, sumsq) of raw output, or null
+    float* splitk_ws = nullptr;       // [splitk][M][N] when splitk > 1
+    int M = 0, N = 0, K = 0, Kpad = 0;
+    // output grid
+    int Hg = 1, Wg = 1, g_h0 = 0, g_w0 = 0;
+    // input
+    int Hin = 1, Win = 1, Cin = 0, ldx = 0;
+    long x_bstride = 0;
+    int in_sh = 1, in_sw = 1;
+    // taps: tap -> (th, tw) = (tap / TW, tap % TW); dh = th*tap_sh + tap_h0; dw = tw*tap_sw + tap_w0
+    int ntaps = 1, TW = 1, tap_sh = 1, tap_sw = 1, tap_h0 = 0, tap_w0 = 0;
+    int log2Cin = -1;                 // required (>=2) when ntaps > 1
+    // output (depth-to-space factors dsh x dsw; N = dsh*dsw*Cout)
+    int dsh = 1, dsw = 1, Cout = 0;
+    int Hlim = 1, Wlim = 1;           // valid output coordinates: Y < Hlim, X < Wlim
+    long y_bstride = 0;
+    long y_rstride = 0;               // elements per output row (Wout * ldy)
+    int ldy = 0;
+    int relu_out = 0;
+    int splitk = 1;
+};
+
+// tile configurations (BM x BN, 4 waves)
+enum IgemmTile { TILE_128x128 = 0, TILE_128x64, TILE_256x64, TILE_64x64, TILE_128x32, TILE_32x128, TILE_AUTO };
+
+int igemm_launch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);
+int igemm_grid_m(const IgemmDesc& d, IgemmTile tile);       // number of M tiles (stats rows)
+IgemmTile igemm_pick_tile(const IgemmDesc& d);
+// out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep)
+int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
+                         float* y, int ldy, int rep, hipStream_t s);
+
+// filter repacking (pack.hip).  All produce [Npad][Kpad] with zero padding.
+// conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src)
+int pack_conv_launch(const float* w_hwio, int ntaps, int cin_src, int cin_pad, int cout,
+                     float* wp, int Npad, int Kpad, hipStream_t s);
+// deconv as depth-to-space conv: n = (ry, rx, o), k = (dp, dq, c);
+// Wp[n][k] = W[ry + sh*dp][rx + sw*dq][o][c] (0 when outside the kh x kw kernel)
+int pack_deconv_launch(const float* w_hwoi, int kh, int kw, int cout, int cin, int sh, int sw,
+                       float* wp, int Npad, int Kpad, hipStream_t s);
+
+// -----------------------------------------------------------------------------------------
+// batch-norm / elementwise (elementwise.hip)
+// -----------------------------------------------------------------------------------------
+int bn_finalize_launch(const float* stats, int n_tiles, long count, int C, const float* gamma,
+                       const float* beta, float eps, float* scale, float* shift, hipStream_t s);
+int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const float* residual,
+                         float* y, long n_pixels, int C, hipStream_t s);
+int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, float* y,
+                        int B, int H, int W, int C, hipStream_t s);
+// [B,H,W,3] -> zero-bordered [B,H+pt+pb,W+pl+pr,4]
+int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr,
+                        hipStream_t s);
+int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
+                         int snd_contx, int snd_dur, hipStream_t s);
+int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);
+// NO_SEPARATION decoder (model.py:274-280, 430): out[b,n,o] = w[b,step,o,0]*mono + bias
+int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B, int snd_size,
+                     int snd_contx, int snd_dur, int num_out, hipStream_t s);
+
+// -----------------------------------------------------------------------------------------
+// FFT family (fft.hip)
+// -----------------------------------------------------------------------------------------
+// fills the twiddle / Hann tables once per device (first call synchronises the stream)
+int fft_tables_ensure(hipStream_t s);
+int stft_launch(const float* audio, int B, int n_samples, int f0, int f1, float* mag,
+                int c0, int c1, float* spec, hipStream_t s);
+// frames: scratch [B][NF][3][1024]; see fft.hip
+size_t mask_istft_scratch_bytes(int B);
+int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, const float* spec,
+                          const float* coeffs, int B, int ntracks, float* out, float* scratch,
+                          hipStream_t s);
+
+}  // namespace sagen

@@ -1,0 +1,621 @@
+// sagen_ctx: the native runtime of the inference path — variable inventory, workspace carving,
+// filter repacking and the launch sequence that replaces one sess.run of
+// SptAudioGen.inference_ops (reference model.py:356-434; called at deploy.py:141, eval.py:145).
+#include "kernels.h"
+#include <map>
+#include <string>
+#include <vector>
+
+namespace sagen {
+
+struct VarSpec {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    long numel() const {
+        long n = 1;
+        for (int i = 0; i < ndim; ++i) n *= shape[i];
+        return n;
+    }
+};
+
+struct Buf {            // region of the workspace, in floats
+    size_t off = 0, n = 0;
+};
+
+struct Named {          // intermediate exposed to parity tests
+    Buf buf;
+    size_t extra_off = 0;          // float offset inside buf (channel offset of a concat buffer)
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int64_t pixel_stride = 0;
+};
+
+static const int AENC_F[5] = {32, 64, 128, 256, 512};
+static const int AENC_K[5][2] = {{7, 16}, {3, 7}, {3, 5}, {3, 5}, {3, 5}};
+static const int AENC_S[5][2] = {{4, 8}, {2, 4}, {2, 2}, {1, 1}, {1, 1}};
+
+}  // namespace sagen
+
+using namespace sagen;
+
+struct sagen_ctx {
+    sagen_config cfg;
+    int B = 0;
+    int snd_size = 52799, snd_contx = 48000, snd_dur = 4800;
+    int enc_h[6], enc_w[6], enc_c[6];   // audio encoder pyramid (index 0 = magnitude)
+    int Cb = 0;                         // bottleneck width
+    int nsep = 32;
+    bool has_video = false, has_flow = false, freq_mask = true;
+
+    std::vector<VarSpec> vars;
+    std::map<std::string, int> var_index;
+    std::vector<const float*> var_ptr;
+    bool bound = false;
+
+    // workspace
+    size_t ws_floats = 0;
+    float* ws = nullptr;
+    std::map<std::string, Buf> bufs;
+    std::map<std::string, Named> named;
+
+    Buf alloc(const std::string& name, size_t n) {
+        Buf b;
+        b.off = ws_floats;
+        b.n = n;
+        ws_floats += (n + 63) / 64 * 64;     // 256-byte granules
+        bufs[name] = b;
+        return b;
+    }
+    float* p(const std::string& name) const { return ws + bufs.at(name).off; }
+    const float* v(const std::string& name) const { return var_ptr[var_index.at(name)]; }
+    void add_var(const std::string& name, std::initializer_list<int64_t> shape) {
+        VarSpec s;
+        s.name = name;
+        s.ndim = (int)shape.size();
+        int i = 0;
+        for (auto d : shape) s.shape[i++] = d;
+        for (; i < 4; ++i) s.shape[i] = 1;
+        var_index[name] = (int)vars.size();
+        vars.push_back(s);
+    }
+    void expose(const std::string& name, const std::string& buf, size_t extra, std::initializer_list<int64_t> shape,
+                int64_t pixel_stride) {
+        Named nm;
+        nm.buf = bufs.at(buf);
+        nm.extra_off = extra;
+        nm.ndim = (int)shape.size();
+        int i = 0;
+        for (auto d : shape) nm.shape[i++] = d;
+        nm.pixel_stride = pixel_stride;
+        named[name] = nm;
+    }
+};
+
+namespace sagen {
+
+static void add_resnet_vars(sagen_ctx* c, const std::string& scope) {
+    auto bn = [&](const std::string& p, int ch) {
+        for (const char* leaf : {"beta", "gamma", "moving_mean", "moving_variance"}) c->add_var(p + "/bn/" + leaf, {ch});
+    };
+    c->add_var(scope + "/conv1/conv/weights", {7, 7, 3, 64});
+    bn(scope + "/conv1/conv", 64);
+    int cin = 64;
+    const int couts[4] = {64, 128, 256, 512};
+    for (int st = 0; st < 4; ++st) {
+        const int cout = couts[st];
+        for (int unit = 1; unit <= 2; ++unit) {
+            const std::string pfx = scope + "/conv" + std::to_string(st + 2) + "_" + std::to_string(unit);
+            if (unit == 1 && cin != cout) c->add_var(pfx + "/shortcut/weights", {1, 1, cin, cout});
+            c->add_var(pfx + "/conv_1/weights", {3, 3, cin, cout});
+            bn(pfx + "/conv_1", cout);
+            c->add_var(pfx + "/conv_2/weights", {3, 3, cout, cout});
+            bn(pfx + "/conv_2", cout);
+            cin = cout;
+        }
+    }
+}
+
+static size_t packed_floats(long N, long K) { return (size_t)N * ((K + 15) / 16 * 16); }
+
+// choose a split-K factor for low-parallelism contractions (>= ~2 workgroups per CU, >= 8 K tiles per split)
+static int auto_splitk(const IgemmDesc& d, IgemmTile tile) {
+    const int bm = (tile == TILE_32x128) ? 32 : 64, bn = (tile == TILE_32x128) ? 128 : 64;
+    const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn);
+    const int nk = d.Kpad / 16;
+    if (blocks >= 384 || nk < 16) return 1;
+    int sk = (int)std::min<long>({(512 + blocks - 1) / blocks, (long)nk / 8, 64L});
+    return std::max(sk, 1);
+}
+
+}  // namespace sagen
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
+    if (!out || !cfg) return fail(SAGEN_ERR_NULL, "sagen_create: null argument");
+    if (cfg->batch <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_create: batch=%d", cfg->batch);
+    if (!(cfg->encoders & SAGEN_ENC_AUDIO))
+        return fail(SAGEN_ERR_UNSUPPORTED, "the audio encoder is mandatory (reference model.py:207)");
+    if (cfg->audio_rate != 48000 || cfg->video_rate != 10 || cfg->context != 1.0f || cfg->sample_duration != 0.1f ||
+        cfg->ambi_order != 1 || cfg->fft_window != 0.025f)
+        return fail(SAGEN_ERR_UNSUPPORTED,
+                    "HIP path implements audio_rate=48000 video_rate=10 context=1.0 sample_duration=0.1 ambi_order=1 "
+                    "fft_window=0.025 (the geometry of every BASELINE config)");
+    if (cfg->separation != SAGEN_SEP_NONE && cfg->separation != SAGEN_SEP_FREQ_MASK)
+        return fail(SAGEN_ERR_UNSUPPORTED, "unknown separation mode %d", cfg->separation);
+    if (cfg->separation == SAGEN_SEP_FREQ_MASK && cfg->num_sep_tracks != 16 && cfg->num_sep_tracks != 32 &&
+        cfg->num_sep_tracks != 64)
+        return fail(SAGEN_ERR_UNSUPPORTED, "num_sep_tracks=%d (supported 16/32/64)", cfg->num_sep_tracks);
+    if (cfg->n_loc_units < 0 || cfg->n_loc_units > 4) return fail(SAGEN_ERR_SHAPE, "n_loc_units=%d", cfg->n_loc_units);
+    for (int i = 0; i < cfg->n_loc_units; ++i)
+        if (cfg->loc_units[i] <= 0 || cfg->loc_units[i] % 4) return fail(SAGEN_ERR_UNSUPPORTED, "loc_units[%d]=%d must be a positive multiple of 4", i, cfg->loc_units[i]);
+
+    sagen_ctx* c = new sagen_ctx();
+    c->cfg = *cfg;
+    c->B = cfg->batch;
+    c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
+    c->has_flow = cfg->encoders & SAGEN_ENC_FLOW;
+    c->freq_mask = cfg->separation == SAGEN_SEP_FREQ_MASK;
+    c->nsep = c->freq_mask ? cfg->num_sep_tracks : 1;
+    const int B = c->B;
+
+    // audio encoder pyramid (model.py:161-187), H = frames 46:173, W = 1024 bins
+    c->enc_h[0] = 127; c->enc_w[0] = 1024; c->enc_c[0] = 1;
+    for (int l = 0; l < 5; ++l) {
+        c->enc_h[l + 1] = (c->enc_h[l] - AENC_K[l][0]) / AENC_S[l][0] + 1;
+        c->enc_w[l + 1] = (c->enc_w[l] - AENC_K[l][1]) / AENC_S[l][1] + 1;
+        c->enc_c[l + 1] = AENC_F[l];
+    }
+    c->Cb = 1024 + (c->has_video ? 512 : 0) + (c->has_flow ? 512 : 0);
+
+    // ---- variable inventory ----
+    {
+        int cin = 1;
+        for (int l = 0; l < 5; ++l) {
+            const std::string n = "audio_encoder/conv" + std::to_string(l + 1);
+            c->add_var(n + "/weights", {AENC_K[l][0], AENC_K[l][1], cin, AENC_F[l]});
+            c->add_var(n + "/biases", {AENC_F[l]});
+            cin = AENC_F[l];
+        }
+        if (c->has_video) add_resnet_vars(c, "video_encoder");
+        if (c->has_flow) add_resnet_vars(c, "flow_encoder");
+        c->add_var("bottleneck/audio-fc/weights", {c->enc_w[5] * c->enc_c[5], 1024});
+        c->add_var("bottleneck/audio-fc/biases", {1024});
+        for (const char* e : {"video", "flow"}) {
+            if ((std::string(e) == "video" && !c->has_video) || (std::string(e) == "flow" && !c->has_flow)) continue;
+            c->add_var(std::string("bottleneck/") + e + "-fc-red/weights", {512, 128});
+            c->add_var(std::string("bottleneck/") + e + "-fc-red/biases", {128});
+            c->add_var(std::string("bottleneck/") + e + "-fc/weights", {7 * 14 * 128, 512});
+            c->add_var(std::string("bottleneck/") + e + "-fc/biases", {512});
+        }
+        int fin = c->Cb;
+        for (int i = 0; i < cfg->n_loc_units; ++i) {
+            const std::string n = "localization/fc" + std::to_string(i + 1);
+            c->add_var(n + "/weights", {fin, cfg->loc_units[i]});
+            c->add_var(n + "/biases", {cfg->loc_units[i]});
+            fin = cfg->loc_units[i];
+        }
+        const int nlast = 3 * 1 * (c->nsep + 1);
+        const std::string n = "localization/fc" + std::to_string(cfg->n_loc_units + 1);
+        c->add_var(n + "/weights", {fin, nlast});
+        c->add_var(n + "/biases", {nlast});
+        if (c->freq_mask) {
+            c->add_var("separation/fc-feats/weights", {c->Cb, 512});
+            c->add_var("separation/fc-feats/biases", {512});
+            const int nfs[5] = {c->nsep, 32, 64, 128, 256};
+            int dcin = 1024;
+            for (int l = 4; l >= 0; --l) {
+                const std::string dn = "separation/deconv" + std::to_string(l + 1);
+                c->add_var(dn + "/weights", {AENC_K[l][0], AENC_K[l][1], nfs[l], dcin});
+                c->add_var(dn + "/biases", {nfs[l]});
+                dcin = nfs[l] + (l > 0 ? AENC_F[l - 1] : 0);
+            }
+        }
+    }
+    c->var_ptr.assign(c->vars.size(), nullptr);
+
+    // ---- workspace carving ----
+    // packed filters
+    for (const auto& vs : c->vars) {
+        if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
+        size_t n;
+        if (vs.name.find("/deconv") != std::string::npos) {
+            const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
+            const int sh = AENC_S[l][0], sw = AENC_S[l][1];
+            const long taps = (long)cdiv(vs.shape[0], sh) * cdiv(vs.shape[1], sw);
+            n = packed_floats((long)sh * sw * vs.shape[2], taps * vs.shape[3]);
+        } else if (vs.ndim == 4) {
+            long cinp = vs.shape[2] == 3 ? 4 : vs.shape[2];
+            long taps = vs.shape[0] * vs.shape[1];
+            if (vs.shape[2] == 1) { cinp = vs.shape[1]; taps = vs.shape[0]; }   // audio conv1: kw acts as channels
+            n = packed_floats(vs.shape[3], taps * cinp);
+        } else {
+            n = packed_floats(vs.shape[1], vs.shape[0]);
+        }
+        c->alloc("pk:" + vs.name, n);
+    }
+    // activations
+    c->alloc("mag", (size_t)B * 127 * 1024);
+    c->alloc("spec", (size_t)B * 28 * 513 * 2);
+    // concat buffers cat_l: [B, H_l, W_l, C_dec + C_enc]; cat5 = [conv5 | fc-feats]
+    for (int l = 1; l <= 5; ++l)
+        c->alloc("cat" + std::to_string(l), (size_t)B * c->enc_h[l] * c->enc_w[l] * 2 * c->enc_c[l]);
+    c->alloc("bott", (size_t)B * 3 * c->Cb);
+    for (int i = 0; i < cfg->n_loc_units; ++i) c->alloc("loc" + std::to_string(i + 1), (size_t)B * 3 * cfg->loc_units[i]);
+    c->alloc("coeffs", (size_t)B * 3 * 3 * (c->nsep + 1));
+    c->alloc("splitk", (size_t)16 << 20);            // 64 MB of fp32 partials, checked per use
+    if (c->freq_mask) {
+        c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
+        c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
+    }
+    if (c->has_video || c->has_flow) {
+        c->alloc("xpad", (size_t)B * 229 * 453 * 4);
+        c->alloc("y0", (size_t)B * 112 * 224 * 64);
+        const size_t stage = (size_t)B * 56 * 112 * 64;
+        for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc"}) c->alloc(nm, stage);
+        c->alloc("stats", (size_t)cdiv((long)B * 112 * 224, 128) * 2 * 64 + 4096);
+        c->alloc("bnp", (size_t)24 * 2 * 512);        // scale/shift per BN layer of one stream
+        c->alloc("fcred", (size_t)B * 98 * 128);
+    }
+    // intermediates for parity tests
+    c->expose("mag", "mag", 0, {B, 127, 1024, 1}, 1);
+    c->expose("stft", "spec", 0, {B, 28, 513, 2}, 2);
+    for (int l = 1; l <= 5; ++l) {
+        const int ce = c->enc_c[l];
+        c->expose("audio_encoder/conv" + std::to_string(l), "cat" + std::to_string(l), l == 5 ? 0 : ce,
+                  {B, c->enc_h[l], c->enc_w[l], ce}, 2 * ce);
+    }
+    c->expose("bottleneck", "bott", 0, {B, 3, c->Cb}, c->Cb);
+    c->expose("localization/coeffs", "coeffs", 0, {B, 3, 3, c->nsep + 1}, c->nsep + 1);
+    if (c->freq_mask) c->expose("separation/deconv1", "dmask", 0, {B, 23, 1024, c->nsep}, c->nsep);
+    *out = c;
+    return SAGEN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bind: check + borrow the variables, repack filters into the workspace
+// ------------------------------------------------------------------------------------------------
+int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* workspace, size_t workspace_bytes,
+                    hipStream_t s) {
+    if (!c || !tensors || !workspace) return fail(SAGEN_ERR_NULL, "sagen_bind_weights: null argument");
+    if (workspace_bytes < c->ws_floats * sizeof(float))
+        return fail(SAGEN_ERR_WORKSPACE, "workspace has %zu bytes, need %zu", workspace_bytes, c->ws_floats * sizeof(float));
+    if (((uintptr_t)workspace) % 256) return fail(SAGEN_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    c->ws = (float*)workspace;
+    std::vector<const float*> ptr(c->vars.size(), nullptr);
+    for (int i = 0; i < n; ++i) {
+        const sagen_tensor& t = tensors[i];
+        if (!t.name || !t.data) return fail(SAGEN_ERR_NULL, "tensor %d has a null name or data pointer", i);
+        auto it = c->var_index.find(t.name);
+        if (it == c->var_index.end()) continue;     // checkpoint extras (Adam slots, step, metrics/*) are ignored
+        const VarSpec& vs = c->vars[it->second];
+        bool ok = t.ndim == vs.ndim;
+        for (int k = 0; ok && k < vs.ndim; ++k) ok = t.shape[k] == vs.shape[k];
+        if (!ok) return fail(SAGEN_ERR_WEIGHTS, "variable %s has the wrong shape", t.name);
+        if (((uintptr_t)t.data) % 16) return fail(SAGEN_ERR_WEIGHTS, "variable %s is not 16-byte aligned", t.name);
+        ptr[it->second] = t.data;
+    }
+    for (size_t i = 0; i < c->vars.size(); ++i) {
+        const std::string& nm = c->vars[i].name;
+        const bool moving = nm.find("/moving_") != std::string::npos;   // never read: BN runs in train mode (model.py:197)
+        if (!ptr[i] && !moving) return fail(SAGEN_ERR_WEIGHTS, "variable %s was not provided", nm.c_str());
+    }
+    c->var_ptr = ptr;
+    int rc = fft_tables_ensure(s);
+    if (rc) return rc;
+    // repack filters
+    for (const auto& vs : c->vars) {
+        if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
+        const float* src = c->v(vs.name);
+        float* dst = c->p("pk:" + vs.name);
+        if (vs.name.find("/deconv") != std::string::npos) {
+            const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
+            const int sh = AENC_S[l][0], sw = AENC_S[l][1];
+            const int taps = cdiv(vs.shape[0], sh) * cdiv(vs.shape[1], sw);
+            const int N = sh * sw * (int)vs.shape[2], K = taps * (int)vs.shape[3];
+            rc = pack_deconv_launch(src, (int)vs.shape[0], (int)vs.shape[1], (int)vs.shape[2], (int)vs.shape[3], sh, sw, dst,
+                                    N, (K + 15) / 16 * 16, s);
+        } else if (vs.ndim == 4) {
+            int cin = (int)vs.shape[2], cinp = cin == 3 ? 4 : cin, taps = (int)(vs.shape[0] * vs.shape[1]);
+            if (cin == 1) { cin = cinp = (int)vs.shape[1]; taps = (int)vs.shape[0]; }
+            const int K = taps * cinp;
+            rc = pack_conv_launch(src, taps, cin, cinp, (int)vs.shape[3], dst, (int)vs.shape[3], (K + 15) / 16 * 16, s);
+        } else {
+            const int K = (int)vs.shape[0], N = (int)vs.shape[1];
+            rc = pack_conv_launch(src, 1, K, K, N, dst, N, (K + 15) / 16 * 16, s);
+        }
+        if (rc) return rc;
+    }
+    c->bound = true;
+    return SAGEN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+namespace sagen {
+
+struct Fwd {
+    sagen_ctx* c;
+    hipStream_t s;
+    int rc = SAGEN_OK;
+
+    // run one contraction, through split-K + reduce when parallelism is low or rows are replicated
+    void gemm(IgemmDesc d, int rep = 1, bool allow_split = true) {
+        if (rc) return;
+        IgemmTile tile = igemm_pick_tile(d);
+        const bool plain = d.dsh * d.dsw == 1 && !d.stats;
+        int sk = (plain && allow_split) ? auto_splitk(d, tile) : 1;
+        if (rep > 1 && !plain) { rc = fail(SAGEN_ERR_UNSUPPORTED, "replicated store needs a plain epilogue"); return; }
+        if (sk > 1 || rep > 1) {
+            const Buf& wsb = c->bufs.at("splitk");
+            while (sk > 1 && (size_t)sk * d.M * d.N > wsb.n) --sk;
+            if ((size_t)sk * d.M * d.N > wsb.n) { rc = fail(SAGEN_ERR_WORKSPACE, "split-K scratch too small"); return; }
+            // the reduce kernel applies bias / activation / row replication with a dense [M][N] -> pixel mapping
+            if (d.Hg * d.Wg * (long)d.ldy != d.y_bstride && d.M > d.Hg * d.Wg) { rc = fail(SAGEN_ERR_UNSUPPORTED, "split-K needs dense output rows"); return; }
+            IgemmDesc e = d;
+            e.splitk = sk;
+            e.splitk_ws = c->ws + wsb.off;
+            e.bias = nullptr;
+            e.relu_out = 0;
+            rc = igemm_launch(e, tile, s);
+            if (rc) return;
+            rc = splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, s);
+        } else {
+            rc = igemm_launch(d, tile, s);
+        }
+    }
+
+    // tfw.conv_2d geometry (core.py:156-220): dense NHWC input/output with pixel strides
+    IgemmDesc conv_desc(const float* x, int Hin, int Win, int Cin, int ldx, const float* wp, int kh, int kw, int sh, int sw,
+                        bool same, int Cout, float* y, int ldy, int& Hout, int& Wout) {
+        IgemmDesc d;
+        int pt = 0, pl = 0;
+        if (same) {
+            Hout = cdiv(Hin, sh); Wout = cdiv(Win, sw);
+            pt = std::max((Hout - 1) * sh + kh - Hin, 0) / 2;
+            pl = std::max((Wout - 1) * sw + kw - Win, 0) / 2;
+        } else {
+            Hout = (Hin - kh) / sh + 1; Wout = (Win - kw) / sw + 1;
+        }
+        d.x = x; d.w = wp; d.y = y;
+        d.M = c->B * Hout * Wout; d.N = Cout; d.K = kh * kw * Cin; d.Kpad = (d.K + 15) / 16 * 16;
+        d.Hg = Hout; d.Wg = Wout;
+        d.Hin = Hin; d.Win = Win; d.Cin = Cin; d.ldx = ldx; d.x_bstride = (long)Hin * Win * ldx;
+        d.in_sh = sh; d.in_sw = sw;
+        d.ntaps = kh * kw; d.TW = kw; d.tap_sh = 1; d.tap_sw = 1; d.tap_h0 = -pt; d.tap_w0 = -pl;
+        d.log2Cin = ilog2_exact(Cin);
+        d.Cout = Cout; d.Hlim = Hout; d.Wlim = Wout;
+        d.ldy = ldy; d.y_rstride = (long)Wout * ldy; d.y_bstride = (long)Hout * Wout * ldy;
+        return d;
+    }
+
+    // tfw.fully_connected (core.py:43-93) on dense rows
+    void fc(const float* x, int M, int K, int ldx, const std::string& name, int N, bool relu, float* y, int ldy, int rep = 1) {
+        IgemmDesc d;
+        d.x = x; d.w = c->p("pk:" + name + "/weights"); d.y = y; d.bias = c->v(name + "/biases");
+        d.M = M; d.N = N; d.K = K; d.Kpad = (K + 15) / 16 * 16;
+        d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = K; d.ldx = ldx; d.x_bstride = ldx;
+        d.ntaps = 1; d.Cout = N; d.Hlim = 1; d.Wlim = 1; d.ldy = ldy; d.y_rstride = ldy; d.y_bstride = ldy;
+        d.relu_out = relu;
+        gemm(d, rep);
+    }
+
+    // tfw.deconv_2d (core.py:96-153) as a stride-1 conv with a depth-to-space epilogue
+    void deconv(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int a0, int a1, int Ylim,
+                long y_bstride, long y_row0) {
+        const std::string name = "separation/deconv" + std::to_string(l + 1);
+        const int kh = AENC_K[l][0], kw = AENC_K[l][1], sh = AENC_S[l][0], sw = AENC_S[l][1];
+        const int Cout = l == 0 ? c->nsep : AENC_F[l - 1];
+        const int Hout = Hin * sh + kh - sh, Wout = Win * sw + kw - sw;
+        const int nth = cdiv(kh, sh), ntw = cdiv(kw, sw);
+        IgemmDesc d;
+        d.x = x; d.w = c->p("pk:" + name + "/weights"); d.bias = c->v(name + "/biases");
+        d.Hg = (a1 > a0 ? a1 - a0 : cdiv(Hout, sh)); d.g_h0 = a0; d.Wg = cdiv(Wout, sw);
+        d.M = c->B * d.Hg * d.Wg; d.N = sh * sw * Cout; d.K = nth * ntw * Cin; d.Kpad = (d.K + 15) / 16 * 16;
+        d.Hin = Hin; d.Win = Win; d.Cin = Cin; d.ldx = Cin; d.x_bstride = (long)Hin * Win * Cin;
+        d.ntaps = nth * ntw; d.TW = ntw; d.tap_sh = -1; d.tap_sw = -1; d.log2Cin = ilog2_exact(Cin);
+        d.dsh = sh; d.dsw = sw; d.Cout = Cout;
+        d.Hlim = Ylim > 0 ? Ylim : Hout; d.Wlim = Wout;
+        d.ldy = ldy; d.y_rstride = (long)Wout * ldy;
+        d.y_bstride = y_bstride > 0 ? y_bstride : (long)Hout * Wout * ldy;
+        d.y = y - y_row0 * d.y_rstride;
+        d.relu_out = relu;
+        gemm(d);
+    }
+
+    void bn_finalize(const IgemmDesc& d, IgemmTile tile, const std::string& bn_name, float* scale, float* shift) {
+        if (rc) return;
+        rc = bn_finalize_launch(d.stats, igemm_grid_m(d, tile), (long)d.M, d.N, c->v(bn_name + "/bn/gamma"),
+                                c->v(bn_name + "/bn/beta"), 1e-3f, scale, shift, s);
+    }
+
+    // conv (+BN statistics) of the ResNet trunk: raw output + scale/shift for the consumer
+    void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
+                 const float* in_scale, const float* in_shift, float* y, float* scale, float* shift, int& Hout, int& Wout) {
+        if (rc) return;
+        IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
+                                Cout, Hout, Wout);
+        d.in_scale = in_scale; d.in_shift = in_shift;
+        d.stats = c->p("stats");
+        IgemmTile tile = igemm_pick_tile(d);
+        if ((size_t)igemm_grid_m(d, tile) * 2 * d.N > c->bufs.at("stats").n) { rc = fail(SAGEN_ERR_WORKSPACE, "stats buffer too small"); return; }
+        rc = igemm_launch(d, tile, s);
+        bn_finalize(d, tile, name, scale, shift);
+    }
+
+    // ResNet18 -> conv5_2 in training-mode BN (resnet.py:123-236); returns the [B,7,14,512] output
+    const float* resnet(const float* img, const std::string& scope) {
+        const int B = c->B;
+        float* bnp = c->p("bnp");
+        int li = 0;
+        auto sc_of = [&](int i) { return bnp + (size_t)i * 1024; };
+        auto sh_of = [&](int i) { return bnp + (size_t)i * 1024 + 512; };
+        if (!rc) rc = pad_nhwc3to4_launch(img, c->p("xpad"), B, 224, 448, 2, 3, 2, 3, s);
+        // conv1 7x7/2 SAME == VALID on the padded 4-channel image
+        int H = 0, W = 0;
+        {
+            const std::string name = scope + "/conv1/conv";
+            IgemmDesc d = conv_desc(c->p("xpad"), 229, 453, 4, 4, c->p("pk:" + name + "/weights"), 7, 7, 2, 2, false, 64,
+                                    c->p("y0"), 64, H, W);
+            d.stats = c->p("stats");
+            IgemmTile tile = igemm_pick_tile(d);
+            if (!rc) rc = igemm_launch(d, tile, s);
+            bn_finalize(d, tile, name, sc_of(li), sh_of(li));
+            if (!rc) rc = maxpool3x3s2_launch(c->p("y0"), sc_of(li), sh_of(li), c->p("rx0"), B, H, W, 64, s);
+            ++li;
+            H = (H + 1) / 2; W = (W + 1) / 2;
+        }
+        float* xin = c->p("rx0");
+        float* xout = c->p("rx1");
+        int cin = 64;
+        const int couts[4] = {64, 128, 256, 512};
+        for (int st = 0; st < 4; ++st) {
+            const int cout = couts[st];
+            for (int unit = 1; unit <= 2; ++unit) {
+                const std::string pfx = scope + "/conv" + std::to_string(st + 2) + "_" + std::to_string(unit);
+                const bool first = unit == 1 && cin != cout;
+                const int stride = first ? 2 : 1;
+                int Ho = 0, Wo = 0;
+                const float* shortcut = xin;
+                if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
+                    IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
+                                            cout, c->p("rsc"), cout, Ho, Wo);
+                    gemm(d, 1, false);
+                    shortcut = c->p("rsc");
+                }
+                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, nullptr, nullptr, c->p("ry1"), sc_of(li), sh_of(li), Ho, Wo);
+                const int l1 = li++;
+                int H2, W2;
+                conv_bn(c->p("ry1"), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, sc_of(l1), sh_of(l1), c->p("ry2"), sc_of(li),
+                        sh_of(li), H2, W2);
+                if (!rc) rc = bn_apply_relu_launch(c->p("ry2"), sc_of(li), sh_of(li), shortcut, xout, (long)B * Ho * Wo, cout, s);
+                ++li;
+                std::swap(xin, xout);
+                H = Ho; W = Wo; cin = cout;
+            }
+        }
+        return xin;
+    }
+};
+
+}  // namespace sagen
+
+int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s) {
+    if (!c || !audio || !out) return fail(SAGEN_ERR_NULL, "sagen_forward: null argument");
+    if (!c->bound) return fail(SAGEN_ERR_WEIGHTS, "sagen_forward: weights are not bound");
+    if (c->has_video && !video) return fail(SAGEN_ERR_NULL, "sagen_forward: video encoder enabled but video is NULL");
+    if (c->has_flow && !flow) return fail(SAGEN_ERR_NULL, "sagen_forward: flow encoder enabled but flow is NULL");
+    const int B = c->B;
+    Fwd f{c, s};
+
+    // STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
+    f.rc = stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), s);
+
+    // audio encoder (model.py:161-187): conv l writes the encoder half of concat buffer l
+    for (int l = 0; l < 5 && !f.rc; ++l) {
+        const std::string name = "audio_encoder/conv" + std::to_string(l + 1);
+        const int ce = c->enc_c[l + 1];
+        float* y = c->p("cat" + std::to_string(l + 1)) + (l == 4 ? 0 : ce);
+        int Ho, Wo;
+        IgemmDesc d;
+        if (l == 0) {
+            // Cin = 1: the 16 taps along frequency are contiguous floats -> treat kw as 16 channels of a 7-tap conv
+            d = f.conv_desc(c->p("mag"), 127, 1024, 16, 1, c->p("pk:" + name + "/weights"), 7, 1, 4, 8, false, ce, y, 2 * ce, Ho, Wo);
+            Wo = c->enc_w[1];
+            d.M = B * Ho * Wo; d.Wg = Wo; d.Wlim = Wo;
+            d.y_rstride = (long)Wo * 2 * ce; d.y_bstride = (long)Ho * Wo * 2 * ce;
+        } else {
+            const int cp = c->enc_c[l];
+            const float* x = c->p("cat" + std::to_string(l)) + (l == 5 ? 0 : cp);
+            d = f.conv_desc(x, c->enc_h[l], c->enc_w[l], cp, 2 * cp, c->p("pk:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1],
+                            AENC_S[l][0], AENC_S[l][1], false, ce, y, 2 * ce, Ho, Wo);
+        }
+        d.bias = c->v(name + "/biases");
+        d.relu_out = 1;
+        f.gemm(d);
+    }
+
+    // bottleneck (model.py:203-239)
+    float* bott = c->p("bott");
+    {   // audio-fc over (w, c) of conv5: 6 taps along W, 512 channels each
+        IgemmDesc d;
+        d.x = c->p("cat5"); d.w = c->p("pk:bottleneck/audio-fc/weights"); d.y = bott; d.bias = c->v("bottleneck/audio-fc/biases");
+        d.M = B * 3; d.N = 1024; d.K = 6 * 512; d.Kpad = d.K;
+        d.Hg = 3; d.Wg = 1; d.Hin = 3; d.Win = 6; d.Cin = 512; d.ldx = 1024; d.x_bstride = 3L * 6 * 1024;
+        d.ntaps = 6; d.TW = 6; d.log2Cin = 9;
+        d.Cout = 1024; d.Hlim = 3; d.Wlim = 1; d.ldy = c->Cb; d.y_rstride = c->Cb; d.y_bstride = 3L * c->Cb;
+        d.relu_out = 1;
+        f.gemm(d);
+    }
+    int choff = 1024;
+    for (int e = 0; e < 2; ++e) {
+        const bool on = e == 0 ? c->has_video : c->has_flow;
+        if (!on) continue;
+        const std::string enc = e == 0 ? "video" : "flow";
+        const float* feat = f.resnet(e == 0 ? video : flow, enc + "_encoder");          // [B,7,14,512]
+        f.fc(feat, B * 98, 512, 512, "bottleneck/" + enc + "-fc-red", 128, true, c->p("fcred"), 128);
+        f.fc(c->p("fcred"), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
+        choff += 512;
+    }
+
+    // localization (model.py:241-271)
+    {
+        const float* x = bott;
+        int K = c->Cb;
+        for (int i = 0; i < c->cfg.n_loc_units; ++i) {
+            float* y = c->p("loc" + std::to_string(i + 1));
+            f.fc(x, B * 3, K, K, "localization/fc" + std::to_string(i + 1), c->cfg.loc_units[i], true, y, c->cfg.loc_units[i]);
+            x = y; K = c->cfg.loc_units[i];
+        }
+        const int nlast = 3 * (c->nsep + 1);
+        f.fc(x, B * 3, K, K, "localization/fc" + std::to_string(c->cfg.n_loc_units + 1), nlast, false, c->p("coeffs"), nlast);
+    }
+
+    if (!c->freq_mask) {
+        if (!f.rc) f.rc = nosep_mix_launch(audio, c->p("coeffs"), out, B, c->snd_size, c->snd_contx, c->snd_dur, 3, s);
+        return f.rc;
+    }
+
+    // separation (model.py:282-348)
+    f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6);     // tile over 6 freq columns
+    for (int l = 4; l >= 1; --l) {
+        const int Cin = 2 * c->enc_c[l + 1];
+        f.deconv(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
+                 2 * c->enc_c[l], true, 0, 0, 0, 0, 0);
+    }
+    // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16
+    f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44);
+    if (!f.rc)
+        f.rc = mask_istft_mix_launch(c->p("dmask"), 23L * 1024 * c->nsep, 1, c->p("spec"), c->p("coeffs"), B, c->nsep, out,
+                                     c->p("frames"), s);
+    return f.rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small accessors
+// ------------------------------------------------------------------------------------------------
+void sagen_destroy_impl(sagen_ctx* c) { delete c; }
+size_t sagen_workspace_bytes_impl(const sagen_ctx* c) { return c->ws_floats * sizeof(float); }
+int sagen_num_variables_impl(const sagen_ctx* c) { return (int)c->vars.size(); }
+int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32_t* ndim, int64_t shape[4]) {
+    if (i < 0 || i >= (int)c->vars.size()) return fail(SAGEN_ERR_SHAPE, "variable index %d out of range", i);
+    *name = c->vars[i].name.c_str();
+    *ndim = c->vars[i].ndim;
+    for (int k = 0; k < 4; ++k) shape[k] = c->vars[i].shape[k];
+    return SAGEN_OK;
+}
+int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
+                                int64_t* pixel_stride) {
+    if (!c->ws) return fail(SAGEN_ERR_WORKSPACE, "no workspace bound");
+    auto it = c->named.find(name);
+    if (it == c->named.end()) return fail(SAGEN_ERR_SHAPE, "unknown intermediate %s", name);
+    const Named& nm = it->second;
+    *data = c->ws + nm.buf.off + nm.extra_off;
+    *ndim = nm.ndim;
+    for (int k = 0; k < 4; ++k) shape[k] = nm.shape[k];
+    *pixel_stride = nm.pixel_stride;
+    return SAGEN_OK;
+}

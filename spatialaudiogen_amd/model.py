@@ -1,0 +1,199 @@
+"""SptAudioGen facade — same constructor and `inference_ops` signature as the reference class
+(model.py:24-60, 356-434), executing on libsagen_hip.so instead of building a TF1 graph.
+
+    net = SptAudioGen(ambi_order=1, encoders=['audio', 'video'], separation='unet_mask',
+                      params=SptAudioGenParams(sep_num_tracks=32, loc_fc_units=[512, 512]))
+    net.load_variables(P)                      # {TF checkpoint key: tensor/ndarray}  (deploy.py:79-87)
+    x_ambi = net.inference_ops(audio, video)   # audio [B,52799,1], video [B,1,224,448,3] -> [B,4800,3]
+"""
+import ctypes as C
+from collections import OrderedDict
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, SagenConfig, SagenTensor
+from .definitions import *   # noqa: F401,F403  (AUDIO/VIDEO/FLOW, separation modes, defaults)
+from .geometry import Geometry
+
+
+class SptAudioGenParams(object):
+    """reference model.py:10-21 (ctx_feats_fc_units / sep_freq_mask_fc_units are carried but, as in
+    the reference graph, unused by inference_ops)."""
+
+    def __init__(self, sep_num_tracks=NUM_SEP_TRACKS_DEF, ctx_feats_fc_units=CTX_FEATS_FCUNITS_DEF,
+                 loc_fc_units=LOC_FCUNITS_DEF, sep_freq_mask_fc_units=SEP_FREQ_MASK_FCUNITS_DEF,
+                 sep_fft_window=SEP_FFT_WINDOW_DEF):
+        self.sep_num_tracks = sep_num_tracks
+        self.ctx_feats_fc_units = ctx_feats_fc_units
+        self.loc_fc_units = loc_fc_units
+        self.sep_freq_mask_fc_units = sep_freq_mask_fc_units
+        self.sep_fft_window = sep_fft_window
+
+
+class _Ctx(object):
+    """One native context = one batch size (the TF graph is also built for a fixed batch)."""
+
+    def __init__(self, cfg, variables, device):
+        l = _lib.lib()
+        self.handle = C.c_void_p()
+        check(l.sagen_create(C.byref(self.handle), C.byref(cfg)))
+        self.batch = cfg.batch
+        nbytes = int(l.sagen_workspace_bytes(self.handle))
+        self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        n = l.sagen_num_variables(self.handle)
+        arr = (SagenTensor * n)()
+        keep = []
+        name, ndim, shape = C.c_char_p(), C.c_int32(), (C.c_int64 * 4)()
+        for i in range(n):
+            check(l.sagen_variable_spec(self.handle, i, C.byref(name), C.byref(ndim), shape))
+            key = name.value.decode()
+            if key not in variables:
+                if '/moving_' in key:      # never read: BN always runs in training mode (model.py:197)
+                    arr[i].name, arr[i].data, arr[i].ndim = name.value, None, ndim.value
+                    continue
+                raise KeyError('variable %s missing from the checkpoint dict' % key)
+            t = variables[key]
+            want = tuple(shape[k] for k in range(ndim.value))
+            if tuple(t.shape) != want:
+                raise ValueError('variable %s has shape %s, expected %s' % (key, tuple(t.shape), want))
+            keep.append(name.value)
+            arr[i].name = name.value
+            arr[i].data = t.data_ptr()
+            arr[i].ndim = ndim.value
+            for k in range(4):
+                arr[i].shape[k] = shape[k]
+        valid = [a for a in arr if a.data]
+        arr2 = (SagenTensor * len(valid))(*valid)
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        check(l.sagen_bind_weights(self.handle, arr2, len(valid), C.c_void_p(self.workspace.data_ptr()),
+                                   self.workspace.numel() * 4, stream))
+        self._keep = keep
+
+    def intermediate(self, name):
+        l = _lib.lib()
+        data, ndim, shape, ps = C.c_void_p(), C.c_int32(), (C.c_int64 * 4)(), C.c_int64()
+        check(l.sagen_get_intermediate(self.handle, name.encode(), C.byref(data), C.byref(ndim), shape, C.byref(ps)))
+        dims = [shape[k] for k in range(ndim.value)]
+        off = (data.value - self.workspace.data_ptr()) // 4
+        # strided view into the workspace (concat buffers hold two tensors side by side)
+        if ndim.value == 4:
+            st = [dims[1] * dims[2] * ps.value, dims[2] * ps.value, ps.value, 1]
+        elif ndim.value == 3:
+            st = [dims[1] * ps.value, ps.value, 1]
+        else:
+            raise ValueError(ndim.value)
+        return torch.as_strided(self.workspace, dims, st, off).clone()
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().sagen_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class SptAudioGen(object):
+    def __init__(self, ambi_order, audio_rate=48000, video_rate=10, context=1., sample_duration=0.1,
+                 encoders=None, separation='none', params=None, device=None):
+        params = params or SptAudioGenParams()
+        self.geom = Geometry(audio_rate=audio_rate, video_rate=video_rate, context=context,
+                             sample_duration=sample_duration, ambi_order=ambi_order,
+                             fft_window=params.sep_fft_window)        # asserts of model.py:33,42
+        self.ambi_order = ambi_order
+        self.num_ambi_channels = sum([2 * i + 1 for i in range(ambi_order + 1)])
+        self.snd_rate, self.vid_rate = audio_rate, video_rate
+        self.context, self.duration = context, sample_duration
+        self.snd_contx, self.snd_dur, self.snd_size = self.geom.snd_contx, self.geom.snd_dur, self.geom.snd_size
+        if encoders is None:
+            encoders = [AUDIO, VIDEO, FLOW]
+        assert isinstance(encoders, list)
+        assert all([e in ENCODERS for e in encoders])
+        if separation not in SEPARATION:
+            raise ValueError('Unknown separation mode.')                 # model.py:350
+        self.encoders = encoders
+        self.separation = separation
+        self.params = params
+        self.wind_size = self.geom.wind_size
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        self._variables = None
+        self._ctx = {}
+
+    # ---- weights (tf.train.Saver.restore, deploy.py:79-87) ---------------------------------
+    def variable_specs(self):
+        from .weights import variable_specs
+        return variable_specs(self.encoders, self.separation, self.params.sep_num_tracks,
+                              tuple(self.params.loc_fc_units), self.geom)
+
+    def load_variables(self, variables):
+        if self.device is None:
+            raise RuntimeError('SptAudioGen needs a ROCm device: there is no CPU implementation of the path')
+        specs = self.variable_specs()
+        dev = OrderedDict()
+        for k, shape in specs.items():
+            if k not in variables:
+                if '/moving_' in k:
+                    continue
+                raise KeyError('variable %s missing' % k)
+            t = torch.as_tensor(np.asarray(variables[k]) if not isinstance(variables[k], torch.Tensor) else variables[k])
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError('variable %s has shape %s, expected %s' % (k, tuple(t.shape), tuple(shape)))
+            dev[k] = t.to(device=self.device, dtype=torch.float32).contiguous()
+        self._variables = dev
+        self._ctx = {}
+
+    def _config(self, batch):
+        cfg = SagenConfig()
+        cfg.batch = batch
+        cfg.encoders = sum({AUDIO: 1, VIDEO: 2, FLOW: 4}[e] for e in set(self.encoders))
+        cfg.separation = {NO_SEPARATION: 0, FREQ_MASK: 1}[self.separation]
+        cfg.num_sep_tracks = self.params.sep_num_tracks
+        cfg.n_loc_units = len(self.params.loc_fc_units)
+        for i, u in enumerate(self.params.loc_fc_units):
+            cfg.loc_units[i] = u
+        cfg.ambi_order = self.ambi_order
+        cfg.audio_rate, cfg.video_rate = self.snd_rate, self.vid_rate
+        cfg.context, cfg.sample_duration = self.context, self.duration
+        cfg.fft_window = self.params.sep_fft_window
+        return cfg
+
+    def context_for(self, batch):
+        if self._variables is None:
+            raise RuntimeError('load_variables() first')
+        if batch not in self._ctx:
+            self._ctx[batch] = _Ctx(self._config(batch), self._variables, self.device)
+        return self._ctx[batch]
+
+    # ---- the hot path ------------------------------------------------------------------------
+    def inference_ops(self, audio, video=None, flow=None, is_training=True, out=None):
+        """audio [B,snd_size,1]; video/flow [B,1,224,448,3] -> x_ambi [B,snd_dur,3] (Y,Z,X).
+        `is_training` is accepted for signature parity; as in the reference graph it does not change
+        the arithmetic (BN uses batch statistics either way, model.py:197)."""
+        def prep(t, name, tail):
+            if t is None:
+                return None
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(np.asarray(t))
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            if tuple(t.shape[1:]) != tail:
+                raise ValueError('%s has shape %s, expected [B,%s]' % (name, tuple(t.shape), ','.join(map(str, tail))))
+            return t
+        audio = prep(audio, 'audio', (self.snd_size, 1))
+        video = prep(video, 'video', (1, 224, 448, 3)) if VIDEO in self.encoders else None
+        flow = prep(flow, 'flow', (1, 224, 448, 3)) if FLOW in self.encoders else None
+        if VIDEO in self.encoders and video is None:
+            raise ValueError('video encoder enabled but no video given')
+        if FLOW in self.encoders and flow is None:
+            raise ValueError('flow encoder enabled but no flow given')
+        B = audio.shape[0]
+        ctx = self.context_for(B)
+        if out is None:
+            out = torch.empty(B, self.snd_dur, self.geom.num_out, dtype=torch.float32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(_lib.lib().sagen_forward(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
+        return out
+
+    def intermediate(self, batch, name):
+        return self.context_for(batch).intermediate(name)

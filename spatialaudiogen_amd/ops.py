@@ -1,0 +1,150 @@
+"""Op-level Python surface over the C ABI — the counterparts of the reference's layer wrappers
+(pyutils/tflib/wrappers/core.py: conv_2d :156-220, deconv_2d :96-153, fully_connected :43-93) and
+of myutils.stft / istft (myutils.py:119-211).  Tensors are torch CUDA fp32, NHWC like the TF graph.
+torch is only the owner of device memory and streams here; all arithmetic is in libsagen_hip.so.
+"""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError('%s must be a CUDA float32 tensor' % name)
+    return t.contiguous()
+
+
+def _scratch(nbytes, dev):
+    return torch.empty((int(nbytes) + 255) // 256 * 64, dtype=torch.float32, device=dev)
+
+
+def stft_mag(audio, f0, f1, c0=None, c1=None):
+    """myutils.stft (myutils.py:119-147) + crop + tf.abs (model.py:166-178).
+    audio [B, n]; returns (mag [B,f1-f0,1024], spec [B,c1-c0,513,2] or None)."""
+    audio = _f32(audio, 'audio')
+    B, n = audio.shape
+    mag = torch.empty(B, f1 - f0, 1024, dtype=torch.float32, device=audio.device)
+    spec = None
+    if c0 is not None:
+        spec = torch.empty(B, c1 - c0, 513, 2, dtype=torch.float32, device=audio.device)
+    check(_lib.lib().sagen_stft_mag(_ptr(audio), B, n, f0, f1, _ptr(mag), c0 or 0, c1 or 0, _ptr(spec), _stream()))
+    return mag, spec
+
+
+def conv_2d(x, weights, stride=1, padding='SAME', biases=None, relu=False, in_scale=None, in_shift=None,
+            return_bn_stats=False):
+    """tfw.conv_2d minus batch-norm (core.py:156-220).  x [B,H,W,Cin]; weights HWIO.
+    With return_bn_stats the raw-output statistics for training-mode BN come back too."""
+    x, weights = _f32(x, 'x'), _f32(weights, 'weights')
+    B, H, W, Cin = x.shape
+    kh, kw, cin2, cout = weights.shape
+    assert cin2 == Cin
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    pad = {'VALID': 0, 'SAME': 1}[padding]
+    if pad:
+        Ho, Wo = -(-H // sh), -(-W // sw)
+    else:
+        Ho, Wo = (H - kh) // sh + 1, (W - kw) // sw + 1
+    l = _lib.lib()
+    y = torch.empty(B, Ho, Wo, cout, dtype=torch.float32, device=x.device)
+    scratch = _scratch(l.sagen_conv2d_scratch_bytes(B, H, W, kh, kw, Cin, cout), x.device)
+    stats = None
+    if return_bn_stats:
+        stats = torch.zeros(int(l.sagen_bn_stats_floats(B, Ho, Wo, cout)), dtype=torch.float32, device=x.device)
+    check(l.sagen_conv2d(_ptr(x), B, H, W, Cin, _ptr(weights), kh, kw, cout, sh, sw, pad, _ptr(biases), int(relu),
+                         _ptr(in_scale), _ptr(in_shift), _ptr(y), _ptr(stats), _ptr(scratch), scratch.numel() * 4, _stream()))
+    return (y, stats) if return_bn_stats else y
+
+
+def bn_finalize(stats, shape, gamma, beta, eps=1e-3):
+    """contrib batch_norm, is_training=True (core.py:6,209-210): -> (scale, shift)."""
+    B, Ho, Wo, C_ = shape
+    scale = torch.empty(C_, dtype=torch.float32, device=stats.device)
+    shift = torch.empty(C_, dtype=torch.float32, device=stats.device)
+    check(_lib.lib().sagen_bn_finalize(_ptr(stats), B, Ho, Wo, C_, _ptr(_f32(gamma, 'gamma')), _ptr(_f32(beta, 'beta')),
+                                       eps, _ptr(scale), _ptr(shift), _stream()))
+    return scale, shift
+
+
+def bn_apply_relu(x, scale=None, shift=None, residual=None):
+    x = _f32(x, 'x')
+    y = torch.empty_like(x)
+    C_ = x.shape[-1]
+    check(_lib.lib().sagen_bn_apply_relu(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), x.numel() // C_, C_, _stream()))
+    return y
+
+
+def maxpool3x3s2(x, scale=None, shift=None):
+    x = _f32(x, 'x')
+    B, H, W, C_ = x.shape
+    y = torch.empty(B, (H + 1) // 2, (W + 1) // 2, C_, dtype=torch.float32, device=x.device)
+    check(_lib.lib().sagen_maxpool3x3s2(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), B, H, W, C_, _stream()))
+    return y
+
+
+def fully_connected(x, weights, biases=None, relu=False):
+    """tfw.fully_connected (core.py:43-93): acts on the last axis."""
+    x, weights = _f32(x, 'x'), _f32(weights, 'weights')
+    K, N = weights.shape
+    M = x.numel() // K
+    l = _lib.lib()
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    scratch = _scratch(l.sagen_fc_scratch_bytes(M, K, N), x.device)
+    check(l.sagen_fc(_ptr(x), M, K, _ptr(weights), N, _ptr(biases), int(relu), _ptr(y), _ptr(scratch), scratch.numel() * 4, _stream()))
+    return y
+
+
+def deconv_2d(x, weights, stride, biases=None, relu=False):
+    """tfw.deconv_2d (core.py:96-153), VALID.  weights [kh,kw,Cout,Cin]."""
+    x, weights = _f32(x, 'x'), _f32(weights, 'weights')
+    B, H, W, Cin = x.shape
+    kh, kw, cout, cin2 = weights.shape
+    assert cin2 == Cin
+    sh, sw = stride
+    l = _lib.lib()
+    y = torch.empty(B, H * sh + kh - sh, W * sw + kw - sw, cout, dtype=torch.float32, device=x.device)
+    scratch = _scratch(l.sagen_deconv2d_scratch_bytes(kh, kw, Cin, cout, sh, sw), x.device)
+    check(l.sagen_deconv2d(_ptr(x), B, H, W, Cin, _ptr(weights), kh, kw, cout, sh, sw, _ptr(biases), int(relu), _ptr(y),
+                           _ptr(scratch), scratch.numel() * 4, _stream()))
+    return y
+
+
+def mask_istft_mix(dmask, spec, coeffs):
+    """sigmoid mask x STFT -> myutils.istft -> crop -> decoder sum (model.py:326-347, 421-434).
+    dmask [B,28,1024,K]; spec [B,28,513,2]; coeffs [B,3,3,K+1] -> [B,4800,3]."""
+    dmask, spec, coeffs = _f32(dmask, 'dmask'), _f32(spec, 'spec'), _f32(coeffs, 'coeffs')
+    B, ntr = dmask.shape[0], dmask.shape[3]
+    l = _lib.lib()
+    out = torch.empty(B, 4800, 3, dtype=torch.float32, device=dmask.device)
+    scratch = _scratch(l.sagen_mask_istft_mix_scratch_bytes(B), dmask.device)
+    check(l.sagen_mask_istft_mix(_ptr(dmask), _ptr(spec), _ptr(coeffs), B, ntr, _ptr(out), _ptr(scratch), scratch.numel() * 4, _stream()))
+    return out
+
+
+def power_map(ambi_wyzx, sh_matrix):
+    """AmbiDecoder.decode('projection') + per-direction RMS (decoder.py:24-28, distance.py:41-52)."""
+    a, sh = _f32(ambi_wyzx, 'ambi'), _f32(sh_matrix, 'sh')
+    T, P = a.shape[0], sh.shape[0]
+    rms = torch.empty(P + 24 + (P % 2), dtype=torch.float32, device=a.device)
+    check(_lib.lib().sagen_power_map(_ptr(a), T, _ptr(sh), P, _ptr(rms), _stream()))
+    return rms[:P]
+
+
+def assemble_wyzx(audio, ambi_yzx, snd_contx=48000):
+    """deploy.py:143-152: prepend W = mono[snd_contx/2 : snd_contx/2 + snd_dur]."""
+    audio, ambi_yzx = _f32(audio, 'audio'), _f32(ambi_yzx, 'ambi')
+    B, n = audio.shape[0], audio.shape[1]
+    dur = ambi_yzx.shape[1]
+    out = torch.empty(B, dur, 4, dtype=torch.float32, device=audio.device)
+    check(_lib.lib().sagen_assemble_wyzx(_ptr(audio), _ptr(ambi_yzx), _ptr(out), B, n, snd_contx, dur, _stream()))
+    return out

@@ -1,0 +1,146 @@
+"""End-to-end parity of the HIP path (through sagen_forward) against the fp64 numpy oracle on the
+same seeded inputs and weights.  Bar: ambisonic output RMS error <= 1e-4 absolute
+and <= 1e-3 relative to the output RMS; channel order [Y,Z,X] and sample indexing exact."""
+import numpy as np
+import pytest
+
+from util import rms, rel_rms_err, ensure_lib
+from oracle.np_oracle import SptAudioGenOracle
+from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL, REL_TOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    ensure_lib()
+    return torch
+
+
+def run_pair(T, encoders, separation='unet_mask', batch=2, seed=0, nsep=32, loc_units=(512, 512)):
+    from spatialaudiogen_amd.model import SptAudioGen, SptAudioGenParams
+    specs = variable_specs(encoders, separation, nsep, loc_units)
+    P = init_weights(specs, seed=seed, mode='test')
+    inp = synth_inputs(batch, encoders, seed=1234 + seed)
+    orc = SptAudioGenOracle(encoders=encoders, separation=separation, sep_num_tracks=nsep, loc_fc_units=loc_units)
+    ref = orc.inference_ops(inp['audio'], P, video=inp.get('video'), flow=inp.get('flow'))
+    net = SptAudioGen(1, encoders=list(encoders), separation=separation,
+                      params=SptAudioGenParams(sep_num_tracks=nsep, loc_fc_units=list(loc_units)))
+    net.load_variables(P)
+    out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow'))
+    T.cuda.synchronize()
+    return net, orc, out.cpu().numpy(), ref
+
+
+def check_out(got, ref):
+    err = rms(got - ref)
+    assert np.isfinite(got).all()
+    assert err <= ABS_TOL, 'abs RMS err %g' % err
+    assert err <= REL_TOL * rms(ref), 'rel RMS err %g (out rms %g)' % (err / rms(ref), rms(ref))
+
+
+def test_audio_only_intermediates_and_output(T):
+    net, orc, got, ref = run_pair(T, ['audio'])
+    B = 2
+    names = ['mag'] + ['audio_encoder/conv%d' % l for l in range(1, 6)] + ['bottleneck', 'localization/coeffs']
+    for n in names:
+        g = net.intermediate(B, n).cpu().numpy()
+        r = orc.ends['audio_encoder/mag' if n == 'mag' else n]
+        r = r.reshape(g.shape)
+        e = rel_rms_err(g, r)
+        assert e < 5e-5, (n, e)
+    d1 = net.intermediate(B, 'separation/deconv1').cpu().numpy()          # rows 44..66 only
+    assert rel_rms_err(d1, orc.ends['separation/deconv1'][:, 44:67]) < 5e-5
+    check_out(got, ref)
+
+
+def test_audio_video(T):
+    net, orc, got, ref = run_pair(T, ['audio', 'video'])
+    g = net.intermediate(2, 'bottleneck').cpu().numpy()
+    assert rel_rms_err(g, orc.ends['bottleneck']) < 2e-4
+    check_out(got, ref)
+
+
+def test_audio_video_flow(T):
+    _, _, got, ref = run_pair(T, ['audio', 'video', 'flow'], seed=1)
+    check_out(got, ref)
+
+
+def test_no_separation_mode(T):
+    _, _, got, ref = run_pair(T, ['audio'], separation='none')
+    check_out(got, ref)
+
+
+def test_other_widths(T):
+    _, _, got, ref = run_pair(T, ['audio'], nsep=64, loc_units=(256, 256), batch=3)
+    check_out(got, ref)
+
+
+def test_channel_order_and_step_indexing(T):
+    """Decoder with hand-set localisation: fc weights zero, fc3 bias selects track k for channel o at
+    step s — output channel o must equal that separated track on samples [1600 s, 1600 (s+1))."""
+    import torch
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio']
+    specs = variable_specs(enc)
+    P = init_weights(specs, seed=3, mode='test')
+    P['localization/fc3/weights'][:] = 0
+    b = np.zeros((3, 1, 33), np.float32)
+    b[0, 0, 4] = 1.0      # Y <- track 4
+    b[1, 0, 32] = 0.25    # Z <- constant bias
+    b[2, 0, 9] = -1.0     # X <- -track 9
+    P['localization/fc3/biases'][:] = b.reshape(-1)
+    inp = synth_inputs(2, enc, seed=7)
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(inp['audio'], P)
+    tracks = orc.ends['separation/all_channels'][:, 0]                      # [B,32,4800]
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(inp['audio']).cpu().numpy()
+    assert rms(got[:, :, 0] - tracks[:, 4]) < 1e-5
+    assert np.abs(got[:, :, 1] - 0.25).max() < 1e-6
+    assert rms(got[:, :, 2] + tracks[:, 9]) < 1e-5
+    check_out(got, ref)
+
+
+def test_batch_coupling_through_batchnorm(T):
+    """Training-mode BN couples windows of a batch: zero-padding a partial batch the way
+    deploy.py:125-132 does must change the real windows' outputs exactly as the oracle says."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    specs = variable_specs(enc)
+    P = init_weights(specs, seed=5, mode='test')
+    inp = synth_inputs(3, enc, seed=11)
+    a = inp['audio'].copy(); v = inp['video'].copy()
+    a[2] = 0; v[2] = 0                                                     # dummy window of a short last batch
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(a, P, video=v)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(a, v).cpu().numpy()
+    check_out(got, ref)
+    ref_full = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp['video'])
+    assert rms(ref_full[:2] - ref[:2]) > 10 * ABS_TOL                     # the coupling is real
+
+
+def test_errors_are_loud(T):
+    from spatialaudiogen_amd.model import SptAudioGen
+    from spatialaudiogen_amd._lib import SagenError
+    net = SptAudioGen(1, encoders=['audio'], separation='unet_mask')
+    with pytest.raises(RuntimeError):
+        net.inference_ops(np.zeros((1, 52799, 1), np.float32))             # no variables loaded
+    P = init_weights(variable_specs(['audio']), seed=0)
+    bad = dict(P); bad.pop('separation/deconv3/biases')
+    with pytest.raises(KeyError):
+        net.load_variables(bad)
+    net.load_variables(P)
+    with pytest.raises(ValueError):
+        net.inference_ops(np.zeros((1, 1000, 1), np.float32))
+    net2 = SptAudioGen(1, audio_rate=44100, video_rate=10, encoders=['audio'], separation='unet_mask')
+    net2.load_variables(init_weights(net2.variable_specs(), seed=0))
+    with pytest.raises(SagenError):
+        net2.inference_ops(np.zeros((1, net2.snd_size, 1), np.float32))    # unsupported geometry: explicit error
