@@ -108,6 +108,14 @@ int    sagen_assemble_wyzx(const float* audio, const float* ambi_yzx, float* out
 int    sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float** data,
                               int32_t* ndim, int64_t shape[4], int64_t* pixel_stride);
 
+/* Measurement aid (the reference's only analogue is the samples/sec printout, myutils.py:15-26):
+ * when enabled, every launch of the following sagen_forward calls is bracketed by a pair of
+ * hipEvents on the launch stream.  sagen_profile_report waits for the last forward's events and
+ * writes one line per launch, "kernel\tlayer\tmicroseconds\tflops\n"; returns the number of lines
+ * (>= 0) or a negative sagen_status. */
+int    sagen_profile_enable(sagen_ctx* ctx, int on);
+int    sagen_profile_report(sagen_ctx* ctx, char* buf, size_t buflen);
+
 /* ---- op-level (unit-testable; same conventions) ----------------------------------------- */
 
 /* myutils.stft (myutils.py:119-147) fused with the crop + tf.abs of audio_encoder_ops

@@ -42,6 +42,8 @@ SIGNATURES = {
     'sagen_assemble_wyzx': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'sagen_get_intermediate': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]),
+    'sagen_profile_enable': (C.c_int, [_P, _I]),
+    'sagen_profile_report': (C.c_int, [_P, C.c_char_p, _SZ]),
     'sagen_stft_mag': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
     'sagen_conv2d_scratch_bytes': (_SZ, [_I] * 7),
     'sagen_bn_stats_floats': (_SZ, [_I] * 4),

@@ -11,6 +11,8 @@ void sagen_destroy_impl(sagen_ctx* c);
 size_t sagen_workspace_bytes_impl(const sagen_ctx* c);
 int sagen_num_variables_impl(const sagen_ctx* c);
 int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32_t* ndim, int64_t shape[4]);
+int sagen_profile_enable_impl(sagen_ctx* c, int on);
+int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen);
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride);
 
@@ -74,6 +76,15 @@ int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float**
                            int64_t* pixel_stride) {
     if (!ctx || !name || !data || !ndim || !shape || !pixel_stride) return fail(SAGEN_ERR_NULL, "sagen_get_intermediate: null argument");
     return guarded([&] { return sagen_get_intermediate_impl(ctx, name, data, ndim, shape, pixel_stride); });
+}
+
+int sagen_profile_enable(sagen_ctx* ctx, int on) {
+    if (!ctx) return fail(SAGEN_ERR_NULL, "sagen_profile_enable: null ctx");
+    return sagen_profile_enable_impl(ctx, on);
+}
+int sagen_profile_report(sagen_ctx* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf) return fail(SAGEN_ERR_NULL, "sagen_profile_report: null argument");
+    return guarded([&] { return sagen_profile_report_impl(ctx, buf, buflen); });
 }
 
 int sagen_assemble_wyzx(const float* audio, const float* ambi_yzx, float* out_wyzx, int batch, int snd_size, int snd_contx,

@@ -307,6 +307,18 @@ static int tile_bn(IgemmTile t) {
     }
 }
 
+const char* igemm_tile_name(IgemmTile t) {
+    switch (t) {
+        case TILE_128x128: return "igemm_kernel<128,128,64,64,16>";
+        case TILE_128x64: return "igemm_kernel<128,64,64,32,16>";
+        case TILE_256x64: return "igemm_kernel<256,64,64,64,16>";
+        case TILE_64x64: return "igemm_kernel<64,64,32,32,16>";
+        case TILE_128x32: return "igemm_kernel<128,32,32,32,16>";
+        case TILE_32x128: return "igemm_kernel<32,128,32,32,16>";
+        default: return "igemm_kernel<?>";
+    }
+}
+
 IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     if (d.M <= 32) return TILE_32x128;
     if (d.N <= 32) return TILE_128x32;

@@ -49,6 +49,7 @@ enum IgemmTile { TILE_128x128 = 0, TILE_128x64, TILE_256x64, TILE_64x64, TILE_12
 int igemm_launch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);
 int igemm_grid_m(const IgemmDesc& d, IgemmTile tile);       // number of M tiles (stats rows)
 IgemmTile igemm_pick_tile(const IgemmDesc& d);
+const char* igemm_tile_name(IgemmTile t);              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep)
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
                          float* y, int ldy, int rep, hipStream_t s);

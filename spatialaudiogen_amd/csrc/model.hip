@@ -39,8 +39,19 @@ static const int AENC_S[5][2] = {{4, 8}, {2, 4}, {2, 2}, {1, 1}, {1, 1}};
 
 using namespace sagen;
 
+struct ProfRec {
+    std::string kernel, layer;
+    double flops = 0.0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
 struct sagen_ctx {
     sagen_config cfg;
+    // optional per-launch HIP-event profiler (sagen_profile_enable)
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
     int B = 0;
     int snd_size = 52799, snd_contx = 48000, snd_dur = 4800;
     int enc_h[6], enc_w[6], enc_c[6];   // audio encoder pyramid (index 0 = magnitude)
@@ -341,6 +352,31 @@ struct Fwd {
     sagen_ctx* c;
     hipStream_t s;
     int rc = SAGEN_OK;
+    std::string layer;      // label of the layer being launched (profiling only)
+
+    hipEvent_t next_event() {
+        if (c->events_used == c->event_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            c->event_pool.push_back(e);
+        }
+        return c->event_pool[c->events_used++];
+    }
+    // time one launch (or launch group) with a pair of events on the launch stream
+    template <class F>
+    void timed(const char* kernel, double flops, F&& launch) {
+        if (rc) return;
+        if (!c->profiling) { rc = launch(); return; }
+        ProfRec r;
+        r.kernel = kernel; r.layer = layer; r.flops = flops;
+        r.e0 = next_event(); r.e1 = next_event();
+        if (!r.e0 || !r.e1) { rc = fail(SAGEN_ERR_HIP, "hipEventCreate failed"); return; }
+        hipError_t he = hipEventRecord(r.e0, s);
+        rc = launch();
+        if (he == hipSuccess) he = hipEventRecord(r.e1, s);
+        if (he != hipSuccess && !rc) rc = fail(SAGEN_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(he));
+        c->prof.push_back(r);
+    }
 
     // run one contraction, through split-K + reduce when parallelism is low or rows are replicated
     void gemm(IgemmDesc d, int rep = 1, bool allow_split = true) {
@@ -360,11 +396,10 @@ struct Fwd {
             e.splitk_ws = c->ws + wsb.off;
             e.bias = nullptr;
             e.relu_out = 0;
-            rc = igemm_launch(e, tile, s);
-            if (rc) return;
-            rc = splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, s);
+            timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
+            timed("splitk_reduce_kernel", 0.0, [&] { return splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, s); });
         } else {
-            rc = igemm_launch(d, tile, s);
+            timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
         }
     }
 
@@ -394,6 +429,7 @@ struct Fwd {
 
     // tfw.fully_connected (core.py:43-93) on dense rows
     void fc(const float* x, int M, int K, int ldx, const std::string& name, int N, bool relu, float* y, int ldy, int rep = 1) {
+        layer = name;
         IgemmDesc d;
         d.x = x; d.w = c->p("pk:" + name + "/weights"); d.y = y; d.bias = c->v(name + "/biases");
         d.M = M; d.N = N; d.K = K; d.Kpad = (K + 15) / 16 * 16;
@@ -407,6 +443,7 @@ struct Fwd {
     void deconv(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int a0, int a1, int Ylim,
                 long y_bstride, long y_row0) {
         const std::string name = "separation/deconv" + std::to_string(l + 1);
+        layer = name;
         const int kh = AENC_K[l][0], kw = AENC_K[l][1], sh = AENC_S[l][0], sw = AENC_S[l][1];
         const int Cout = l == 0 ? c->nsep : AENC_F[l - 1];
         const int Hout = Hin * sh + kh - sh, Wout = Win * sw + kw - sw;
@@ -427,9 +464,9 @@ struct Fwd {
     }
 
     void bn_finalize(const IgemmDesc& d, IgemmTile tile, const std::string& bn_name, float* scale, float* shift) {
-        if (rc) return;
-        rc = bn_finalize_launch(d.stats, igemm_grid_m(d, tile), (long)d.M, d.N, c->v(bn_name + "/bn/gamma"),
-                                c->v(bn_name + "/bn/beta"), 1e-3f, scale, shift, s);
+        timed("bn_finalize_kernel", 0.0, [&] {
+            return bn_finalize_launch(d.stats, igemm_grid_m(d, tile), (long)d.M, d.N, c->v(bn_name + "/bn/gamma"),
+                                      c->v(bn_name + "/bn/beta"), 1e-3f, scale, shift, s); });
     }
 
     // conv (+BN statistics) of the ResNet trunk: raw output + scale/shift for the consumer
@@ -442,7 +479,8 @@ struct Fwd {
         d.stats = c->p("stats");
         IgemmTile tile = igemm_pick_tile(d);
         if ((size_t)igemm_grid_m(d, tile) * 2 * d.N > c->bufs.at("stats").n) { rc = fail(SAGEN_ERR_WORKSPACE, "stats buffer too small"); return; }
-        rc = igemm_launch(d, tile, s);
+        layer = name;
+        timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
         bn_finalize(d, tile, name, scale, shift);
     }
 
@@ -453,7 +491,8 @@ struct Fwd {
         int li = 0;
         auto sc_of = [&](int i) { return bnp + (size_t)i * 1024; };
         auto sh_of = [&](int i) { return bnp + (size_t)i * 1024 + 512; };
-        if (!rc) rc = pad_nhwc3to4_launch(img, c->p("xpad"), B, 224, 448, 2, 3, 2, 3, s);
+        layer = scope + "/pad";
+        timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad"), B, 224, 448, 2, 3, 2, 3, s); });
         // conv1 7x7/2 SAME == VALID on the padded 4-channel image
         int H = 0, W = 0;
         {
@@ -462,9 +501,10 @@ struct Fwd {
                                     c->p("y0"), 64, H, W);
             d.stats = c->p("stats");
             IgemmTile tile = igemm_pick_tile(d);
-            if (!rc) rc = igemm_launch(d, tile, s);
+            layer = name;
+            timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
             bn_finalize(d, tile, name, sc_of(li), sh_of(li));
-            if (!rc) rc = maxpool3x3s2_launch(c->p("y0"), sc_of(li), sh_of(li), c->p("rx0"), B, H, W, 64, s);
+            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0"), sc_of(li), sh_of(li), c->p("rx0"), B, H, W, 64, s); });
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
         }
@@ -483,6 +523,7 @@ struct Fwd {
                 if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
                                             cout, c->p("rsc"), cout, Ho, Wo);
+                    layer = pfx + "/shortcut";
                     gemm(d, 1, false);
                     shortcut = c->p("rsc");
                 }
@@ -491,7 +532,8 @@ struct Fwd {
                 int H2, W2;
                 conv_bn(c->p("ry1"), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, sc_of(l1), sh_of(l1), c->p("ry2"), sc_of(li),
                         sh_of(li), H2, W2);
-                if (!rc) rc = bn_apply_relu_launch(c->p("ry2"), sc_of(li), sh_of(li), shortcut, xout, (long)B * Ho * Wo, cout, s);
+                layer = pfx + "/merge";
+                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2"), sc_of(li), sh_of(li), shortcut, xout, (long)B * Ho * Wo, cout, s); });
                 ++li;
                 std::swap(xin, xout);
                 H = Ho; W = Wo; cin = cout;
@@ -512,7 +554,10 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     Fwd f{c, s};
 
     // STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
-    f.rc = stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), s);
+    c->events_used = 0;
+    c->prof.clear();
+    f.layer = "stft";
+    f.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), s); });
 
     // audio encoder (model.py:161-187): conv l writes the encoder half of concat buffer l
     for (int l = 0; l < 5 && !f.rc; ++l) {
@@ -535,6 +580,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         }
         d.bias = c->v(name + "/biases");
         d.relu_out = 1;
+        f.layer = name;
         f.gemm(d);
     }
 
@@ -548,6 +594,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         d.ntaps = 6; d.TW = 6; d.log2Cin = 9;
         d.Cout = 1024; d.Hlim = 3; d.Wlim = 1; d.ldy = c->Cb; d.y_rstride = c->Cb; d.y_bstride = 3L * c->Cb;
         d.relu_out = 1;
+        f.layer = "bottleneck/audio-fc";
         f.gemm(d);
     }
     int choff = 1024;
@@ -575,7 +622,8 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     }
 
     if (!c->freq_mask) {
-        if (!f.rc) f.rc = nosep_mix_launch(audio, c->p("coeffs"), out, B, c->snd_size, c->snd_contx, c->snd_dur, 3, s);
+        f.layer = "decoder";
+        f.timed("nosep_mix_kernel", 0.0, [&] { return nosep_mix_launch(audio, c->p("coeffs"), out, B, c->snd_size, c->snd_contx, c->snd_dur, 3, s); });
         return f.rc;
     }
 
@@ -588,16 +636,45 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     }
     // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16
     f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44);
-    if (!f.rc)
-        f.rc = mask_istft_mix_launch(c->p("dmask"), 23L * 1024 * c->nsep, 1, c->p("spec"), c->p("coeffs"), B, c->nsep, out,
-                                     c->p("frames"), s);
+    f.layer = "separation/mask-istft-mix";
+    f.timed("mask_istft_kernel+ola_mix_kernel", 0.0, [&] {
+        return mask_istft_mix_launch(c->p("dmask"), 23L * 1024 * c->nsep, 1, c->p("spec"), c->p("coeffs"), B, c->nsep, out,
+                                     c->p("frames"), s); });
     return f.rc;
 }
 
 // ------------------------------------------------------------------------------------------------
 // small accessors
 // ------------------------------------------------------------------------------------------------
-void sagen_destroy_impl(sagen_ctx* c) { delete c; }
+void sagen_destroy_impl(sagen_ctx* c) {
+    if (!c) return;
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int sagen_profile_enable_impl(sagen_ctx* c, int on) {
+    c->profiling = on != 0;
+    c->prof.clear();
+    c->events_used = 0;
+    return SAGEN_OK;
+}
+
+// one line per launch of the last forward: kernel \t layer \t microseconds \t flops
+int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen) {
+    std::string out;
+    for (const ProfRec& r : c->prof) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (e != hipSuccess) return fail(SAGEN_ERR_HIP, "profile: %s", hipGetErrorString(e));
+        char line[512];
+        snprintf(line, sizeof line, "%s\t%s\t%.3f\t%.6g\n", r.kernel.c_str(), r.layer.c_str(), ms * 1e3, r.flops);
+        out += line;
+    }
+    if (out.size() + 1 > buflen) return fail(SAGEN_ERR_WORKSPACE, "profile report needs %zu bytes", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)c->prof.size();
+}
 size_t sagen_workspace_bytes_impl(const sagen_ctx* c) { return c->ws_floats * sizeof(float); }
 int sagen_num_variables_impl(const sagen_ctx* c) { return (int)c->vars.size(); }
 int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32_t* ndim, int64_t shape[4]) {

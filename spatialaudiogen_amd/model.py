@@ -197,3 +197,19 @@ class SptAudioGen(object):
 
     def intermediate(self, batch, name):
         return self.context_for(batch).intermediate(name)
+
+    # ---- measurement aid: per-launch HIP-event timing inside the native runtime ---------------
+    def profile_enable(self, batch, on=True):
+        check(_lib.lib().sagen_profile_enable(self.context_for(batch).handle, int(on)))
+
+    def profile_report(self, batch):
+        """[(kernel, layer, microseconds, flops)] for every launch of the last forward."""
+        buf = C.create_string_buffer(1 << 18)
+        n = _lib.lib().sagen_profile_report(self.context_for(batch).handle, buf, len(buf))
+        if n < 0:
+            check(n)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            k, layer, us, fl = line.split('\t')
+            rows.append((k, layer, float(us), float(fl)))
+        return rows
