@@ -70,6 +70,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('%s is missing: build the HIP extension first '
                                '(python -m spatialaudiogen_amd.build). There is no CPU fallback.' % LIB_PATH)
+        # torch owns device memory and streams: its HIP runtime (libamdhip64 bundled with the wheel) must be
+        # the one this library binds to, so it has to be loaded first.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported

@@ -3,49 +3,95 @@
 // Replaces, for the inference path, tf.nn.convolution (core.py:206), tf.nn.conv2d_transpose
 // (core.py:140) and tf.matmul (core.py:79) of the reference's TF1 runtime.
 //
-// Design (CDNA4):
-//  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A wave owns a (WM x WN) patch of
-//    32x32 accumulators; a 256-thread workgroup (one wave per SIMD) owns BM x BN.
-//  * No im2col: the A tile is gathered straight from the NHWC activation (16 B per lane, a
-//    (tap, 4-channel) group per load), optionally through the previous layer's batch-norm
-//    (relu(v*scale+shift)), and staged in LDS rows of BK+4 floats (conflict-free ds_read_b128).
+// Design (CDNA4) — shaped by one measured fact: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles,
+// 64 FLOP/clk/SIMD = the vector rate) does NOT overlap with VALU work of either wave on its SIMD
+// (per-phase s_memtime traces).  Everything that is not an MFMA is therefore paid in
+// full, and the kernel is built to have almost nothing but MFMAs in its K loop:
+//  * no im2col and no register staging: A and B tiles go global -> LDS by LDS-DMA
+//    (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction: 16 rows x 64 B).  No ds_write phase.
+//  * buffer descriptors do the bounds work: a lane whose tap falls in the padding, whose row is
+//    >= M, whose k is >= K or whose filter row is >= N sets bit 31 of its offset and the hardware
+//    range check writes zeros.  Cost per 16-byte load: 3 VALU (bfe, add, lshl_or).
+//  * per-row byte offsets and 64-bit tap-validity masks are computed once per workgroup (LDS);
+//    the tap / channel position of a K tile is tracked in SGPRs (no division, no table).
+//  * LDS rows are 64 B, unpadded (DMA writes are lane-linear); the 16-B chunk index is XOR-swizzled
+//    with (row >> 2) & 3 on the SOURCE side of the DMA and on the fragment read, which makes every
+//    ds_read_b128 of an MFMA fragment conflict-free.
 //  * k is consumed in a lane-permuted order: lane (i, kk) of the MFMA holds the float4
-//    A[i][8u+4kk .. +3]; MFMA r of the group contracts k in {8u+r, 8u+4+r}.  The filter is packed
-//    [n][k] (k contiguous) so B fragments are read the same way.  One ds_read_b128 per operand
-//    per four MFMAs.
-//  * register-staged double buffering: global loads of tile t+1 are in flight while tile t is
-//    contracted; one barrier per K tile.
+//    A[i][8u+4kk .. +3]; MFMA r of a group contracts k in {8u+r, 8u+4+r}; the filter is packed
+//    [n][k] so B fragments are read the same way: one ds_read_b128 per operand per four MFMAs.
+//  * double-buffered LDS, one barrier per K tile; the DMA of tile t+1 flies under the MFMAs of t.
+//  * the previous layer's training-mode batch-norm (relu(v*scale+shift)) is applied to A fragments
+//    after the LDS read (padding stays exactly zero through the per-row masks).
 //  * epilogue: bias / ReLU, depth-to-space scatter (transposed convs), per-tile per-channel
-//    (sum, sumsq) partials for training-mode batch-norm, or raw split-K partials.
+//    (sum, sumsq) partials for batch-norm, or raw split-K partials.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace sagen {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MAX_TAPS = 128;
+constexpr int BK = 16;
+constexpr unsigned OOB = 0x80000000u;
 
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+struct RowInfo {        // per output-grid row of the tile, shared through LDS
+    unsigned boff;      // byte offset of x[b, a*in_sh, bb*in_sw, 0] (mod 2^32)
+    unsigned nmlo, nmhi;  // INVERTED tap-validity mask (bit t set = tap t reads padding / row invalid)
+    int hrem, wrem;     // valid depth-to-space extents
+    int pad;
+    long rowoff;        // element offset of the output pixel
+};
 
-template <int BM, int BN, int WM, int WN, int BK>
+// one LDS-DMA instruction: 64 lanes x 16 B, global (buffer, bounds-checked) -> LDS at `lds` + lane*16.
+// (kept out of the kernel template: the builtin silently blocks host-side stub instantiation otherwise)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// workgroup barrier that does NOT drain the LDS-DMA queue (hipcc's __syncthreads() would emit vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
-    constexpr int LD = BK + 4;              // LDS row stride in floats (16-B aligned, odd multiple of 4)
-    constexpr int KQ = BK / 4;              // float4 groups per row per K tile
-    constexpr int RPP = 256 / KQ;           // rows loaded per pass
-    constexpr int A_IT = (BM + RPP - 1) / RPP;
-    constexpr int B_IT = (BN + RPP - 1) / RPP;
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
+    constexpr int A_DMA = BM / 16, B_DMA = BN / 16;          // DMA instructions per tile (16 rows each)
+    constexpr int A_PW = (A_DMA + 3) / 4, B_PW = (B_DMA + 3) / 4;   // per wave
+    constexpr int PER = A_PW + B_PW;                          // DMA instructions per wave per K tile
+    // ring depth: 3 stages (two tiles in flight, counted vmcnt) when every wave issues the same number of
+    // DMA instructions per tile; otherwise 2 stages with a full drain
+    constexpr bool EVEN = (A_DMA % 4 == 0) && (B_DMA % 4 == 0);
+    constexpr int STAGES = EVEN ? 3 : 2;
+    constexpr int NMFMA = 8 * MT * NT;                        // MFMAs per wave per K tile
+    constexpr int TILE_F = (BM + BN) * BK;                    // floats per stage
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
-    __shared__ long s_rowoff[BM];
-    __shared__ int s_hrem[BM], s_wrem[BM];
-    float* As = smem;                        // [2][BM][LD]
-    float* Bs = smem + 2 * BM * LD;          // [2][BN][LD]
+    __shared__ __attribute__((aligned(16))) float smem[STAGES * TILE_F];
+    __shared__ RowInfo s_row[BM];
+    __shared__ int s_tapb[MAX_TAPS];          // byte displacement per tap (only for the per-lane tap path)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     // XCD-aware M-tile remap (block b runs on XCD b%8; give each XCD a contiguous run of tiles so
@@ -60,55 +106,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
     const int m0 = tile_m * BM;
     const int n0 = blockIdx.y * BN;
     const int z = blockIdx.z;
+    const bool uni = d.uniform_taps != 0;
 
+    // ---- per-row geometry, once per workgroup ----
     const int HgWg = d.Hg * d.Wg;
-    // per-row output addressing for the epilogue
+    if (!uni)
+        for (int t = tid; t < d.ntaps; t += 256) {
+            const int th = t / d.TW;
+            s_tapb[t] = (((th * d.tap_sh + d.tap_h0) * d.Win + ((t - th * d.TW) * d.tap_sw + d.tap_w0)) * d.ldx) * 4;
+        }
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
-        long off = 0;
-        int hr = 0, wr = 0;
+        RowInfo ri;
+        ri.boff = 0; ri.nmlo = 0xffffffffu; ri.nmhi = 0xffffffffu; ri.hrem = 0; ri.wrem = 0; ri.pad = 0; ri.rowoff = 0;
         if (m < d.M) {
             const int b = m / HgWg;
             const int rem = m - b * HgWg;
             const int ia = rem / d.Wg;
             const int a = d.g_h0 + ia, bb = d.g_w0 + (rem - ia * d.Wg);
-            off = (long)b * d.y_bstride + (long)(a * d.dsh) * d.y_rstride + (long)(bb * d.dsw) * d.ldy;
-            hr = d.Hlim - a * d.dsh;
-            wr = d.Wlim - bb * d.dsw;
+            const int hi0 = a * d.in_sh, wi0 = bb * d.in_sw;
+            ri.boff = (unsigned)(((long)b * d.x_bstride + ((long)hi0 * d.Win + wi0) * d.ldx) * 4);
+            ri.rowoff = (long)b * d.y_bstride + (long)(a * d.dsh) * d.y_rstride + (long)(bb * d.dsw) * d.ldy;
+            ri.hrem = d.Hlim - a * d.dsh;
+            ri.wrem = d.Wlim - bb * d.dsw;
+            if (d.no_bounds) {
+                ri.nmlo = 0; ri.nmhi = 0;
+            } else {
+                unsigned lo = 0, hi = 0;
+                for (int t = 0; t < d.ntaps; ++t) {
+                    const int th = t / d.TW;
+                    const int hh = hi0 + th * d.tap_sh + d.tap_h0, ww = wi0 + (t - th * d.TW) * d.tap_sw + d.tap_w0;
+                    const unsigned bad = ((unsigned)hh < (unsigned)d.Hin && (unsigned)ww < (unsigned)d.Win) ? 0u : 1u;
+                    if (t < 32) lo |= bad << t; else hi |= bad << (t - 32);
+                }
+                ri.nmlo = lo; ri.nmhi = hi;
+            }
         }
-        s_rowoff[r] = off;
-        s_hrem[r] = hr;
-        s_wrem[r] = wr;
+        s_row[r] = ri;
     }
+    __syncthreads();
 
-    // loader state: this thread stages float4 group `kq` of rows lrow + it*RPP
-    const int kq = tid % KQ;
-    const int lrow = tid / KQ;
-    long a_off[A_IT];
-    int a_hi0[A_IT], a_wi0[A_IT];
+    // ---- LDS-DMA loader state ----
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.x, 0, d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.w_bytes, 0x00020000);
+    const int src_chunk = (lane & 3) ^ (lane >> 4);          // logical 16-B chunk this lane fetches (XOR swizzle)
+    unsigned a_voff[A_PW], a_nmlo[A_PW], a_nmhi[A_PW], b_voff[B_PW];
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int row = lrow + it * RPP;
-        const int m = m0 + row;
-        a_off[it] = 0;
-        a_hi0[it] = -(1 << 28);
-        a_wi0[it] = 0;
-        if (row < BM && m < d.M) {
-            const int b = m / HgWg;
-            const int rem = m - b * HgWg;
-            const int ia = rem / d.Wg;
-            const int hi0 = (d.g_h0 + ia) * d.in_sh, wi0 = (d.g_w0 + (rem - ia * d.Wg)) * d.in_sw;
-            a_hi0[it] = hi0;
-            a_wi0[it] = wi0;
-            a_off[it] = (long)b * d.x_bstride + ((long)hi0 * d.Win + wi0) * d.ldx;
+    for (int j = 0; j < A_PW; ++j) {
+        const int inst = wave + 4 * j;                       // wave-uniform
+        a_voff[j] = OOB; a_nmlo[j] = 0xffffffffu; a_nmhi[j] = 0xffffffffu;
+        if (inst < A_DMA) {
+            const RowInfo ri = s_row[inst * 16 + (lane >> 2)];
+            a_voff[j] = ri.boff + 16u * src_chunk;
+            a_nmlo[j] = ri.nmlo; a_nmhi[j] = ri.nmhi;
         }
     }
-    const float* b_ptr[B_IT];
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int row = lrow + it * RPP;
-        const int n = n0 + row;
-        b_ptr[it] = (row < BN && n < d.N) ? d.w + (long)n * d.Kpad + 4 * kq : nullptr;
+    for (int j = 0; j < B_PW; ++j) {
+        const int inst = wave + 4 * j;
+        const int n = n0 + inst * 16 + (lane >> 2);
+        b_voff[j] = (inst < B_DMA && n < d.N) ? (unsigned)((long)n * d.Kpad * 4) + 16u * src_chunk : OOB;
     }
 
     const int nk = d.Kpad / BK;
@@ -117,56 +174,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
     const int kc1 = min(nk, kc0 + nk_per);
     const bool prologue = d.in_scale != nullptr;
 
-    float4 ra[A_IT], rb[B_IT];
-    auto load_tile = [&](int kc) {
-        const int k = kc * BK + 4 * kq;
-        int tap = 0, c = k;
-        if (d.ntaps > 1) {
-            tap = k >> d.log2Cin;
-            c = k & (d.Cin - 1);
-        }
-        const int th = tap / d.TW;
-        const int dh = th * d.tap_sh + d.tap_h0;
-        const int dw = (tap - th * d.TW) * d.tap_sw + d.tap_w0;
-        const long toff = ((long)dh * d.Win + dw) * d.ldx + c;
-        const bool kok = k < d.K;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (prologue && kok) {
-            sc = ldg4(d.in_scale + c);
-            sh = ldg4(d.in_shift + c);
-        }
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int hi = a_hi0[it] + dh, wi = a_wi0[it] + dw;
-            const bool ok = kok && (unsigned)hi < (unsigned)d.Hin && (unsigned)wi < (unsigned)d.Win;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = ldg4(d.x + a_off[it] + toff);
-                if (prologue) {
-                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f);
-                    v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f);
-                    v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                }
+    // SGPR trackers of the (tap, channel) position: q_* = next tile to ISSUE, p_* = tile being CONTRACTED
+    int q_tap = 0, q_th = 0, q_tw = 0, q_c0 = 0, p_tap = 0, p_c0 = 0;
+    if (uni) {
+        const int k0 = kc0 * BK;
+        if (d.ntaps > 1) { q_tap = k0 >> d.log2Cin; q_c0 = k0 & (d.Cin - 1); q_th = q_tap / d.TW; q_tw = q_tap - q_th * d.TW; }
+        else q_c0 = k0;
+        p_tap = q_tap; p_c0 = q_c0;
+    }
+
+    // issue state of the tile being issued (computed by begin_issue, consumed by issue_one)
+    unsigned i_tb = 0, i_bit = 0, i_kbyte = 0, i_kok = 1;
+    int i_stage = 0;
+    bool i_hi = false;
+    auto begin_issue = [&](int kc, int stage) {
+        i_stage = stage;
+        i_kbyte = (unsigned)(kc * (BK * 4));
+        if (uni) {
+            i_tb = (unsigned)((((q_th * d.tap_sh + d.tap_h0) * d.Win + (q_tw * d.tap_sw + d.tap_w0)) * d.ldx + q_c0) * 4);
+            i_bit = (unsigned)(q_tap & 31);
+            i_hi = q_tap >= 32;
+            q_c0 += BK;
+            if (d.ntaps > 1 && q_c0 == d.Cin) {
+                q_c0 = 0; ++q_tap; ++q_tw;
+                if (q_tw == d.TW) { q_tw = 0; ++q_th; }
             }
-            ra[it] = v;
+        } else {       // per-lane tap (Cin < 16 or a ragged K tail): table lookup
+            const int k = kc * BK + 4 * src_chunk;
+            const bool kok = k < d.K;
+            const int tap = (kok && d.ntaps > 1) ? (k >> d.log2Cin) : 0;
+            const int c = d.ntaps > 1 ? (k & (d.Cin - 1)) : k;
+            i_tb = (unsigned)(s_tapb[tap] + 4 * c) - 16u * src_chunk;
+            i_bit = (unsigned)(tap & 31);
+            i_hi = tap >= 32;
+            i_kok = kok ? 1u : 0u;
         }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            rb[it] = b_ptr[it] ? ldg4(b_ptr[it] + kc * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int row = lrow + it * RPP;
-            if (A_IT * RPP == BM || row < BM)
-                *reinterpret_cast<float4*>(&As[(buf * BM + row) * LD + 4 * kq]) = ra[it];
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int row = lrow + it * RPP;
-            if (B_IT * RPP == BN || row < BN)
-                *reinterpret_cast<float4*>(&Bs[(buf * BN + row) * LD + 4 * kq]) = rb[it];
+    // g-th DMA instruction of this wave for the tile prepared by begin_issue (g is a compile-time constant)
+    auto issue_one = [&](int g) {
+        float* st = smem + i_stage * TILE_F;
+        if (g < A_PW) {
+            const int inst = wave + 4 * g;
+            if (EVEN || inst < A_DMA) {
+                const unsigned word = i_hi ? a_nmhi[g] : a_nmlo[g];
+                unsigned bad = (word >> i_bit) & 1u;
+                if (!uni) bad |= (i_kok ^ 1u);
+                dma16(x_rsrc, st + inst * 16 * BK, (a_voff[g] + i_tb) | (bad << 31), 0);
+            }
+        } else {
+            const int inst = wave + 4 * (g - A_PW);
+            if (EVEN || inst < B_DMA) dma16(w_rsrc, st + (BM + inst * 16) * BK, b_voff[g - A_PW], i_kbyte);
         }
     };
 
@@ -179,36 +236,103 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int li = lane & 31, kk = lane >> 5;
-    if (kc0 < kc1) {
-        load_tile(kc0);
-        store_tile(0);
+    // fragment addressing: row (wm*WM + i*32 + li), physical chunk (2u + kk) ^ ((li >> 2) & 3)
+    const int fsw = (li >> 2) & 3;
+    const int f_off0 = 4 * ((kk) ^ fsw), f_off1 = 4 * ((2 + kk) ^ fsw);
+    // BN prologue state: inverted masks of this lane's fragment rows
+    unsigned f_nmlo[MT], f_nmhi[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        f_nmlo[i] = 0; f_nmhi[i] = 0;
+        if (prologue) { const RowInfo ri = s_row[wm * WM + i * 32 + li]; f_nmlo[i] = ri.nmlo; f_nmhi[i] = ri.nmhi; }
     }
-    __syncthreads();
-    for (int kc = kc0; kc < kc1; ++kc) {
-        const int buf = (kc - kc0) & 1;
-        const bool more = kc + 1 < kc1;
-        if (more) load_tile(kc + 1);
-        const float* Ab = &As[(buf * BM + wm * WM + li) * LD + 4 * kk];
-        const float* Bb = &Bs[(buf * BN + wn * WN + li) * LD + 4 * kk];
+
+#ifdef SAGEN_TRACE
+    unsigned long long* trc = (d.trace && tile_m == d.trace_block && blockIdx.y == 0) ? (unsigned long long*)d.trace + (size_t)wave * 64 * 8 : nullptr;
+#define TRC(ph) do { if (trc && lane == 0 && (kc - kc0) < 64) trc[(kc - kc0) * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRC(ph) do { } while (0)
+#endif
+
+    // ---- pipeline fill: STAGES-1 tiles in flight ----
+    const int ntiles = kc1 - kc0;
 #pragma unroll
-        for (int u = 0; u < BK / 8; ++u) {
-            float4 af[MT], bf[NT];
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < ntiles) {
+            begin_issue(kc0 + t, t);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LD + 8 * u);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LD + 8 * u);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+            for (int g = 0; g < PER; ++g) issue_one(g);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
+    if (STAGES == 3 && ntiles > 1) wait_vmcnt<EVEN ? PER : 0>(); else wait_vmcnt<0>();
+    lds_barrier();
+
+    int stage = 0;                                   // ring slot of the tile being contracted
+    for (int kc = kc0; kc < kc1; ++kc) {
+        TRC(0);
+        const bool more = kc + (STAGES - 1) < kc1;   // is there a tile to issue during this iteration?
+        int istage = stage + (STAGES - 1);
+        if (istage >= STAGES) istage -= STAGES;
+        if (more) begin_issue(kc + (STAGES - 1), istage);
+        const float* Ab = smem + stage * TILE_F + (wm * WM + li) * BK;
+        const float* Bb = smem + stage * TILE_F + (BM + wn * WN + li) * BK;
+        float4 af[2][MT], bf[2][NT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[u][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + (u ? f_off1 : f_off0));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[u][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + (u ? f_off1 : f_off0));
+        }
+        if (prologue) {
+            // relu(v*scale[c] + shift[c]) of the producer's batch-norm; padding / invalid rows stay 0
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = p_c0 + 8 * u + 4 * kk;     // channel of af[u][.].x  (prologue => uniform taps)
+                const float4 sc = *reinterpret_cast<const float4*>(d.in_scale + c);
+                const float4 sh = *reinterpret_cast<const float4*>(d.in_shift + c);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const unsigned word = p_tap < 32 ? f_nmlo[i] : f_nmhi[i];
+                    const bool ok = ((word >> (p_tap & 31)) & 1u) == 0;
+                    float4 v = af[u][i];
+                    v.x = ok ? fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
+                    v.y = ok ? fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
+                    v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
+                    v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
+                    af[u][i] = v;
+                }
+            }
+        }
+        TRC(1);
+        // MFMAs with the DMA issue of a later tile spread between them (it hides in the 64-cycle MFMA shadow)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float a = r == 0 ? af[u][i].x : r == 1 ? af[u][i].y : r == 2 ? af[u][i].z : af[u][i].w;
+                        const float b = r == 0 ? bf[u][j].x : r == 1 ? bf[u][j].y : r == 2 ? bf[u][j].z : bf[u][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                        const int idx = ((u * 4 + r) * MT + i) * NT + j;          // 0 .. NMFMA-1
+                        // after MFMA idx, issue DMA g when idx == (g+1)*NMFMA/(PER+1) - 1
+#pragma unroll
+                        for (int g = 0; g < PER; ++g)
+                            if (idx == (g + 1) * NMFMA / (PER + 1) - 1 && more) issue_one(g);
+                    }
+        TRC(2);
+        if (uni) {                                   // advance the consume-side tracker
+            p_c0 += BK;
+            if (d.ntaps > 1 && p_c0 == d.Cin) { p_c0 = 0; ++p_tap; }
+        }
+        // the next tile to contract (kc+1) must have landed; with 3 stages the one issued just now may still fly
+        if (STAGES == 3 && more) wait_vmcnt<EVEN ? PER : 0>(); else wait_vmcnt<0>();
+        TRC(3);
+        lds_barrier();
+        TRC(4);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
     }
 
     // ---------------- epilogue ----------------
@@ -241,13 +365,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
                 if (to_ws) {
                     if (nok && m < d.M) d.splitk_ws[((long)z * d.M + m) * d.N + n] = v;
                 } else {
-                    const bool ok = nok && ry < s_hrem[row] && rx < s_wrem[row];
+                    const bool ok = nok && ry < s_row[row].hrem && rx < s_row[row].wrem;
                     if (ok) {
                         csum[j] += v;
                         csq[j] += v * v;
                         v += bias;
                         if (d.relu_out) v = fmaxf(v, 0.f);
-                        d.y[s_rowoff[row] + coloff] = v;
+                        d.y[s_row[row].rowoff + coloff] = v;
                     }
                 }
             }
@@ -255,7 +379,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
     }
     if (d.stats != nullptr) {
         // per-tile per-channel partial sums of the raw conv output (pre-bias; BN convs have none)
-        __syncthreads();                       // all waves are done reading the A/B tiles
+        __syncthreads();                       // (the K loop already ended with a barrier; kept for clarity)
         float* red = smem;                     // [2][WAVES_M][BN]
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -284,7 +408,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 16>), grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -309,17 +433,19 @@ static int tile_bn(IgemmTile t) {
 
 const char* igemm_tile_name(IgemmTile t) {
     switch (t) {
-        case TILE_128x128: return "igemm_kernel<128,128,64,64,16>";
-        case TILE_128x64: return "igemm_kernel<128,64,64,32,16>";
-        case TILE_256x64: return "igemm_kernel<256,64,64,64,16>";
-        case TILE_64x64: return "igemm_kernel<64,64,32,32,16>";
-        case TILE_128x32: return "igemm_kernel<128,32,32,32,16>";
-        case TILE_32x128: return "igemm_kernel<32,128,32,32,16>";
+        case TILE_128x128: return "igemm_kernel<128,128,64,64>";
+        case TILE_128x64: return "igemm_kernel<128,64,64,32>";
+        case TILE_256x64: return "igemm_kernel<256,64,64,64>";
+        case TILE_64x64: return "igemm_kernel<64,64,32,32>";
+        case TILE_128x32: return "igemm_kernel<128,32,32,32>";
+        case TILE_32x128: return "igemm_kernel<32,128,32,32>";
         default: return "igemm_kernel<?>";
     }
 }
 
 IgemmTile igemm_pick_tile(const IgemmDesc& d) {
+    static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: 0..5 = IgemmTile
+    if (force && d.M > 128 && d.N >= 64) return (IgemmTile)atoi(force);
     if (d.M <= 32) return TILE_32x128;
     if (d.N <= 32) return TILE_128x32;
     auto blocks = [&](IgemmTile t) { return (long)cdiv(d.M, tile_bm(t)) * cdiv(d.N, tile_bn(t)) * d.splitk; };
@@ -339,7 +465,8 @@ int igemm_grid_m(const IgemmDesc& d, IgemmTile tile) {
     return cdiv(d.M, tile_bm(tile));
 }
 
-int igemm_launch(const IgemmDesc& d, IgemmTile tile, hipStream_t s) {
+int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
+    IgemmDesc d = d_in;
     if (!d.x || !d.w || (!d.y && !d.splitk_ws)) return fail(SAGEN_ERR_NULL, "igemm: null operand");
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return fail(SAGEN_ERR_SHAPE, "igemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
     if (d.Kpad % 16 || d.Kpad < d.K) return fail(SAGEN_ERR_SHAPE, "igemm: Kpad=%d must be a multiple of 16 >= K=%d", d.Kpad, d.K);
@@ -351,7 +478,28 @@ int igemm_launch(const IgemmDesc& d, IgemmTile tile, hipStream_t s) {
     if (d.splitk_ws && (d.stats || d.dsh * d.dsw != 1))
         return fail(SAGEN_ERR_UNSUPPORTED, "igemm: partial-sum output needs a plain epilogue");
     if (d.N != d.dsh * d.dsw * d.Cout) return fail(SAGEN_ERR_SHAPE, "igemm: N=%d != dsh*dsw*Cout", d.N);
+    {   // 32-bit buffer addressing + exact host-side bounds analysis of the taps
+        const int nb = d.M / (d.Hg * d.Wg) + (d.M % (d.Hg * d.Wg) ? 1 : 0);
+        const long xb = (long)nb * d.x_bstride * 4, wb = (long)d.N * d.Kpad * 4;
+        if (xb >= (1L << 31) || wb >= (1L << 31))
+            return fail(SAGEN_ERR_UNSUPPORTED, "igemm: operand of %ld bytes exceeds 2 GiB buffer addressing (use a smaller batch)", xb > wb ? xb : wb);
+        d.x_bytes = (unsigned)xb;
+        d.w_bytes = (unsigned)wb;
+        bool inside = true;
+        for (int t = 0; t < d.ntaps && inside; ++t) {
+            const int th = t / d.TW, dh = th * d.tap_sh + d.tap_h0, dw = (t - th * d.TW) * d.tap_sw + d.tap_w0;
+            const long h_lo = (long)d.g_h0 * d.in_sh + dh, h_hi = (long)(d.g_h0 + d.Hg - 1) * d.in_sh + dh;
+            const long w_lo = (long)d.g_w0 * d.in_sw + dw, w_hi = (long)(d.g_w0 + d.Wg - 1) * d.in_sw + dw;
+            inside = h_lo >= 0 && h_hi < d.Hin && w_lo >= 0 && w_hi < d.Win;
+        }
+        d.no_bounds = inside ? 1 : 0;
+        // wave-uniform tap per K tile: every 16-wide K tile lies inside one tap (and there is no ragged K tail)
+        d.uniform_taps = (d.ntaps > 1 ? (d.Cin % 16 == 0) : true) && (d.K % 16 == 0) ? 1 : 0;
+        if (d.in_scale && !d.uniform_taps) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: input batch-norm needs Cin %% 16 == 0");
+        if (!inside && d.ntaps > 64) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: padded conv with %d taps (max 64)", d.ntaps);
+    }
     if (tile == TILE_AUTO) tile = igemm_pick_tile(d);
+    if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
     switch (tile) {
         case TILE_128x128: return launch_cfg<128, 128, 64, 64>(d, s);
         case TILE_128x64: return launch_cfg<128, 64, 64, 32>(d, s);

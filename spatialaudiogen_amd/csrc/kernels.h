@@ -41,6 +41,13 @@ struct IgemmDesc {
     int ldy = 0;
     int relu_out = 0;
     int splitk = 1;
+    // filled by igemm_launch
+    unsigned x_bytes = 0, w_bytes = 0;
+    int no_bounds = 0;
+    int uniform_taps = 0;
+    // debug builds (-DSAGEN_TRACE): phase timeline of workgroup `trace_block`
+    void* trace = nullptr;
+    int trace_block = 0;
 };
 
 // tile configurations (BM x BN, 4 waves)

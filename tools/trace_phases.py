@@ -1,0 +1,44 @@
+"""Dev helper (GPU box): build a -DSAGEN_TRACE copy of the library and print the per-phase cycle
+timeline of one workgroup of the stage-2 conv."""
+import sys, os, subprocess, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+csrc = os.path.join(ROOT, 'spatialaudiogen_amd', 'csrc')
+out = '/tmp/libsagen_trace.so'
+srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'elementwise.hip', 'fft.hip', 'model.hip', 'api.hip')]
+extra = os.path.join('/tmp', 'trace_entry.hip')
+open(extra, 'w').write('''
+#include "%s/kernels.h"
+using namespace sagen;
+extern "C" int sagen_trace_conv(const float* x, const float* wp, float* y, float* stats, void* trace, int block,
+                                int B, int H, int W, int C, int tile, void* stream) {
+    IgemmDesc d;
+    d.x = x; d.w = wp; d.y = y; d.stats = stats;
+    d.M = B * H * W; d.N = C; d.K = 9 * C; d.Kpad = d.K; d.Hg = H; d.Wg = W; d.Hin = H; d.Win = W; d.Cin = C; d.ldx = C;
+    d.x_bstride = (long)H * W * C; d.ntaps = 9; d.TW = 3; d.tap_h0 = -1; d.tap_w0 = -1; d.log2Cin = ilog2_exact(C);
+    d.Cout = C; d.Hlim = H; d.Wlim = W; d.ldy = C; d.y_rstride = (long)W * C; d.y_bstride = (long)H * W * C;
+    d.trace = trace; d.trace_block = block;
+    return igemm_launch(d, (IgemmTile)tile, (hipStream_t)stream);
+}
+''' % csrc)
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSAGEN_TRACE'] + srcs + [extra, '-o', out]
+subprocess.check_call(cmd)
+lib = C.CDLL(out)
+B, H, W, Cc = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 64, 128, 64
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+block = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+x = torch.randn(B, H, W, Cc, device='cuda'); wp = torch.randn(Cc, 9 * Cc, device='cuda') * 0.05
+y = torch.empty(B, H, W, Cc, device='cuda'); stats = torch.zeros(1 << 20, device='cuda')
+trace = torch.zeros(4 * 64 * 8, dtype=torch.int64, device='cuda')
+p = lambda t: C.c_void_p(t.data_ptr())
+for _ in range(3):
+    rc = lib.sagen_trace_conv(p(x), p(wp), p(y), p(stats), p(trace), block, B, H, W, Cc, tile, None)
+    torch.cuda.synchronize()
+assert rc == 0, rc
+t = trace.cpu().numpy().reshape(4, 64, 8)
+for w in range(4):
+    tw = t[w, :36, :5].astype(np.int64)
+    print('wave', w, 'total per tile (median):', int(np.median(np.diff(tw[:, 0]))))
+    d = np.stack([tw[:, 1] - tw[:, 0], tw[:, 2] - tw[:, 1], tw[:, 3] - tw[:, 2], tw[:, 4] - tw[:, 3]], 1)
+    print('   load-issue, ds_read+MFMA, store(+vmcnt wait), barrier : median', np.median(d, 0).astype(int), ' tile 5:', d[5], ' tile 20:', d[20])
