@@ -362,10 +362,11 @@ class SptAudioGenOracle(object):
 # ----------------------------------------------------------------------------------------
 # deploy.py / feeder.py window arithmetic (row 13) — host float64 quirks reproduced verbatim
 # ----------------------------------------------------------------------------------------
-def audio_pow_times(clip_duration, duration=0.1, context=1.0):
-    """Times listed in audio_pow.lst (scraping/preprocess.py:146-153): 0.5, 0.6, ... while the
-    full context fits; reproduced as written (np.arange)."""
-    return [float(t) for t in np.arange(context / 2., clip_duration - context / 2. - duration, duration)]
+def audio_pow_times(n_audio_files):
+    """Times listed in audio_pow.lst (scraping/preprocess.py:146-153): t = i/10.+0.5 for
+    i < (duration-1)*10, where duration = number of 1-s wav chunks; written with '{}'.format(t)
+    (Python 2: 12 significant digits) and parsed back with float() (feeder.py:217)."""
+    return [float('%.12g' % (i / 10. + 0.5)) for i in range((int(n_audio_files) - 1) * 10)]
 
 
 def deploy_window_table(chunks_t, deploy_start=0., deploy_duration=10., audio_rate=48000,

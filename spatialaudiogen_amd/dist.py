@@ -1,0 +1,55 @@
+"""Multi-GPU: one process per GPU, windows/clips sharded over ranks, no data-path collective.
+
+The reference is single-device (deploy.py:156, eval.py:33).  Clips are independent given whole
+batches (training-mode batch-norm couples windows of a batch), so each rank owns a
+full weight replica and a contiguous block of clips; the only exchange is the eval-time reduction
+of metric sums (model.py:122-150 families + count), one all-reduce over RCCL ('nccl' on ROCm) —
+or gloo on CPU for tests.
+"""
+import os
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous block [lo, hi) of rank `rank`: sizes differ by at most one, order preserved."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_process_group(backend=None):
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world == 1:
+        return 0, 1
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group(backend, rank=int(os.environ['RANK']), world_size=world)
+    return dist.get_rank(), world
+
+
+class MetricReducer(object):
+    """Per-rank float64 sums + sample count -> global means with ONE all-reduce (232 bytes for the 28
+    metric sums of eval.py:125-133)."""
+
+    def __init__(self, names, device=None):
+        import torch
+        self.names = list(names)
+        self.buf = torch.zeros(len(self.names) + 1, dtype=torch.float64, device=device)
+
+    def add(self, values, count):
+        import torch
+        self.buf[:-1] += torch.as_tensor(values, dtype=torch.float64, device=self.buf.device) * count
+        self.buf[-1] += count
+
+    def reduce(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.buf)
+        total = float(self.buf[-1].item())
+        vals = (self.buf[:-1] / max(total, 1.0)).tolist()
+        return dict(zip(self.names, vals)), int(total)

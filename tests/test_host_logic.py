@@ -1,0 +1,61 @@
+"""Host-side logic: deploy window arithmetic (row 13), parameter-file parsing, sharding."""
+import os
+import numpy as np
+
+from oracle import np_oracle as O
+from spatialaudiogen_amd import deploy as D
+from spatialaudiogen_amd.dist import shard_range
+
+
+def test_window_table_reproduces_reference_float_quirks():
+    """Transcription of feeder.py:64-72,121 + deploy.py:106-107: with audio_pow times
+    0.5,0.6,... the shifted times are float64 values like 0.09999999999999998, so int() truncates: frame
+    indices 0,0,1,3,4,5 (frame 2 never) and audio starts off by one in ~20% of the windows."""
+    chunks = O.audio_pow_times(12)
+    rows = O.deploy_window_table(chunks, 0., 10.)
+    assert len(rows) == 95 and rows[-1][4] == 9                       # 95 windows, 10 groups (last has 5)
+    assert [r[3] for r in rows[:8]] == [0, 0, 1, 3, 4, 5, 6, 7]
+    assert [r[1] for r in rows[:8]] == [-24000, -19200, -14400, -9599, -4799, 0, 4800, 9599]
+    assert [r[2] for r in rows[:6]] == [24000, 19200, 14400, 9599, 4799, 0]
+    assert len(O.deploy_window_table(O.audio_pow_times(10), 0., 10.)) == 90
+
+
+def test_deploy_helpers_match_the_oracle_table():
+    chunks = O.audio_pow_times(12)
+    ts = D.window_times(chunks, 0., 10.)
+    rows = O.deploy_window_table(chunks, 0., 10.)
+    assert ts == [r[0] for r in rows]
+    assert [D.frame_index(t, 10) for t in ts] == [r[3] for r in rows]
+    audio = (np.arange(12 * 48000, dtype=np.float64) + 1.0)[:, None]    # sample value = index + 1
+    for t, start, pad_before, _, _ in rows:
+        w = D.audio_window(audio, t, 1.0, 52799, 48000)
+        assert w.shape == (52799, 1)
+        assert np.all(w[:pad_before] == 0)
+        assert w[pad_before, 0] == max(start, 0) + 1                    # first real sample
+    late = D.audio_window(audio, 11.9, 1.0, 52799, 48000)              # runs past the end: zero post-padding
+    assert late.shape == (52799, 1) and late[-1, 0] == 0 and late[0, 0] == int(11.4 * 48000) + 1
+
+
+def test_load_params_defaults_and_types(tmp_path):
+    (tmp_path / 'train-params.txt').write_text(
+        "encoders: ['audio', 'video']\nseparation: UNET_MASK\nambi_order: 1\naudio_rate: 48000\nvideo_rate: 10\n"
+        "context: 1.0\nsample_dur: 0.1\nlr: 0.0001\n")
+    p = D.load_params(str(tmp_path))
+    assert p.encoders == ['audio', 'video'] and p.separation == 'unet_mask'
+    assert p.num_sep_tracks == 64 and p.loc_units == [256, 256]       # legacy defaults (myutils.py:55-76)
+    assert p.fft_window == 0.025 and p.context_units == [64, 128, 128] and p.freq_mask_units == []
+    (tmp_path / 'train-params.txt').write_text(
+        "encoders: ['audio']\nseparation: none\nambi_order: 1\naudio_rate: 48000\nvideo_rate: 10\ncontext: 1.0\n"
+        "num_sep_tracks: 32\nloc_units: [512, 512]\nfreq_mask_units: []\n")
+    p = D.load_params(str(tmp_path))
+    assert p.num_sep_tracks == 32 and p.loc_units == [512, 512] and p.separation == 'none'
+
+
+def test_shard_range_partitions_in_order():
+    for n in (0, 1, 7, 8, 1024, 1023):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1

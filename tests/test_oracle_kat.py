@@ -1,0 +1,151 @@
+"""Known-answer tests that pin the CPU oracle without the (uninstallable) TF1 reference:
+analytic identities from SURVEY.md 8(c)/9 plus the reference's own structural facts."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from spatialaudiogen_amd.geometry import Geometry
+from spatialaudiogen_amd.weights import variable_specs, count_params, init_weights
+from util import rng, rms
+
+
+def test_geometry_matches_reference_constants():
+    g = Geometry()
+    assert (g.snd_contx, g.snd_dur, g.snd_size, g.wind_size, g.n_frames) == (48000, 4800, 52799, 1024, 200)
+    assert (g.enc_ss, g.enc_tt) == (46, 173) and (g.mask_ss, g.mask_tt) == (89, 117)
+    assert (g.dec_row0, g.dec_row1) == (43, 71) and g.istft_len == 6400 and g.out_crop0 == 448
+    assert g.encoder_shapes() == [(127, 1024, 1), (31, 127, 32), (15, 31, 64), (7, 14, 128), (5, 10, 256), (3, 6, 512)]
+
+
+def test_variable_inventory_totals():
+    assert count_params(variable_specs(['audio'])) == 12614723
+    assert count_params(variable_specs(['audio', 'video'])) == 30810243
+    assert count_params(variable_specs(['audio', 'video', 'flow'])) == 49005763
+    s = variable_specs(['audio', 'video'])
+    assert s['separation/deconv1/weights'] == (7, 16, 32, 64)            # [kh,kw,Cout,Cin]  (core.py:118)
+    assert s['video_encoder/conv3_1/shortcut/weights'] == (1, 1, 64, 128)
+    assert 'video_encoder/conv3_1/shortcut/biases' not in s              # no bias, no bn (resnet.py:211-212)
+    assert s['bottleneck/video-fc/weights'] == (12544, 512) and s['localization/fc3/weights'] == (512, 99)
+
+
+def test_stft_frames_are_hop256_hann_ffts():
+    r = rng(0)
+    x = r.normal(size=(2, 1, 52799))
+    S = O.stft(x, 1024, 4)
+    assert S.shape == (2, 1, 200, 1024)
+    hann = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1024)
+    for t in (0, 1, 46, 89, 117, 199):
+        ref = np.fft.fft(x[:, 0, 256 * t:256 * t + 1024] * hann.astype(np.float32))
+        assert np.abs(S[:, 0, t] - ref).max() < 1e-9
+
+
+def test_stft_sinusoid_known_answer_and_cola():
+    n = np.arange(52799)
+    k0, A = 37, 0.7
+    S = O.stft((A * np.cos(2 * np.pi * k0 * n / 1024.))[None, None], 1024, 4)[0, 0]
+    assert np.allclose(np.abs(S[:, k0]), 256 * A, rtol=1e-6) and np.allclose(np.abs(S[:, 1024 - k0]), 256 * A, rtol=1e-6)
+    assert np.allclose(np.abs(S[:, k0 + 1]), 128 * A, rtol=1e-6)
+    hann = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1024)
+    cola = sum(np.roll(hann, 256 * i) for i in range(4))
+    assert np.allclose(cola, 2.0)
+
+
+def test_identity_mask_round_trip_is_half_mono():
+    """istft(stft(x)[89:117])[448:5248] == 0.5 * x[24000:28800]  (SURVEY.md 9.3)."""
+    x = rng(1).normal(size=(1, 1, 52799))
+    S = O.stft(x, 1024, 4)[:, :, 89:117]
+    y = O.istft(S, 4)
+    assert y.shape == (1, 1, 6400)
+    # exact up to the float32 rounding of the Hann table the reference builds (myutils.py:134)
+    assert np.abs(y[0, 0, 448:5248] - 0.5 * x[0, 0, 24000:28800]).max() < 3e-7
+
+
+def test_same_padding_table():
+    """TF SAME pads asymmetrically (extra after)."""
+    assert O.same_pad(224, 7, 2) == (112, 2, 3) and O.same_pad(448, 7, 2) == (224, 2, 3)
+    assert O.same_pad(112, 3, 2) == (56, 0, 1) and O.same_pad(56, 3, 1) == (56, 1, 1)
+    assert O.same_pad(56, 3, 2) == (28, 0, 1) and O.same_pad(56, 1, 2) == (28, 0, 0)
+
+
+@pytest.mark.parametrize('k,s,padding', [((3, 3), (1, 1), 'SAME'), ((3, 3), (2, 2), 'SAME'), ((7, 7), (2, 2), 'SAME'),
+                                         ((3, 5), (2, 2), 'VALID'), ((1, 1), (2, 2), 'SAME')])
+def test_delta_kernel_convs_are_strided_crops(k, s, padding):
+    """A one-hot filter tap (p,q) must return x shifted by (p - pad_top, q - pad_left) and strided."""
+    x = rng(2).normal(size=(1, 12, 14, 2))
+    H, W = x.shape[1:3]
+    for (p, q) in [(0, 0), (k[0] - 1, k[1] - 1), (k[0] // 2, k[1] // 2)]:
+        w = np.zeros(k + (2, 2))
+        w[p, q] = np.eye(2)
+        y = O.nn_convolution(x, w, s, padding)
+        pt = O.same_pad(H, k[0], s[0])[1] if padding == 'SAME' else 0
+        pl = O.same_pad(W, k[1], s[1])[1] if padding == 'SAME' else 0
+        for i in range(y.shape[1]):
+            for j in range(y.shape[2]):
+                hi, wi = i * s[0] + p - pt, j * s[1] + q - pl
+                ref = x[0, hi, wi] if (0 <= hi < H and 0 <= wi < W) else 0.0
+                assert np.allclose(y[0, i, j], ref)
+
+
+def test_conv2d_transpose_is_the_adjoint_of_conv2d():
+    """tf.nn.conv2d_transpose is defined as the gradient of conv2d: <conv(x,w), y> == <x, convT(y,w')>
+    with w' = w viewed as [kh,kw,Cout(of convT),Cin(of convT)]."""
+    r = rng(3)
+    for k, s in [((3, 5), (1, 1)), ((3, 7), (2, 4)), ((7, 16), (4, 8))]:
+        cx, cy = 3, 5                                     # conv: cx -> cy ; convT: cy -> cx
+        y = r.normal(size=(2, 4, 6, cy))
+        w = r.normal(size=k + (cx, cy))                   # HWIO of the forward conv == [kh,kw,Cout,Cin] of its transpose
+        xt = O.nn_conv2d_transpose(y, w, s)               # [2, 4*s+k-s, ..., cx]
+        x = r.normal(size=xt.shape)
+        fwd = O.nn_convolution(x, w, s, 'VALID')
+        assert fwd.shape == y.shape
+        assert np.isclose((fwd * y).sum(), (x * xt).sum(), rtol=1e-10)
+
+
+def test_batch_norm_training_mode():
+    x = rng(4).normal(2.0, 3.0, size=(4, 5, 6, 7))
+    y = O.batch_norm_train(x, np.ones(7), np.zeros(7))
+    assert np.abs(y.mean(axis=(0, 1, 2))).max() < 1e-12
+    v = x.var(axis=(0, 1, 2))
+    assert np.allclose(y.var(axis=(0, 1, 2)), v / (v + 1e-3))
+
+
+def test_maxpool_same_uses_minus_inf_padding():
+    x = -np.ones((1, 4, 4, 1))
+    y = O.max_pool_3x3_s2_same(x)
+    assert y.shape == (1, 2, 2, 1) and np.all(y == -1)     # zero padding would have produced 0
+
+
+def test_sh_matrix_acn_sn3d_against_reference_formula():
+    """common.py:121-178: (-1)^m * norm * lpmv(|m|, n, sin(nu)) * cos/sin(|m| phi), ACN order W,Y,Z,X."""
+    from scipy.special import lpmv
+    r = rng(5)
+    phi, nu = r.uniform(-np.pi, np.pi, 50), r.uniform(-np.pi / 2, np.pi / 2, 50)
+    Y = O.sh_matrix_order1(phi, nu)
+    ref = np.zeros((50, 4))
+    for idx, (n, m) in enumerate([(0, 0), (1, -1), (1, 0), (1, 1)]):      # ACN index n(n+1)+m
+        ref[:, idx] = (-1) ** m * 1.0 * lpmv(abs(m), n, np.sin(nu)) * (np.cos(abs(m) * phi) if m >= 0 else np.sin(abs(m) * phi))
+    assert np.abs(Y - ref).max() < 1e-12
+    assert np.allclose(O.sh_matrix_order1([np.pi / 2], [0.]), [[1, 1, 0, 0]], atol=1e-15)
+    assert np.allclose(O.sh_matrix_order1([0.], [0.]), [[1, 0, 0, 1]], atol=1e-15)
+    assert np.allclose(O.sh_matrix_order1([0.3], [np.pi / 2]), [[1, 0, 1, 0]], atol=1e-15)
+    phi_m, nu_m = O.spherical_mesh(30.)
+    assert phi_m.shape == (7, 12)
+
+
+def test_decoder_selects_track_and_step():
+    """Oracle end-to-end with hand-set localisation (fc3 weights 0, biases one-hot): channel o of window
+    samples [1600 s, 1600 (s+1)) equals the chosen separated track — pins channel order Y,Z,X."""
+    enc = ['audio']
+    P = init_weights(variable_specs(enc), seed=3, mode='test')
+    P['localization/fc3/weights'][:] = 0
+    b = np.zeros((3, 1, 33), np.float32)
+    b[0, 0, 4], b[1, 0, 32], b[2, 0, 9] = 1.0, 0.25, -1.0
+    P['localization/fc3/biases'][:] = b.reshape(-1)
+    from spatialaudiogen_amd.weights import synth_inputs
+    inp = synth_inputs(1, enc, seed=7)
+    orc = O.SptAudioGenOracle(encoders=enc)
+    y = orc.inference_ops(inp['audio'], P)
+    tr = orc.ends['separation/all_channels'][:, 0]
+    assert rms(y[:, :, 0] - tr[:, 4]) < 1e-12 and np.abs(y[:, :, 1] - 0.25).max() < 1e-12 and rms(y[:, :, 2] + tr[:, 9]) < 1e-12
+    assert orc.ends['separation/deconv1'].shape == (1, 127, 1024, 32)
+    assert orc.ends['separation/mask'].shape == (1, 1, 32, 28, 1024)
