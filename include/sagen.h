@@ -108,6 +108,17 @@ int    sagen_assemble_wyzx(const float* audio, const float* ambi_yzx, float* out
 int    sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float** data,
                               int32_t* ndim, int64_t shape[4], int64_t* pixel_stride);
 
+/* Per-layer launch planning (no reference analogue; cuDNN-style autotune): runs one forward on the given
+ * inputs in which every contraction times its (tile shape, split-K) candidates with hipEvents and keeps the
+ * fastest; later sagen_forward calls use the stored plan.  Synchronises the stream.  Without it (or with
+ * SAGEN_NO_AUTOTUNE set) shape heuristics are used.  sagen_plan_describe writes
+ * "layer\ttile\tsplitk\tmicroseconds\n" per contraction and returns the number of lines. */
+int    sagen_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow,
+                      float* ambi_yzx, void* stream);
+int    sagen_plan_describe(sagen_ctx* ctx, char* buf, size_t buflen);
+/* pin one layer's launch: tile = 0..5 (128x128, 128x64, 256x64, 64x64, 128x32, 32x128), splitk >= 1 */
+int    sagen_plan_set(sagen_ctx* ctx, const char* layer, int tile, int splitk);
+
 /* Measurement aid (the reference's only analogue is the samples/sec printout, myutils.py:15-26):
  * when enabled, every launch of the following sagen_forward calls is bracketed by a pair of
  * hipEvents on the launch stream.  sagen_profile_report waits for the last forward's events and
@@ -127,7 +138,8 @@ int sagen_stft_mag(const float* audio, int batch, int n_samples, int f0, int f1,
 
 /* tfw.conv_2d (core.py:156-220) = tf.nn.convolution NHWC/HWIO + (bias | nothing) + optional ReLU.
  * padding: 0 = VALID, 1 = SAME (TF asymmetric).  Batch-norm is NOT applied here: pass bn_stats
- * (>= sagen_bn_stats_floats(...) floats) to receive per-channel partial sums of the raw output and
+ * (>= sagen_bn_stats_floats(...) floats, 8-byte aligned; holds 2*cout fp64 accumulators that the call
+ * zeroes and fills with the per-channel sum and sum of squares of the raw output) and
  * call sagen_bn_finalize; the consumer applies scale/shift (+ReLU) via in_scale/in_shift.
  * in_scale/in_shift [Cin] (nullable): input is relu(x*scale+shift) before padding.
  * scratch: >= sagen_conv2d_scratch_bytes(...) bytes for the repacked filter (and, for cin == 3, the

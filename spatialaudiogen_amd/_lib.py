@@ -42,6 +42,9 @@ SIGNATURES = {
     'sagen_assemble_wyzx': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'sagen_get_intermediate': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]),
+    'sagen_autotune': (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    'sagen_plan_set': (C.c_int, [_P, C.c_char_p, _I, _I]),
+    'sagen_plan_describe': (C.c_int, [_P, C.c_char_p, _SZ]),
     'sagen_profile_enable': (C.c_int, [_P, _I]),
     'sagen_profile_report': (C.c_int, [_P, C.c_char_p, _SZ]),
     'sagen_stft_mag': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),

@@ -12,6 +12,9 @@ size_t sagen_workspace_bytes_impl(const sagen_ctx* c);
 int sagen_num_variables_impl(const sagen_ctx* c);
 int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32_t* ndim, int64_t shape[4]);
 int sagen_profile_enable_impl(sagen_ctx* c, int on);
+int sagen_autotune_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
+int sagen_plan_describe_impl(sagen_ctx* c, char* buf, size_t buflen);
+int sagen_plan_set_impl(sagen_ctx* c, const char* layer, int tile, int splitk);
 int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen);
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride);
@@ -78,6 +81,17 @@ int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float**
     return guarded([&] { return sagen_get_intermediate_impl(ctx, name, data, ndim, shape, pixel_stride); });
 }
 
+int sagen_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {
+    return guarded([&] { return sagen_autotune_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
+}
+int sagen_plan_set(sagen_ctx* ctx, const char* layer, int tile, int splitk) {
+    if (!ctx || !layer) return fail(SAGEN_ERR_NULL, "sagen_plan_set: null argument");
+    return guarded([&] { return sagen_plan_set_impl(ctx, layer, tile, splitk); });
+}
+int sagen_plan_describe(sagen_ctx* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf) return fail(SAGEN_ERR_NULL, "sagen_plan_describe: null argument");
+    return guarded([&] { return sagen_plan_describe_impl(ctx, buf, buflen); });
+}
 int sagen_profile_enable(sagen_ctx* ctx, int on) {
     if (!ctx) return fail(SAGEN_ERR_NULL, "sagen_profile_enable: null ctx");
     return sagen_profile_enable_impl(ctx, on);
@@ -107,7 +121,8 @@ size_t sagen_conv2d_scratch_bytes(int batch, int h, int w, int kh, int kw, int c
 }
 
 size_t sagen_bn_stats_floats(int batch, int hout, int wout, int cout) {
-    return (size_t)cdiv((long)batch * hout * wout, 32) * 2 * cout;     // covers every tile height
+    (void)batch; (void)hout; (void)wout;
+    return (size_t)4 * cout;                  // two fp64 accumulators per channel
 }
 
 int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* w_hwio, int kh, int kw, int cout, int sh,
@@ -134,7 +149,7 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
         }
         float* wp = (float*)scratch;
         IgemmDesc d;
-        d.y = y; d.bias = bias; d.relu_out = relu; d.in_scale = in_scale; d.in_shift = in_shift; d.stats = bn_stats;
+        d.y = y; d.bias = bias; d.relu_out = relu; d.in_scale = in_scale; d.in_shift = in_shift; d.stats = (double*)bn_stats;
         d.M = batch * Hout * Wout; d.N = cout; d.Cout = cout;
         d.Hg = Hout; d.Wg = Wout; d.Hlim = Hout; d.Wlim = Wout;
         d.ldy = cout; d.y_rstride = (long)Wout * cout; d.y_bstride = (long)Hout * Wout * cout;
@@ -166,6 +181,7 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
             rc = pack_conv_launch(w_hwio, kh * kw, cin, cin, cout, wp, cout, d.Kpad, s);
         }
         if (rc) return rc;
+        if (bn_stats) SAGEN_HIP_CHECK(hipMemsetAsync(bn_stats, 0, (size_t)2 * cout * sizeof(double), s));
         return igemm_launch(d, TILE_AUTO, s);
     });
 }
@@ -173,10 +189,9 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
 int sagen_bn_finalize(const float* bn_stats, int batch, int hout, int wout, int cout, const float* gamma, const float* beta,
                       float eps, float* scale, float* shift, void* stream) {
     if (!bn_stats || !gamma || !beta || !scale || !shift) return fail(SAGEN_ERR_NULL, "sagen_bn_finalize: null argument");
-    IgemmDesc d;
-    d.M = batch * hout * wout; d.N = cout;
-    const int tiles = igemm_grid_m(d, TILE_AUTO);
-    return bn_finalize_launch(bn_stats, tiles, (long)d.M, cout, gamma, beta, eps, scale, shift, (hipStream_t)stream);
+    if (((uintptr_t)bn_stats) % 8) return fail(SAGEN_ERR_SHAPE, "sagen_bn_finalize: bn_stats must be 8-byte aligned");
+    return bn_finalize_launch((const double*)bn_stats, (long)batch * hout * wout, cout, gamma, beta, eps, scale, shift,
+                              (hipStream_t)stream);
 }
 
 int sagen_bn_apply_relu(const float* x, const float* scale, const float* shift, const float* residual, float* y,
@@ -223,7 +238,7 @@ int sagen_fc(const float* x, int m, int k, const float* w_kn, int n, const float
             d.splitk = sk; d.splitk_ws = ws;
             rc = igemm_launch(d, tile, s);
             if (rc) return rc;
-            return splitk_reduce_launch(ws, sk, m, n, bias, relu, y, n, 1, s);
+            return splitk_reduce_launch(ws, sk, m, n, bias, relu, y, n, 1, nullptr, s);
         }
         d.bias = bias; d.relu_out = relu;
         return igemm_launch(d, tile, s);

@@ -8,38 +8,25 @@ namespace sagen {
 // -----------------------------------------------------------------------------------------
 // contrib batch_norm, training mode (core.py:6,209-210): per-tile partial (sum, sumsq) ->
 // scale = gamma / sqrt(var + eps), shift = beta - mean * scale; biased variance.
-// One 64-lane wave per channel; fp64 accumulation of the fp32 partials.
+// The producers (conv epilogue / split-K reduce) accumulate per-channel (sum, sumsq) with fp64 atomics.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ stats, int n_tiles, double inv_count,
-                                                         int C, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float eps,
-                                                         float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x;
-    const int lane = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int t = lane; t < n_tiles; t += 64) {
-        s += (double)stats[((long)t * 2 + 0) * C + c];
-        q += (double)stats[((long)t * 2 + 1) * C + c];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        q += __shfl_xor(q, o);
-    }
-    if (lane == 0) {
-        const double mean = s * inv_count;
-        double var = q * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double sc = (double)gamma[c] / sqrt(var + (double)eps);
-        scale[c] = (float)sc;
-        shift[c] = (float)((double)beta[c] - mean * sc);
-    }
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ acc, double inv_count, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = acc[c] * inv_count;
+    double var = acc[C + c] * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)gamma[c] / sqrt(var + (double)eps);
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mean * sc);
 }
 
-int bn_finalize_launch(const float* stats, int n_tiles, long count, int C, const float* gamma, const float* beta,
-                       float eps, float* scale, float* shift, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, stats, n_tiles, 1.0 / (double)count, C, gamma, beta,
-                       eps, scale, shift);
+int bn_finalize_launch(const double* stats, long count, int C, const float* gamma, const float* beta, float eps,
+                       float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, stats, 1.0 / (double)count, C, gamma, beta, eps,
+                       scale, shift);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

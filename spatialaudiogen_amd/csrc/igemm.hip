@@ -23,8 +23,8 @@
 //  * double-buffered LDS, one barrier per K tile; the DMA of tile t+1 flies under the MFMAs of t.
 //  * the previous layer's training-mode batch-norm (relu(v*scale+shift)) is applied to A fragments
 //    after the LDS read (padding stays exactly zero through the per-row masks).
-//  * epilogue: bias / ReLU, depth-to-space scatter (transposed convs), per-tile per-channel
-//    (sum, sumsq) partials for batch-norm, or raw split-K partials.
+//  * epilogue: bias / ReLU, depth-to-space scatter (transposed convs), per-channel (sum, sumsq)
+//    accumulated with fp64 atomics for batch-norm, or raw split-K partials.
 #include "kernels.h"
 #include <cstdlib>
 
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
                 float s = 0.f;
 #pragma unroll
                 for (int w2 = 0; w2 < WAVES_M; ++w2) s += red[(which * WAVES_M + w2) * BN + col];
-                d.stats[((long)tile_m * 2 + which) * d.N + n] = s;
+                atomicAdd(&d.stats[(long)which * d.N + n], (double)s);      // fp64 accumulator [2][N], zeroed per forward
             }
         }
     }
@@ -430,6 +430,9 @@ static int tile_bn(IgemmTile t) {
         default: return 0;
     }
 }
+
+int igemm_tile_bm(IgemmTile t) { return tile_bm(t); }
+int igemm_tile_bn(IgemmTile t) { return tile_bn(t); }
 
 const char* igemm_tile_name(IgemmTile t) {
     switch (t) {
@@ -514,24 +517,100 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
 // -----------------------------------------------------------------------------------------
 // split-K reduction + bias + activation + (optional) row replication
 // -----------------------------------------------------------------------------------------
+// out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]).  One thread per 4 columns (N % 4 == 0) or per
+// column; fully parallel over M x N.
+template <int V>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
                                                             const float* __restrict__ bias, int relu,
                                                             float* __restrict__ y, int ldy, int rep) {
+    const int NV = N / V;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)M * N) return;
-    const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
-    float v = 0.f;
-    for (int zz = 0; zz < splitk; ++zz) v += ws[((long)zz * M + m) * N + n];
-    if (bias) v += bias[n];
-    if (relu) v = fmaxf(v, 0.f);
-    for (int r = 0; r < rep; ++r) y[((long)m * rep + r) * ldy + n] = v;
+    if (idx >= (long)M * NV) return;
+    const int m = (int)(idx / NV), n = (int)(idx - (long)m * NV) * V;
+    float v[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = 0.f;
+    const long MN = (long)M * N;
+    const float* p = ws + (long)m * N + n;
+    for (int zz = 0; zz < splitk; ++zz, p += MN) {
+        if (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] += t.x; v[1 % V] += t.y; v[2 % V] += t.z; v[3 % V] += t.w;
+        } else {
+            v[0] += p[0];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        if (bias) v[i] += bias[n + i];
+        if (relu) v[i] = fmaxf(v[i], 0.f);
+    }
+    for (int r = 0; r < rep; ++r) {
+        float* o = y + ((long)m * rep + r) * ldy + n;
+        if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+        else o[0] = v[0];
+    }
+}
+
+// Same sum, plus the per-channel (sum, sumsq) of the raw sums over each block of SPLITK_RB rows
+// (training-mode batch-norm statistics of a split-K conv).  Thread t owns 4 columns n = 4*(t % CN4) and rows
+// (t / CN4) + i*(256 / CN4) of its row block; grid (row blocks, column blocks of 4*CN4).
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ ws, int splitk, int M, int N,
+                                                                  float* __restrict__ y, int ldy, double* __restrict__ stats,
+                                                                  int CN4) {
+    __shared__ float4 red[2][256];
+    const int tid = threadIdx.x;
+    const int cl = tid % CN4, rl = tid / CN4, RL = 256 / CN4;
+    const int n = (blockIdx.y * CN4 + cl) * 4;
+    const int r0 = blockIdx.x * SPLITK_RB;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    const long MN = (long)M * N;
+    if (n < N) {
+        for (int r = rl; r < SPLITK_RB; r += RL) {
+            const int m = r0 + r;
+            if (m >= M) break;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* p = ws + (long)m * N + n;
+            for (int zz = 0; zz < splitk; ++zz, p += MN) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+            *reinterpret_cast<float4*>(y + (long)m * ldy + n) = v;
+        }
+    }
+    red[0][tid] = s;
+    red[1][tid] = q;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        for (int k = 1; k < RL; ++k) {
+            const float4 a = red[0][k * CN4 + cl], b = red[1][k * CN4 + cl];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            q.x += b.x; q.y += b.y; q.z += b.z; q.w += b.w;
+        }
+        atomicAdd(&stats[n + 0], (double)s.x); atomicAdd(&stats[n + 1], (double)s.y);
+        atomicAdd(&stats[n + 2], (double)s.z); atomicAdd(&stats[n + 3], (double)s.w);
+        atomicAdd(&stats[N + n + 0], (double)q.x); atomicAdd(&stats[N + n + 1], (double)q.y);
+        atomicAdd(&stats[N + n + 2], (double)q.z); atomicAdd(&stats[N + n + 3], (double)q.w);
+    }
 }
 
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
-                         float* y, int ldy, int rep, hipStream_t s) {
-    const long total = (long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, ws, splitk, M, N, bias, relu,
-                       y, ldy, rep);
+                         float* y, int ldy, int rep, double* stats, hipStream_t s) {
+    if (stats) {
+        if (N % 4 || ldy % 4 || rep != 1 || bias || relu)
+            return fail(SAGEN_ERR_UNSUPPORTED, "split-K reduce with statistics needs N %% 4 == 0 and a plain epilogue");
+        const int CN4 = N >= 256 ? 64 : (N >= 128 ? 32 : 16);         // 256 / 128 / 64 columns per workgroup
+        dim3 grid(cdiv(M, SPLITK_RB), cdiv(N, CN4 * 4));
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, s, ws, splitk, M, N, y, ldy, stats, CN4);
+    } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0)) {
+        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, s, ws, splitk, M, N, bias,
+                           relu, y, ldy, rep);
+    } else {
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv((long)M * N, 256)), dim3(256), 0, s, ws, splitk, M, N, bias, relu,
+                           y, ldy, rep);
+    }
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -21,7 +21,7 @@ struct IgemmDesc {
     const float* bias = nullptr;      // [Cout] or null
     const float* in_scale = nullptr;  // [Cin] or null
     const float* in_shift = nullptr;
-    float* stats = nullptr;           // [gridM][2][N] per-tile (sum, sumsq) of raw output, or null
+    double* stats = nullptr;          // fp64 accumulators [2][N] of (sum, sumsq) of the raw output (atomics), or null
     float* splitk_ws = nullptr;       // [splitk][M][N] when splitk > 1
     int M = 0, N = 0, K = 0, Kpad = 0;
     // output grid
@@ -56,10 +56,14 @@ enum IgemmTile { TILE_128x128 = 0, TILE_128x64, TILE_256x64, TILE_64x64, TILE_12
 int igemm_launch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);
 int igemm_grid_m(const IgemmDesc& d, IgemmTile tile);       // number of M tiles (stats rows)
 IgemmTile igemm_pick_tile(const IgemmDesc& d);
-const char* igemm_tile_name(IgemmTile t);              // instantiation name as rocprofv3 prints it
-// out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep)
+const char* igemm_tile_name(IgemmTile t);
+int igemm_tile_bm(IgemmTile t);
+int igemm_tile_bn(IgemmTile t);              // instantiation name as rocprofv3 prints it
+// out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the
+// per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)
+constexpr int SPLITK_RB = 16;
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
-                         float* y, int ldy, int rep, hipStream_t s);
+                         float* y, int ldy, int rep, double* stats, hipStream_t s);
 
 // filter repacking (pack.hip).  All produce [Npad][Kpad] with zero padding.
 // conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src)
@@ -73,7 +77,8 @@ int pack_deconv_launch(const float* w_hwoi, int kh, int kw, int cout, int cin, i
 // -----------------------------------------------------------------------------------------
 // batch-norm / elementwise (elementwise.hip)
 // -----------------------------------------------------------------------------------------
-int bn_finalize_launch(const float* stats, int n_tiles, long count, int C, const float* gamma,
+// stats: fp64 accumulators [2][C] (sum, sumsq) filled by the producer's atomics
+int bn_finalize_launch(const double* stats, long count, int C, const float* gamma,
                        const float* beta, float eps, float* scale, float* shift, hipStream_t s);
 int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const float* residual,
                          float* y, long n_pixels, int C, hipStream_t s);

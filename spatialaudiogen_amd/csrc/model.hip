@@ -2,6 +2,8 @@
 // filter repacking and the launch sequence that replaces one sess.run of
 // SptAudioGen.inference_ops (reference model.py:356-434; called at deploy.py:141, eval.py:145).
 #include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -45,8 +47,18 @@ struct ProfRec {
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
+struct Choice {          // how one contraction is launched
+    int tile = -1;       // IgemmTile, -1 = heuristic
+    int splitk = 0;      // 0 = heuristic
+    float us = 0.f;      // measured time of the choice (autotune)
+};
+
 struct sagen_ctx {
     sagen_config cfg;
+    // per-layer launch plan (filled by sagen_autotune; empty = heuristics)
+    std::map<std::string, Choice> plan;
+    bool tuning = false;
+    hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // optional per-launch HIP-event profiler (sagen_profile_enable)
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -256,7 +268,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->alloc("bott", (size_t)B * 3 * c->Cb);
     for (int i = 0; i < cfg->n_loc_units; ++i) c->alloc("loc" + std::to_string(i + 1), (size_t)B * 3 * cfg->loc_units[i]);
     c->alloc("coeffs", (size_t)B * 3 * 3 * (c->nsep + 1));
-    c->alloc("splitk", (size_t)16 << 20);            // 64 MB of fp32 partials, checked per use
+    c->alloc("splitk", std::max<size_t>((size_t)16 << 20, (size_t)B * 56 * 112 * 64 * 2));   // fp32 split-K partials (up to 2 splits of the largest conv), checked per use
     if (c->freq_mask) {
         c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
         c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
@@ -266,7 +278,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         c->alloc("y0", (size_t)B * 112 * 224 * 64);
         const size_t stage = (size_t)B * 56 * 112 * 64;
         for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc"}) c->alloc(nm, stage);
-        c->alloc("stats", (size_t)cdiv((long)B * 112 * 224, 128) * 2 * 64 + 4096);
+        c->alloc("bnacc", (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer of one stream
         c->alloc("bnp", (size_t)24 * 2 * 512);        // scale/shift per BN layer of one stream
         c->alloc("fcred", (size_t)B * 98 * 128);
     }
@@ -378,30 +390,100 @@ struct Fwd {
         c->prof.push_back(r);
     }
 
-    // run one contraction, through split-K + reduce when parallelism is low or rows are replicated
-    void gemm(IgemmDesc d, int rep = 1, bool allow_split = true) {
-        if (rc) return;
-        IgemmTile tile = igemm_pick_tile(d);
-        const bool plain = d.dsh * d.dsw == 1 && !d.stats;
-        int sk = (plain && allow_split) ? auto_splitk(d, tile) : 1;
-        if (rep > 1 && !plain) { rc = fail(SAGEN_ERR_UNSUPPORTED, "replicated store needs a plain epilogue"); return; }
+    // ---- one contraction: direct, or split-K partials + reduce (bias / ReLU / row replication / BN statistics) ----
+    bool dense_out(const IgemmDesc& d) const {
+        return d.dsh * d.dsw == 1 && d.g_h0 == 0 && d.g_w0 == 0 && d.y_rstride == (long)d.Wg * d.ldy &&
+               (d.M <= d.Hg * d.Wg || d.y_bstride == (long)d.Hg * d.Wg * d.ldy);
+    }
+    size_t ws_capacity() const { return c->bufs.at("splitk").n; }
+
+    // launches the contraction with an explicit choice; returns the number of BN partial rows written (0 if none)
+    int run_choice(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
+        if (rc) return 0;
         if (sk > 1 || rep > 1) {
-            const Buf& wsb = c->bufs.at("splitk");
-            while (sk > 1 && (size_t)sk * d.M * d.N > wsb.n) --sk;
-            if ((size_t)sk * d.M * d.N > wsb.n) { rc = fail(SAGEN_ERR_WORKSPACE, "split-K scratch too small"); return; }
-            // the reduce kernel applies bias / activation / row replication with a dense [M][N] -> pixel mapping
-            if (d.Hg * d.Wg * (long)d.ldy != d.y_bstride && d.M > d.Hg * d.Wg) { rc = fail(SAGEN_ERR_UNSUPPORTED, "split-K needs dense output rows"); return; }
             IgemmDesc e = d;
             e.splitk = sk;
-            e.splitk_ws = c->ws + wsb.off;
-            e.bias = nullptr;
-            e.relu_out = 0;
+            e.splitk_ws = c->ws + c->bufs.at("splitk").off;
+            e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
             timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
-            timed("splitk_reduce_kernel", 0.0, [&] { return splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, s); });
-        } else {
-            timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
+            timed("splitk_reduce_kernel", 0.0, [&] {
+                return splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, d.stats, s); });
+            return 0;
         }
+        timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
+        return 0;
     }
+
+    Choice heuristic(const IgemmDesc& d, int rep, bool allow_split) const {
+        Choice ch;
+        const IgemmTile tile = igemm_pick_tile(d);
+        ch.tile = (int)tile;
+        const bool can_split = allow_split && dense_out(d) && !d.stats;
+        ch.splitk = can_split ? auto_splitk(d, tile) : 1;
+        while (ch.splitk > 1 && (size_t)ch.splitk * d.M * d.N > ws_capacity()) --ch.splitk;
+        return ch;
+    }
+
+    // time every (tile, split-K) candidate on the real operands and keep the fastest (sagen_autotune)
+    Choice tune(const IgemmDesc& d, int rep, bool allow_split) {
+        Choice best = heuristic(d, rep, allow_split);
+        best.us = 1e30f;
+        const bool dense = dense_out(d);
+        const int nk = d.Kpad / 16;
+        static const int SKS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+        for (int t = 0; t < (int)TILE_AUTO && !rc; ++t) {
+            const IgemmTile tile = (IgemmTile)t;
+            const int bm = igemm_tile_bm(tile), bn = igemm_tile_bn(tile);
+            if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
+            if (bm > 32 && bm >= 4 * d.M) continue;
+            for (int sk : SKS) {
+                if (sk > 1 && (!allow_split || !dense)) break;
+                if (sk > 1 && (nk / sk < 4 || (size_t)sk * d.M * d.N > ws_capacity())) break;
+                if (sk == 1 && rep > 1 && (size_t)d.M * d.N > ws_capacity()) continue;
+                const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn) * sk;
+                if (sk > 1 && blocks > 8192) break;                     // more parallelism than the chip can use
+                float t_best = 1e30f;
+                for (int it = 0; it < 5 && !rc; ++it) {
+                    (void)hipEventRecord(c->tune_e0, s);
+                    run_choice(d, rep, tile, sk);
+                    (void)hipEventRecord(c->tune_e1, s);
+                    if (hipEventSynchronize(c->tune_e1) != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "autotune: event sync failed"); break; }
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, c->tune_e0, c->tune_e1);
+                    if (it > 0) t_best = std::min(t_best, ms * 1e3f);      // first run warms caches / code
+                }
+                if (t_best < best.us) { best.tile = t; best.splitk = sk; best.us = t_best; }
+            }
+        }
+        return best;
+    }
+
+    int contract(const IgemmDesc& d, int rep = 1, bool allow_split = true) {
+        if (rc) return 0;
+        if (rep > 1 && !dense_out(d)) { rc = fail(SAGEN_ERR_UNSUPPORTED, "replicated store needs a dense plain epilogue"); return 0; }
+        Choice ch;
+        auto it = c->plan.find(layer);
+        if (c->tuning) {
+            const bool was_prof = c->profiling;
+            c->profiling = false;
+            ch = tune(d, rep, allow_split);
+            c->profiling = was_prof;
+            c->plan[layer] = ch;
+            if (d.stats && !rc && hipMemsetAsync(d.stats, 0, (size_t)2 * d.N * sizeof(double), s) != hipSuccess)
+                rc = fail(SAGEN_ERR_HIP, "autotune: memset failed");         // candidates polluted the accumulators
+        } else if (it != c->plan.end()) {
+            ch = it->second;
+            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || d.Kpad / 16 / ch.splitk < 1)) ch.splitk = 1;
+        } else {
+            ch = heuristic(d, rep, allow_split);
+        }
+        if ((ch.splitk > 1 || rep > 1) && (size_t)std::max(ch.splitk, 1) * d.M * d.N > ws_capacity()) {
+            rc = fail(SAGEN_ERR_WORKSPACE, "split-K scratch too small for %s", layer.c_str());
+            return 0;
+        }
+        return run_choice(d, rep, (IgemmTile)ch.tile, std::max(ch.splitk, 1));
+    }
+    void gemm(const IgemmDesc& d, int rep = 1, bool allow_split = true) { contract(d, rep, allow_split); }
 
     // tfw.conv_2d geometry (core.py:156-220): dense NHWC input/output with pixel strides
     IgemmDesc conv_desc(const float* x, int Hin, int Win, int Cin, int ldx, const float* wp, int kh, int kw, int sh, int sw,
@@ -463,25 +545,25 @@ struct Fwd {
         gemm(d);
     }
 
-    void bn_finalize(const IgemmDesc& d, IgemmTile tile, const std::string& bn_name, float* scale, float* shift) {
+    void bn_finalize(const IgemmDesc& d, const std::string& bn_name, float* scale, float* shift) {
         timed("bn_finalize_kernel", 0.0, [&] {
-            return bn_finalize_launch(d.stats, igemm_grid_m(d, tile), (long)d.M, d.N, c->v(bn_name + "/bn/gamma"),
-                                      c->v(bn_name + "/bn/beta"), 1e-3f, scale, shift, s); });
+            return bn_finalize_launch(d.stats, (long)d.M, d.N, c->v(bn_name + "/bn/gamma"), c->v(bn_name + "/bn/beta"), 1e-3f,
+                                      scale, shift, s); });
     }
+    double* bn_acc(int layer_index) { return reinterpret_cast<double*>(c->p("bnacc")) + (size_t)layer_index * 2 * 512; }
 
     // conv (+BN statistics) of the ResNet trunk: raw output + scale/shift for the consumer
     void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
-                 const float* in_scale, const float* in_shift, float* y, float* scale, float* shift, int& Hout, int& Wout) {
+                 const float* in_scale, const float* in_shift, float* y, float* scale, float* shift, int& Hout, int& Wout,
+                 int bn_index) {
         if (rc) return;
         IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
                                 Cout, Hout, Wout);
         d.in_scale = in_scale; d.in_shift = in_shift;
-        d.stats = c->p("stats");
-        IgemmTile tile = igemm_pick_tile(d);
-        if ((size_t)igemm_grid_m(d, tile) * 2 * d.N > c->bufs.at("stats").n) { rc = fail(SAGEN_ERR_WORKSPACE, "stats buffer too small"); return; }
+        d.stats = bn_acc(bn_index);
         layer = name;
-        timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
-        bn_finalize(d, tile, name, scale, shift);
+        contract(d);
+        bn_finalize(d, name, scale, shift);
     }
 
     // ResNet18 -> conv5_2 in training-mode BN (resnet.py:123-236); returns the [B,7,14,512] output
@@ -491,6 +573,8 @@ struct Fwd {
         int li = 0;
         auto sc_of = [&](int i) { return bnp + (size_t)i * 1024; };
         auto sh_of = [&](int i) { return bnp + (size_t)i * 1024 + 512; };
+        if (!rc && hipMemsetAsync(c->p("bnacc"), 0, c->bufs.at("bnacc").n * sizeof(float), s) != hipSuccess)
+            rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
         timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad"), B, 224, 448, 2, 3, 2, 3, s); });
         // conv1 7x7/2 SAME == VALID on the padded 4-channel image
@@ -499,11 +583,10 @@ struct Fwd {
             const std::string name = scope + "/conv1/conv";
             IgemmDesc d = conv_desc(c->p("xpad"), 229, 453, 4, 4, c->p("pk:" + name + "/weights"), 7, 7, 2, 2, false, 64,
                                     c->p("y0"), 64, H, W);
-            d.stats = c->p("stats");
-            IgemmTile tile = igemm_pick_tile(d);
+            d.stats = bn_acc(li);
             layer = name;
-            timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
-            bn_finalize(d, tile, name, sc_of(li), sh_of(li));
+            contract(d);
+            bn_finalize(d, name, sc_of(li), sh_of(li));
             timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0"), sc_of(li), sh_of(li), c->p("rx0"), B, H, W, 64, s); });
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
@@ -527,11 +610,11 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc");
                 }
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, nullptr, nullptr, c->p("ry1"), sc_of(li), sh_of(li), Ho, Wo);
+                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, nullptr, nullptr, c->p("ry1"), sc_of(li), sh_of(li), Ho, Wo, li);
                 const int l1 = li++;
                 int H2, W2;
                 conv_bn(c->p("ry1"), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, sc_of(l1), sh_of(l1), c->p("ry2"), sc_of(li),
-                        sh_of(li), H2, W2);
+                        sh_of(li), H2, W2, li);
                 layer = pfx + "/merge";
                 timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2"), sc_of(li), sh_of(li), shortcut, xout, (long)B * Ho * Wo, cout, s); });
                 ++li;
@@ -649,7 +732,49 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
 void sagen_destroy_impl(sagen_ctx* c) {
     if (!c) return;
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->tune_e0) { (void)hipEventDestroy(c->tune_e0); (void)hipEventDestroy(c->tune_e1); }
     delete c;
+}
+
+int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
+
+// times every (tile, split-K) candidate of every contraction on the given inputs and stores the plan
+int sagen_autotune_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s) {
+    if (!c) return fail(SAGEN_ERR_NULL, "sagen_autotune: null ctx");
+    if (getenv("SAGEN_NO_AUTOTUNE")) return SAGEN_OK;
+    if (!c->tune_e0) {
+        SAGEN_HIP_CHECK(hipEventCreate(&c->tune_e0));
+        SAGEN_HIP_CHECK(hipEventCreate(&c->tune_e1));
+    }
+    c->plan.clear();
+    c->tuning = true;
+    const int rc = sagen_forward_impl(c, audio, video, flow, out, s);
+    c->tuning = false;
+    if (rc) { c->plan.clear(); return rc; }
+    SAGEN_HIP_CHECK(hipStreamSynchronize(s));
+    return SAGEN_OK;
+}
+
+int sagen_plan_set_impl(sagen_ctx* c, const char* layer, int tile, int splitk) {
+    if (tile < 0 || tile >= (int)TILE_AUTO || splitk < 1 || splitk > 64) return fail(SAGEN_ERR_SHAPE, "sagen_plan_set: tile=%d splitk=%d", tile, splitk);
+    Choice ch;
+    ch.tile = tile; ch.splitk = splitk;
+    c->plan[layer] = ch;
+    return SAGEN_OK;
+}
+
+// "layer\ttile\tsplitk\tmicroseconds\n" per contraction of the current plan
+int sagen_plan_describe_impl(sagen_ctx* c, char* buf, size_t buflen) {
+    std::string out;
+    for (const auto& kv : c->plan) {
+        char line[512];
+        snprintf(line, sizeof line, "%s\t%s\t%d\t%.2f\n", kv.first.c_str(), igemm_tile_name((IgemmTile)kv.second.tile),
+                 kv.second.splitk, kv.second.us);
+        out += line;
+    }
+    if (out.size() + 1 > buflen) return fail(SAGEN_ERR_WORKSPACE, "plan description needs %zu bytes", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)c->plan.size();
 }
 
 int sagen_profile_enable_impl(sagen_ctx* c, int on) {

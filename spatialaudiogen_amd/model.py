@@ -198,6 +198,35 @@ class SptAudioGen(object):
     def intermediate(self, batch, name):
         return self.context_for(batch).intermediate(name)
 
+    # ---- per-layer launch plan -------------------------------------------------------------------
+    def autotune(self, audio, video=None, flow=None):
+        """Time every (tile, split-K) candidate of every contraction on these inputs and keep the fastest
+        (stored per batch size).  Returns the plan as [(layer, tile, splitk, microseconds)]."""
+        out = self.inference_ops(audio, video, flow)            # validates / stages the inputs, creates the ctx
+        B = out.shape[0]
+        ctx = self.context_for(B)
+        to_dev = lambda t, tail: None if t is None else torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t).to(
+            device=self.device, dtype=torch.float32).contiguous()
+        a, v, f = to_dev(audio, None), to_dev(video if VIDEO in self.encoders else None, None), to_dev(flow if FLOW in self.encoders else None, None)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(_lib.lib().sagen_autotune(ctx.handle, p(a), p(v), p(f), p(out), stream))
+        return self.plan(B)
+
+    def plan_set(self, batch, layer, tile, splitk):
+        check(_lib.lib().sagen_plan_set(self.context_for(batch).handle, layer.encode(), int(tile), int(splitk)))
+
+    def plan(self, batch):
+        buf = C.create_string_buffer(1 << 16)
+        n = _lib.lib().sagen_plan_describe(self.context_for(batch).handle, buf, len(buf))
+        if n < 0:
+            check(n)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            layer, tile, sk, us = line.split('\t')
+            rows.append((layer, tile, int(sk), float(us)))
+        return rows
+
     # ---- measurement aid: per-launch HIP-event timing inside the native runtime ---------------
     def profile_enable(self, batch, on=True):
         check(_lib.lib().sagen_profile_enable(self.context_for(batch).handle, int(on)))

@@ -19,6 +19,8 @@ def _stream():
 
 
 def _f32(t, name):
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float64 and name == 'stats':
+        return t
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
         raise TypeError('%s must be a CUDA float32 tensor' % name)
     return t.contiguous()
@@ -60,7 +62,7 @@ def conv_2d(x, weights, stride=1, padding='SAME', biases=None, relu=False, in_sc
     scratch = _scratch(l.sagen_conv2d_scratch_bytes(B, H, W, kh, kw, Cin, cout), x.device)
     stats = None
     if return_bn_stats:
-        stats = torch.zeros(int(l.sagen_bn_stats_floats(B, Ho, Wo, cout)), dtype=torch.float32, device=x.device)
+        stats = torch.zeros(int(l.sagen_bn_stats_floats(B, Ho, Wo, cout)) // 2, dtype=torch.float64, device=x.device)
     check(l.sagen_conv2d(_ptr(x), B, H, W, Cin, _ptr(weights), kh, kw, cout, sh, sw, pad, _ptr(biases), int(relu),
                          _ptr(in_scale), _ptr(in_shift), _ptr(y), _ptr(stats), _ptr(scratch), scratch.numel() * 4, _stream()))
     return (y, stats) if return_bn_stats else y

@@ -144,3 +144,35 @@ def test_errors_are_loud(T):
     net2.load_variables(init_weights(net2.variable_specs(), seed=0))
     with pytest.raises(SagenError):
         net2.inference_ops(np.zeros((1, net2.snd_size, 1), np.float32))    # unsupported geometry: explicit error
+
+
+def test_autotuned_plan_keeps_parity(T):
+    """sagen_autotune picks (tile, split-K) per layer by timing; whatever it picks must stay inside the bar."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=2, mode='test')
+    inp = synth_inputs(3, enc, seed=21)
+    ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    plan = net.autotune(inp['audio'], inp['video'])
+    assert len(plan) >= 30 and all(us > 0 for _, _, _, us in plan)
+    check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('tile,splitk', [(0, 2), (1, 3), (2, 1), (3, 4), (0, 1)])
+def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
+    """Pin every batch-norm conv of the trunk (and the dense decoder / FC layers) to one tile shape and split-K
+    factor: exercises split-K partials + reduce-with-statistics and each kernel instantiation end to end."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=6, mode='test')
+    inp = synth_inputs(2, enc, seed=31)
+    ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.inference_ops(inp['audio'], inp['video'])
+    for name in variable_specs(enc):
+        if name.endswith('/weights'):
+            net.plan_set(2, name[:-len('/weights')], tile, splitk)
+    check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)

@@ -13,6 +13,9 @@ net.load_variables(P)
 a = torch.as_tensor(inp['audio']).cuda(); v = torch.as_tensor(inp['video']).cuda() if 'video' in inp else None
 f = torch.as_tensor(inp['flow']).cuda() if 'flow' in inp else None
 for _ in range(3): net.inference_ops(a, v, f)
+if os.environ.get('TUNE', '1') == '1':
+    plan = net.autotune(a, v, f)
+    for row in plan: print('plan %-44s %-30s sk=%-3d %8.1f us' % row)
 net.profile_enable(B, True)
 acc = None
 N = 5
