@@ -116,7 +116,8 @@ int    sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const floa
 int    sagen_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow,
                       float* ambi_yzx, void* stream);
 int    sagen_plan_describe(sagen_ctx* ctx, char* buf, size_t buflen);
-/* pin one layer's launch: tile = 0..5 (128x128, 128x64, 256x64, 64x64, 128x32, 32x128), splitk >= 1 */
+/* pin one layer's launch: tile = index into the kernel's tile table (0..5 = 128x128, 128x64, 256x64, 64x64,
+ * 128x32, 32x128 with the default LDS ring; 6.. = 2-stage and extra-aspect variants), splitk >= 1 */
 int    sagen_plan_set(sagen_ctx* ctx, const char* layer, int tile, int splitk);
 
 /* Measurement aid (the reference's only analogue is the samples/sec printout, myutils.py:15-26):

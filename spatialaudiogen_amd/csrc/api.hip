@@ -199,14 +199,14 @@ int sagen_bn_apply_relu(const float* x, const float* scale, const float* shift, 
     if (!x || !y) return fail(SAGEN_ERR_NULL, "sagen_bn_apply_relu: null argument");
     if ((scale == nullptr) != (shift == nullptr)) return fail(SAGEN_ERR_NULL, "sagen_bn_apply_relu: scale/shift must come together");
     if (n_pixels <= 0 || c <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_bn_apply_relu: bad sizes");
-    return bn_apply_relu_launch(x, scale, shift, residual, y, n_pixels, c, (hipStream_t)stream);
+    return bn_apply_relu_launch(x, scale, shift, BnRef(), residual, y, n_pixels, c, (hipStream_t)stream);
 }
 
 int sagen_maxpool3x3s2(const float* x, const float* scale, const float* shift, float* y, int batch, int h, int w, int c,
                        void* stream) {
     if (!x || !y) return fail(SAGEN_ERR_NULL, "sagen_maxpool3x3s2: null argument");
     if (batch <= 0 || h <= 0 || w <= 0 || c <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_maxpool3x3s2: bad sizes");
-    return maxpool3x3s2_launch(x, scale, shift, y, batch, h, w, c, (hipStream_t)stream);
+    return maxpool3x3s2_launch(x, scale, shift, BnRef(), y, batch, h, w, c, (hipStream_t)stream);
 }
 
 size_t sagen_fc_scratch_bytes(int m, int k, int n) {

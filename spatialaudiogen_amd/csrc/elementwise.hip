@@ -31,19 +31,44 @@ int bn_finalize_launch(const double* stats, long count, int C, const float* gamm
     return SAGEN_OK;
 }
 
+// scale/shift of 4 consecutive channels: from arrays, or derived from a producer's fp64 (sum, sumsq) accumulators
+__device__ __forceinline__ void bn_coeffs4(const float4* scale, const float4* shift, const BnRef& bn, int C4, int c4,
+                                           float4& sc, float4& sh) {
+    if (bn.acc != nullptr) {
+        float s4[4], h4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * c4 + k;
+            const double mean = bn.acc[c] * bn.inv_count;
+            double var = bn.acc[4 * C4 + c] * bn.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double a = (double)bn.gamma[c] / sqrt(var + (double)bn.eps);
+            s4[k] = (float)a;
+            h4[k] = (float)((double)bn.beta[c] - mean * a);
+        }
+        sc = make_float4(s4[0], s4[1], s4[2], s4[3]);
+        sh = make_float4(h4[0], h4[1], h4[2], h4[3]);
+    } else if (scale != nullptr) {
+        sc = scale[c4];
+        sh = shift[c4];
+    } else {
+        sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // y = relu(x*scale[c] + shift[c] (+ residual))   (resnet.py:221,235)
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
-                                                            const float4* __restrict__ shift,
+                                                            const float4* __restrict__ shift, const BnRef bn,
                                                             const float4* __restrict__ res, float4* __restrict__ y,
                                                             long n4, int C4) {
+    // the grid stride is a multiple of C4 (launcher), so a thread always sees the same 4 channels
+    float4 sc, sh;
+    bn_coeffs4(scale, shift, bn, C4, (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4), sc, sh);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C4);
         float4 v = x[i];
-        if (scale) {
-            const float4 sc = scale[c], sh = shift[c];
-            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-        }
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
         if (res) {
             const float4 r = res[i];
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -53,13 +78,24 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float4* __rest
     }
 }
 
-int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const float* residual, float* y,
-                         long n_pixels, int C, hipStream_t s) {
+// grid whose stride (grid*256 threads) is a multiple of C4, so per-thread channel groups are loop-invariant
+static int channel_aligned_grid(long n4, int C4) {
+    long g = std::min<long>(cdiv(n4, 256), 256L * 16);
+    if ((g * 256) % C4) {
+        long unit = C4;                       // smallest g with (g*256) % C4 == 0 is C4 / gcd(256, C4)
+        for (long a = 256, b = C4; b;) { const long t = a % b; a = b; b = t; unit = C4 / a; }
+        g = std::max<long>(unit, g / unit * unit);
+    }
+    return (int)g;
+}
+
+int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual,
+                         float* y, long n_pixels, int C, hipStream_t s) {
     if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "bn_apply_relu: C=%d must be a multiple of 4", C);
     const long n4 = n_pixels * (C / 4);
-    const int grid = (int)std::min<long>(cdiv(n4, 256), 256L * 16);
+    const int grid = channel_aligned_grid(n4, C / 4);
     hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(grid), dim3(256), 0, s, (const float4*)x, (const float4*)scale,
-                       (const float4*)shift, (const float4*)residual, (float4*)y, n4, C / 4);
+                       (const float4*)shift, bn, (const float4*)residual, (float4*)y, n4, C / 4);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -67,17 +103,19 @@ int bn_apply_relu_launch(const float* x, const float* scale, const float* shift,
 // tf.nn.max_pool(x,[1,3,3,1],[1,2,2,1],'SAME') (resnet.py:135) of relu(bn(x)); TF SAME pads
 // (0 before, 1 after) for even H/W -> window rows 2*ho .. 2*ho+2 clipped at the border (-inf pad).
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
-                                                           const float4* __restrict__ shift, float4* __restrict__ y,
+                                                           const float4* __restrict__ shift, const BnRef bn,
+                                                           float4* __restrict__ y,
                                                            int B, int H, int W, int C4, int Ho, int Wo, int pt, int pl) {
     const long total = (long)B * Ho * Wo * C4;
+    float4 sc, sh;
+    bn_coeffs4(scale, shift, bn, C4, (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4), sc, sh);
+    const bool has_bn = scale != nullptr || bn.acc != nullptr;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C4);
         long p = i / C4;
         const int wo = (int)(p % Wo); p /= Wo;
         const int ho = (int)(p % Ho);
         const int b = (int)(p / Ho);
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (scale) { sc = scale[c]; sh = shift[c]; }
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -93,22 +131,22 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restr
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        if (scale) {   // relu commutes with max
+        if (has_bn) {   // relu commutes with max
             m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f);
         }
         y[i] = m;
     }
 }
 
-int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, float* y, int B, int H, int W, int C,
-                        hipStream_t s) {
+int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, int B, int H,
+                        int W, int C, hipStream_t s) {
     if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool: C=%d must be a multiple of 4", C);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
     const long total = (long)B * Ho * Wo * (C / 4);
-    const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
+    const int grid = channel_aligned_grid(total, C / 4);
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, (const float4*)x, (const float4*)scale,
-                       (const float4*)shift, (float4*)y, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2);
+                       (const float4*)shift, bn, (float4*)y, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

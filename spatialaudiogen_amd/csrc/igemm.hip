@@ -34,6 +34,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MAX_TAPS = 128;
 constexpr int BK = 16;
 constexpr unsigned OOB = 0x80000000u;
+constexpr int MAX_BN_C = 512;
 
 struct RowInfo {        // per output-grid row of the tile, shared through LDS
     unsigned boff;      // byte offset of x[b, a*in_sh, bb*in_sw, 0] (mod 2^32)
@@ -46,7 +47,7 @@ struct RowInfo {        // per output-grid row of the tile, shared through LDS
 // one LDS-DMA instruction: 64 lanes x 16 B, global (buffer, bounds-checked) -> LDS at `lds` + lane*16.
 // (kept out of the kernel template: the builtin silently blocks host-side stub instantiation otherwise)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voff, unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SAGEN_ABLATE_DMA)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 #endif
 }
@@ -69,8 +70,8 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
+template <int BM, int BN, int WM, int WN, int STG>
+__global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 4))) void igemm_kernel(const IgemmDesc d) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -81,13 +82,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
     // ring depth: 3 stages (two tiles in flight, counted vmcnt) when every wave issues the same number of
     // DMA instructions per tile; otherwise 2 stages with a full drain
     constexpr bool EVEN = (A_DMA % 4 == 0) && (B_DMA % 4 == 0);
-    constexpr int STAGES = EVEN ? 3 : 2;
+    constexpr int STAGES = (EVEN && STG == 3) ? 3 : 2;
     constexpr int NMFMA = 8 * MT * NT;                        // MFMAs per wave per K tile
     constexpr int TILE_F = (BM + BN) * BK;                    // floats per stage
 
     __shared__ __attribute__((aligned(16))) float smem[STAGES * TILE_F];
     __shared__ RowInfo s_row[BM];
     __shared__ int s_tapb[MAX_TAPS];          // byte displacement per tap (only for the per-lane tap path)
+    __shared__ __attribute__((aligned(16))) float s_bn[2][MAX_BN_C];   // input batch-norm scale / shift per channel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,6 +146,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
         }
         s_row[r] = ri;
     }
+    if (d.bn_in.acc != nullptr) {          // producer's batch statistics -> scale / shift (replaces a finalize launch)
+        for (int ch = tid; ch < d.Cin; ch += 256) {
+            const double mean = d.bn_in.acc[ch] * d.bn_in.inv_count;
+            double var = d.bn_in.acc[d.Cin + ch] * d.bn_in.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double sc = (double)d.bn_in.gamma[ch] / sqrt(var + (double)d.bn_in.eps);
+            s_bn[0][ch] = (float)sc;
+            s_bn[1][ch] = (float)((double)d.bn_in.beta[ch] - mean * sc);
+        }
+    } else if (d.in_scale != nullptr) {
+        for (int ch = tid; ch < d.Cin; ch += 256) { s_bn[0][ch] = d.in_scale[ch]; s_bn[1][ch] = d.in_shift[ch]; }
+    }
     __syncthreads();
 
     // ---- LDS-DMA loader state ----
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
     const int nk_per = (nk + d.splitk - 1) / d.splitk;
     const int kc0 = z * nk_per;
     const int kc1 = min(nk, kc0 + nk_per);
-    const bool prologue = d.in_scale != nullptr;
+    const bool prologue = d.in_scale != nullptr || d.bn_in.acc != nullptr;
 
     // SGPR trackers of the (tap, channel) position: q_* = next tile to ISSUE, p_* = tile being CONTRACTED
     int q_tap = 0, q_th = 0, q_tw = 0, q_c0 = 0, p_tap = 0, p_c0 = 0;
@@ -288,8 +302,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int c = p_c0 + 8 * u + 4 * kk;     // channel of af[u][.].x  (prologue => uniform taps)
-                const float4 sc = *reinterpret_cast<const float4*>(d.in_scale + c);
-                const float4 sh = *reinterpret_cast<const float4*>(d.in_shift + c);
+                const float4 sc = *reinterpret_cast<const float4*>(&s_bn[0][c]);
+                const float4 sh = *reinterpret_cast<const float4*>(&s_bn[1][c]);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const unsigned word = p_tap < 32 ? f_nmlo[i] : f_nmhi[i];
@@ -315,7 +329,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
                     for (int j = 0; j < NT; ++j) {
                         const float a = r == 0 ? af[u][i].x : r == 1 ? af[u][i].y : r == 2 ? af[u][i].z : af[u][i].w;
                         const float b = r == 0 ? bf[u][j].x : r == 1 ? bf[u][j].y : r == 2 ? bf[u][j].z : bf[u][j].w;
+#ifndef SAGEN_ABLATE_MFMA
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+#else
+                        acc[i][j][0] += a * b;          // keeps the fragment reads alive
+#endif
                         const int idx = ((u * 4 + r) * MT + i) * NT + j;          // 0 .. NMFMA-1
                         // after MFMA idx, issue DMA g when idx == (g+1)*NMFMA/(PER+1) - 1
 #pragma unroll
@@ -405,49 +423,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STG>
 static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STG>), grid, dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
 
-static int tile_bm(IgemmTile t) {
-    switch (t) {
-        case TILE_128x128: case TILE_128x64: case TILE_128x32: return 128;
-        case TILE_256x64: return 256;
-        case TILE_64x64: return 64;
-        case TILE_32x128: return 32;
-        default: return 0;
-    }
-}
-static int tile_bn(IgemmTile t) {
-    switch (t) {
-        case TILE_128x128: case TILE_32x128: return 128;
-        case TILE_128x64: case TILE_256x64: case TILE_64x64: return 64;
-        case TILE_128x32: return 32;
-        default: return 0;
-    }
-}
-
+struct TileCfg { int bm, bn; const char* name; };
+static const TileCfg kTiles[TILE_AUTO] = {
+    {128, 128, "igemm_kernel<128,128,64,64,3>"}, {128, 64, "igemm_kernel<128,64,64,32,3>"},
+    {256, 64, "igemm_kernel<256,64,64,64,3>"},   {64, 64, "igemm_kernel<64,64,32,32,3>"},
+    {128, 32, "igemm_kernel<128,32,32,32,2>"},   {32, 128, "igemm_kernel<32,128,32,32,2>"},
+    {128, 128, "igemm_kernel<128,128,64,64,2>"}, {128, 64, "igemm_kernel<128,64,64,32,2>"},
+    {256, 64, "igemm_kernel<256,64,64,64,2>"},   {64, 64, "igemm_kernel<64,64,32,32,2>"},
+    {64, 128, "igemm_kernel<64,128,32,64,3>"},   {64, 128, "igemm_kernel<64,128,32,64,2>"},
+    {64, 256, "igemm_kernel<64,256,64,64,3>"},   {64, 256, "igemm_kernel<64,256,64,64,2>"},
+    {256, 32, "igemm_kernel<256,32,64,32,2>"},
+};
+static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
+static int tile_bn(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bn : 0; }
 int igemm_tile_bm(IgemmTile t) { return tile_bm(t); }
 int igemm_tile_bn(IgemmTile t) { return tile_bn(t); }
-
-const char* igemm_tile_name(IgemmTile t) {
-    switch (t) {
-        case TILE_128x128: return "igemm_kernel<128,128,64,64>";
-        case TILE_128x64: return "igemm_kernel<128,64,64,32>";
-        case TILE_256x64: return "igemm_kernel<256,64,64,64>";
-        case TILE_64x64: return "igemm_kernel<64,64,32,32>";
-        case TILE_128x32: return "igemm_kernel<128,32,32,32>";
-        case TILE_32x128: return "igemm_kernel<32,128,32,32>";
-        default: return "igemm_kernel<?>";
-    }
-}
+const char* igemm_tile_name(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].name : "igemm_kernel<?>"; }
 
 IgemmTile igemm_pick_tile(const IgemmDesc& d) {
-    static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: 0..5 = IgemmTile
+    static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: IgemmTile index
     if (force && d.M > 128 && d.N >= 64) return (IgemmTile)atoi(force);
     if (d.M <= 32) return TILE_32x128;
     if (d.N <= 32) return TILE_128x32;
@@ -498,18 +500,28 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         d.no_bounds = inside ? 1 : 0;
         // wave-uniform tap per K tile: every 16-wide K tile lies inside one tap (and there is no ragged K tail)
         d.uniform_taps = (d.ntaps > 1 ? (d.Cin % 16 == 0) : true) && (d.K % 16 == 0) ? 1 : 0;
-        if (d.in_scale && !d.uniform_taps) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: input batch-norm needs Cin %% 16 == 0");
+        if ((d.in_scale || d.bn_in.acc) && (!d.uniform_taps || d.ntaps == 1 || d.Cin > MAX_BN_C))
+            return fail(SAGEN_ERR_UNSUPPORTED, "igemm: input batch-norm needs a multi-tap conv with Cin %% 16 == 0 and Cin <= %d", MAX_BN_C);
         if (!inside && d.ntaps > 64) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: padded conv with %d taps (max 64)", d.ntaps);
     }
     if (tile == TILE_AUTO) tile = igemm_pick_tile(d);
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
     switch (tile) {
-        case TILE_128x128: return launch_cfg<128, 128, 64, 64>(d, s);
-        case TILE_128x64: return launch_cfg<128, 64, 64, 32>(d, s);
-        case TILE_256x64: return launch_cfg<256, 64, 64, 64>(d, s);
-        case TILE_64x64: return launch_cfg<64, 64, 32, 32>(d, s);
-        case TILE_128x32: return launch_cfg<128, 32, 32, 32>(d, s);
-        case TILE_32x128: return launch_cfg<32, 128, 32, 32>(d, s);
+        case TILE_128x128: return launch_cfg<128, 128, 64, 64, 3>(d, s);
+        case TILE_128x64: return launch_cfg<128, 64, 64, 32, 3>(d, s);
+        case TILE_256x64: return launch_cfg<256, 64, 64, 64, 3>(d, s);
+        case TILE_64x64: return launch_cfg<64, 64, 32, 32, 3>(d, s);
+        case TILE_128x32: return launch_cfg<128, 32, 32, 32, 2>(d, s);
+        case TILE_32x128: return launch_cfg<32, 128, 32, 32, 2>(d, s);
+        case TILE_128x128_S2: return launch_cfg<128, 128, 64, 64, 2>(d, s);
+        case TILE_128x64_S2: return launch_cfg<128, 64, 64, 32, 2>(d, s);
+        case TILE_256x64_S2: return launch_cfg<256, 64, 64, 64, 2>(d, s);
+        case TILE_64x64_S2: return launch_cfg<64, 64, 32, 32, 2>(d, s);
+        case TILE_64x128: return launch_cfg<64, 128, 32, 64, 3>(d, s);
+        case TILE_64x128_S2: return launch_cfg<64, 128, 32, 64, 2>(d, s);
+        case TILE_64x256: return launch_cfg<64, 256, 64, 64, 3>(d, s);
+        case TILE_64x256_S2: return launch_cfg<64, 256, 64, 64, 2>(d, s);
+        case TILE_256x32: return launch_cfg<256, 32, 64, 32, 2>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "igemm: bad tile id %d", (int)tile);
     }
 }

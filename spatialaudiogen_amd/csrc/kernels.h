@@ -14,6 +14,16 @@ namespace sagen {
 //   f = identity or relu(v*in_scale[c] + in_shift[c]) (previous layer's batch-norm),
 //   n = (ry, rx, o): stored at y[b, a*dsh + ry, bb*dsw + rx, o] (+bias[o], optional ReLU).
 // -----------------------------------------------------------------------------------------
+// Training-mode batch-norm of a producer layer, by reference to its fp64 (sum, sumsq) accumulators: consumers
+// derive scale = gamma/sqrt(var+eps), shift = beta - mean*scale themselves (no finalize launch).
+struct BnRef {
+    const double* acc = nullptr;      // [2][C]; nullptr = no batch-norm
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    double inv_count = 0.0;
+    float eps = 1e-3f;
+};
+
 struct IgemmDesc {
     const float* x = nullptr;         // input, channel offset already applied
     const float* w = nullptr;         // packed filter [Npad][Kpad], k contiguous, zero padded
@@ -21,6 +31,7 @@ struct IgemmDesc {
     const float* bias = nullptr;      // [Cout] or null
     const float* in_scale = nullptr;  // [Cin] or null
     const float* in_shift = nullptr;
+    BnRef bn_in;                      // alternative to in_scale/in_shift: derive them in-kernel (Cin <= 512)
     double* stats = nullptr;          // fp64 accumulators [2][N] of (sum, sumsq) of the raw output (atomics), or null
     float* splitk_ws = nullptr;       // [splitk][M][N] when splitk > 1
     int M = 0, N = 0, K = 0, Kpad = 0;
@@ -51,7 +62,14 @@ struct IgemmDesc {
 };
 
 // tile configurations (BM x BN, 4 waves)
-enum IgemmTile { TILE_128x128 = 0, TILE_128x64, TILE_256x64, TILE_64x64, TILE_128x32, TILE_32x128, TILE_AUTO };
+// The first six are the shape-heuristic set; the rest exist for the autotuner (2-stage LDS ring = less LDS,
+// more resident workgroups; extra aspect ratios).
+enum IgemmTile {
+    TILE_128x128 = 0, TILE_128x64, TILE_256x64, TILE_64x64, TILE_128x32, TILE_32x128,
+    TILE_128x128_S2, TILE_128x64_S2, TILE_256x64_S2, TILE_64x64_S2,
+    TILE_64x128, TILE_64x128_S2, TILE_64x256, TILE_64x256_S2, TILE_256x32,
+    TILE_AUTO
+};
 
 int igemm_launch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);
 int igemm_grid_m(const IgemmDesc& d, IgemmTile tile);       // number of M tiles (stats rows)
@@ -80,9 +98,10 @@ int pack_deconv_launch(const float* w_hwoi, int kh, int kw, int cout, int cin, i
 // stats: fp64 accumulators [2][C] (sum, sumsq) filled by the producer's atomics
 int bn_finalize_launch(const double* stats, long count, int C, const float* gamma,
                        const float* beta, float eps, float* scale, float* shift, hipStream_t s);
-int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const float* residual,
+// scale/shift arrays OR a BnRef (bn.acc != nullptr takes precedence)
+int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual,
                          float* y, long n_pixels, int C, hipStream_t s);
-int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, float* y,
+int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y,
                         int B, int H, int W, int C, hipStream_t s);
 // [B,H,W,3] -> zero-bordered [B,H+pt+pb,W+pl+pr,4]
 int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr,

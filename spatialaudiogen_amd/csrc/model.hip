@@ -279,7 +279,6 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         const size_t stage = (size_t)B * 56 * 112 * 64;
         for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc"}) c->alloc(nm, stage);
         c->alloc("bnacc", (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer of one stream
-        c->alloc("bnp", (size_t)24 * 2 * 512);        // scale/shift per BN layer of one stream
         c->alloc("fcred", (size_t)B * 98 * 128);
     }
     // intermediates for parity tests
@@ -545,34 +544,35 @@ struct Fwd {
         gemm(d);
     }
 
-    void bn_finalize(const IgemmDesc& d, const std::string& bn_name, float* scale, float* shift) {
-        timed("bn_finalize_kernel", 0.0, [&] {
-            return bn_finalize_launch(d.stats, (long)d.M, d.N, c->v(bn_name + "/bn/gamma"), c->v(bn_name + "/bn/beta"), 1e-3f,
-                                      scale, shift, s); });
-    }
     double* bn_acc(int layer_index) { return reinterpret_cast<double*>(c->p("bnacc")) + (size_t)layer_index * 2 * 512; }
+    // batch-norm of layer `bn_name` by reference to its statistics accumulators (consumers finalize in-kernel)
+    BnRef bn_ref(int layer_index, const std::string& bn_name, long count) {
+        BnRef r;
+        r.acc = bn_acc(layer_index);
+        r.gamma = c->v(bn_name + "/bn/gamma");
+        r.beta = c->v(bn_name + "/bn/beta");
+        r.inv_count = 1.0 / (double)count;
+        r.eps = 1e-3f;
+        return r;
+    }
 
-    // conv (+BN statistics) of the ResNet trunk: raw output + scale/shift for the consumer
+    // conv of the ResNet trunk: raw output + batch statistics into accumulator `bn_index`; `bn_in` = the producer's
+    // batch-norm + ReLU applied to the input on the fly
     void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
-                 const float* in_scale, const float* in_shift, float* y, float* scale, float* shift, int& Hout, int& Wout,
-                 int bn_index) {
+                 const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index) {
         if (rc) return;
         IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
                                 Cout, Hout, Wout);
-        d.in_scale = in_scale; d.in_shift = in_shift;
+        d.bn_in = bn_in;
         d.stats = bn_acc(bn_index);
         layer = name;
         contract(d);
-        bn_finalize(d, name, scale, shift);
     }
 
     // ResNet18 -> conv5_2 in training-mode BN (resnet.py:123-236); returns the [B,7,14,512] output
     const float* resnet(const float* img, const std::string& scope) {
         const int B = c->B;
-        float* bnp = c->p("bnp");
         int li = 0;
-        auto sc_of = [&](int i) { return bnp + (size_t)i * 1024; };
-        auto sh_of = [&](int i) { return bnp + (size_t)i * 1024 + 512; };
         if (!rc && hipMemsetAsync(c->p("bnacc"), 0, c->bufs.at("bnacc").n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
@@ -586,8 +586,8 @@ struct Fwd {
             d.stats = bn_acc(li);
             layer = name;
             contract(d);
-            bn_finalize(d, name, sc_of(li), sh_of(li));
-            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0"), sc_of(li), sh_of(li), c->p("rx0"), B, H, W, 64, s); });
+            const BnRef bn = bn_ref(li, name, (long)B * H * W);
+            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0"), nullptr, nullptr, bn, c->p("rx0"), B, H, W, 64, s); });
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
         }
@@ -610,13 +610,14 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc");
                 }
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, nullptr, nullptr, c->p("ry1"), sc_of(li), sh_of(li), Ho, Wo, li);
-                const int l1 = li++;
+                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1"), Ho, Wo, li);
+                const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
+                ++li;
                 int H2, W2;
-                conv_bn(c->p("ry1"), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, sc_of(l1), sh_of(l1), c->p("ry2"), sc_of(li),
-                        sh_of(li), H2, W2, li);
+                conv_bn(c->p("ry1"), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, bn1, c->p("ry2"), H2, W2, li);
+                const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 layer = pfx + "/merge";
-                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2"), sc_of(li), sh_of(li), shortcut, xout, (long)B * Ho * Wo, cout, s); });
+                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2"), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
                 ++li;
                 std::swap(xin, xout);
                 H = Ho; W = Wo; cin = cout;
