@@ -59,6 +59,9 @@ struct sagen_ctx {
     std::map<std::string, Choice> plan;
     bool tuning = false;
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
+    // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // optional per-launch HIP-event profiler (sagen_profile_enable)
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -273,13 +276,16 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
         c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
     }
-    if (c->has_video || c->has_flow) {
-        c->alloc("xpad", (size_t)B * 229 * 453 * 4);
-        c->alloc("y0", (size_t)B * 112 * 224 * 64);
+    c->alloc("splitk_aux", (size_t)8 << 20);          // split-K scratch of the second stream (audio chain / flow FCs)
+    for (int set = 0; set < 2; ++set) {
+        const std::string x = set ? "_b" : "";
+        if (set == 0 ? !(c->has_video || c->has_flow) : !(c->has_video && c->has_flow)) continue;   // "_b": flow trunk next to the video trunk
+        c->alloc("xpad" + x, (size_t)B * 229 * 453 * 4);
+        c->alloc("y0" + x, (size_t)B * 112 * 224 * 64);
         const size_t stage = (size_t)B * 56 * 112 * 64;
-        for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc"}) c->alloc(nm, stage);
-        c->alloc("bnacc", (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer of one stream
-        c->alloc("fcred", (size_t)B * 98 * 128);
+        for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc"}) c->alloc(nm + x, stage);
+        c->alloc("bnacc" + x, (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer
+        c->alloc("fcred" + x, (size_t)B * 98 * 128);
     }
     // intermediates for parity tests
     c->expose("mag", "mag", 0, {B, 127, 1024, 1}, 1);
@@ -292,6 +298,13 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->expose("bottleneck", "bott", 0, {B, 3, c->Cb}, c->Cb);
     c->expose("localization/coeffs", "coeffs", 0, {B, 3, 3, c->nsep + 1}, c->nsep + 1);
     if (c->freq_mask) c->expose("separation/deconv1", "dmask", 0, {B, 23, 1024, c->nsep}, c->nsep);
+    // second stream + fork/join events (host-side objects; no device memory)
+    if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        c->aux = nullptr;      // no device / no stream: forward falls back to a single stream (and fails at launch)
+    }
     *out = c;
     return SAGEN_OK;
 }
@@ -364,6 +377,8 @@ struct Fwd {
     hipStream_t s;
     int rc = SAGEN_OK;
     std::string layer;      // label of the layer being launched (profiling only)
+    std::string wsname = "splitk";   // split-K scratch of this launch stream
+    std::string sfx;                 // suffix of the trunk buffers this stream owns ("" or "_b")
 
     hipEvent_t next_event() {
         if (c->events_used == c->event_pool.size()) {
@@ -394,7 +409,7 @@ struct Fwd {
         return d.dsh * d.dsw == 1 && d.g_h0 == 0 && d.g_w0 == 0 && d.y_rstride == (long)d.Wg * d.ldy &&
                (d.M <= d.Hg * d.Wg || d.y_bstride == (long)d.Hg * d.Wg * d.ldy);
     }
-    size_t ws_capacity() const { return c->bufs.at("splitk").n; }
+    size_t ws_capacity() const { return c->bufs.at(wsname).n; }
 
     // launches the contraction with an explicit choice; returns the number of BN partial rows written (0 if none)
     int run_choice(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
@@ -402,7 +417,7 @@ struct Fwd {
         if (sk > 1 || rep > 1) {
             IgemmDesc e = d;
             e.splitk = sk;
-            e.splitk_ws = c->ws + c->bufs.at("splitk").off;
+            e.splitk_ws = c->ws + c->bufs.at(wsname).off;
             e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
             timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
             timed("splitk_reduce_kernel", 0.0, [&] {
@@ -544,7 +559,7 @@ struct Fwd {
         gemm(d);
     }
 
-    double* bn_acc(int layer_index) { return reinterpret_cast<double*>(c->p("bnacc")) + (size_t)layer_index * 2 * 512; }
+    double* bn_acc(int layer_index) { return reinterpret_cast<double*>(c->p("bnacc" + sfx)) + (size_t)layer_index * 2 * 512; }
     // batch-norm of layer `bn_name` by reference to its statistics accumulators (consumers finalize in-kernel)
     BnRef bn_ref(int layer_index, const std::string& bn_name, long count) {
         BnRef r;
@@ -573,26 +588,26 @@ struct Fwd {
     const float* resnet(const float* img, const std::string& scope) {
         const int B = c->B;
         int li = 0;
-        if (!rc && hipMemsetAsync(c->p("bnacc"), 0, c->bufs.at("bnacc").n * sizeof(float), s) != hipSuccess)
+        if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
-        timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad"), B, 224, 448, 2, 3, 2, 3, s); });
+        timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 3, s); });
         // conv1 7x7/2 SAME == VALID on the padded 4-channel image
         int H = 0, W = 0;
         {
             const std::string name = scope + "/conv1/conv";
-            IgemmDesc d = conv_desc(c->p("xpad"), 229, 453, 4, 4, c->p("pk:" + name + "/weights"), 7, 7, 2, 2, false, 64,
-                                    c->p("y0"), 64, H, W);
+            IgemmDesc d = conv_desc(c->p("xpad" + sfx), 229, 453, 4, 4, c->p("pk:" + name + "/weights"), 7, 7, 2, 2, false, 64,
+                                    c->p("y0" + sfx), 64, H, W);
             d.stats = bn_acc(li);
             layer = name;
             contract(d);
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
-            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0"), nullptr, nullptr, bn, c->p("rx0"), B, H, W, 64, s); });
+            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
         }
-        float* xin = c->p("rx0");
-        float* xout = c->p("rx1");
+        float* xin = c->p("rx0" + sfx);
+        float* xout = c->p("rx1" + sfx);
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};
         for (int st = 0; st < 4; ++st) {
@@ -605,19 +620,19 @@ struct Fwd {
                 const float* shortcut = xin;
                 if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
-                                            cout, c->p("rsc"), cout, Ho, Wo);
+                                            cout, c->p("rsc" + sfx), cout, Ho, Wo);
                     layer = pfx + "/shortcut";
                     gemm(d, 1, false);
-                    shortcut = c->p("rsc");
+                    shortcut = c->p("rsc" + sfx);
                 }
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1"), Ho, Wo, li);
+                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
-                conv_bn(c->p("ry1"), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, bn1, c->p("ry2"), H2, W2, li);
+                conv_bn(c->p("ry1" + sfx), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, bn1, c->p("ry2" + sfx), H2, W2, li);
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 layer = pfx + "/merge";
-                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2"), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
+                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
                 ++li;
                 std::swap(xin, xout);
                 H = Ho; W = Wo; cin = cout;
@@ -635,16 +650,29 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     if (c->has_video && !video) return fail(SAGEN_ERR_NULL, "sagen_forward: video encoder enabled but video is NULL");
     if (c->has_flow && !flow) return fail(SAGEN_ERR_NULL, "sagen_forward: flow encoder enabled but flow is NULL");
     const int B = c->B;
-    Fwd f{c, s};
-
-    // STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
     c->events_used = 0;
     c->prof.clear();
-    f.layer = "stft";
-    f.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), s); });
+
+    // Two launch streams: `f` (the caller's) carries the video trunk and everything after the bottleneck; `g`
+    // (context-owned) carries the independent audio chain and, with three encoders, the flow trunk.  They fork at
+    // entry and join before the localisation FCs.  While autotuning, or without visual encoders, everything
+    // stays on the caller's stream.
+    static const bool one_stream = getenv("SAGEN_ONE_STREAM") != nullptr;
+    const bool forked = c->aux && !c->tuning && !one_stream && (c->has_video || c->has_flow);
+    Fwd f{c, s};
+    Fwd g{c, forked ? c->aux : s};
+    if (forked) {
+        g.wsname = "splitk_aux";
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    }
+
+    // ---- stream g: STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
+    g.layer = "stft";
+    g.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), g.s); });
 
     // audio encoder (model.py:161-187): conv l writes the encoder half of concat buffer l
-    for (int l = 0; l < 5 && !f.rc; ++l) {
+    for (int l = 0; l < 5 && !g.rc; ++l) {
         const std::string name = "audio_encoder/conv" + std::to_string(l + 1);
         const int ce = c->enc_c[l + 1];
         float* y = c->p("cat" + std::to_string(l + 1)) + (l == 4 ? 0 : ce);
@@ -652,20 +680,20 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         IgemmDesc d;
         if (l == 0) {
             // Cin = 1: the 16 taps along frequency are contiguous floats -> treat kw as 16 channels of a 7-tap conv
-            d = f.conv_desc(c->p("mag"), 127, 1024, 16, 1, c->p("pk:" + name + "/weights"), 7, 1, 4, 8, false, ce, y, 2 * ce, Ho, Wo);
+            d = g.conv_desc(c->p("mag"), 127, 1024, 16, 1, c->p("pk:" + name + "/weights"), 7, 1, 4, 8, false, ce, y, 2 * ce, Ho, Wo);
             Wo = c->enc_w[1];
             d.M = B * Ho * Wo; d.Wg = Wo; d.Wlim = Wo;
             d.y_rstride = (long)Wo * 2 * ce; d.y_bstride = (long)Ho * Wo * 2 * ce;
         } else {
             const int cp = c->enc_c[l];
             const float* x = c->p("cat" + std::to_string(l)) + (l == 5 ? 0 : cp);
-            d = f.conv_desc(x, c->enc_h[l], c->enc_w[l], cp, 2 * cp, c->p("pk:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1],
+            d = g.conv_desc(x, c->enc_h[l], c->enc_w[l], cp, 2 * cp, c->p("pk:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1],
                             AENC_S[l][0], AENC_S[l][1], false, ce, y, 2 * ce, Ho, Wo);
         }
         d.bias = c->v(name + "/biases");
         d.relu_out = 1;
-        f.layer = name;
-        f.gemm(d);
+        g.layer = name;
+        g.gemm(d);
     }
 
     // bottleneck (model.py:203-239)
@@ -678,18 +706,26 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         d.ntaps = 6; d.TW = 6; d.log2Cin = 9;
         d.Cout = 1024; d.Hlim = 3; d.Wlim = 1; d.ldy = c->Cb; d.y_rstride = c->Cb; d.y_bstride = 3L * c->Cb;
         d.relu_out = 1;
-        f.layer = "bottleneck/audio-fc";
-        f.gemm(d);
+        g.layer = "bottleneck/audio-fc";
+        g.gemm(d);
     }
+    // visual encoders: video on f; flow on g when both exist (its own buffer set "_b"), else on f
     int choff = 1024;
     for (int e = 0; e < 2; ++e) {
         const bool on = e == 0 ? c->has_video : c->has_flow;
         if (!on) continue;
         const std::string enc = e == 0 ? "video" : "flow";
-        const float* feat = f.resnet(e == 0 ? video : flow, enc + "_encoder");          // [B,7,14,512]
-        f.fc(feat, B * 98, 512, 512, "bottleneck/" + enc + "-fc-red", 128, true, c->p("fcred"), 128);
-        f.fc(c->p("fcred"), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
+        Fwd& w = (e == 1 && c->has_video) ? g : f;
+        w.sfx = (e == 1 && c->has_video) ? "_b" : "";
+        const float* feat = w.resnet(e == 0 ? video : flow, enc + "_encoder");          // [B,7,14,512]
+        w.fc(feat, B * 98, 512, 512, "bottleneck/" + enc + "-fc-red", 128, true, c->p("fcred" + w.sfx), 128);
+        w.fc(c->p("fcred" + w.sfx), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
         choff += 512;
+    }
+    if (g.rc) return g.rc;
+    if (forked) {
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
 
     // localization (model.py:241-271)
@@ -726,18 +762,16 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
                                      c->p("frames"), s); });
     return f.rc;
 }
-
-// ------------------------------------------------------------------------------------------------
-// small accessors
-// ------------------------------------------------------------------------------------------------
 void sagen_destroy_impl(sagen_ctx* c) {
     if (!c) return;
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->tune_e0) { (void)hipEventDestroy(c->tune_e0); (void)hipEventDestroy(c->tune_e1); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     delete c;
 }
 
-int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
 
 // times every (tile, split-K) candidate of every contraction on the given inputs and stores the plan
 int sagen_autotune_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s) {
