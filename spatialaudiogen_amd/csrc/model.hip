@@ -57,6 +57,7 @@ struct sagen_ctx {
     sagen_config cfg;
     // per-layer launch plan (filled by sagen_autotune; empty = heuristics)
     std::map<std::string, Choice> plan;
+    std::map<std::string, bool> materialize;     // conv_2 layers: apply the producer's BN+ReLU in a separate pass?
     bool tuning = false;
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
@@ -283,7 +284,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         c->alloc("xpad" + x, (size_t)B * 229 * 453 * 4);
         c->alloc("y0" + x, (size_t)B * 112 * 224 * 64);
         const size_t stage = (size_t)B * 56 * 112 * 64;
-        for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc"}) c->alloc(nm + x, stage);
+        for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc", "ry1n"}) c->alloc(nm + x, stage);
         c->alloc("bnacc" + x, (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer
         c->alloc("fcred" + x, (size_t)B * 98 * 128);
     }
@@ -574,13 +575,13 @@ struct Fwd {
     // conv of the ResNet trunk: raw output + batch statistics into accumulator `bn_index`; `bn_in` = the producer's
     // batch-norm + ReLU applied to the input on the fly
     void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
-                 const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index) {
+                 const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index, const std::string& plan_key = "") {
         if (rc) return;
         IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
                                 Cout, Hout, Wout);
         d.bn_in = bn_in;
         d.stats = bn_acc(bn_index);
-        layer = name;
+        layer = plan_key.empty() ? name : plan_key;
         contract(d);
     }
 
@@ -629,7 +630,37 @@ struct Fwd {
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
-                conv_bn(c->p("ry1" + sfx), Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, bn1, c->p("ry2" + sfx), H2, W2, li);
+                // conv_2 input = relu(bn1(y1)): on the fly in the conv's fragment path, or materialised once
+                // (cheaper for the small late-stage tensors, where every wave would redo the transform)
+                const std::string l2 = pfx + "/conv_2";
+                auto run_prologue = [&] { conv_bn(c->p("ry1" + sfx), Ho, Wo, cout, l2, 3, 1, cout, bn1, c->p("ry2" + sfx), H2, W2, li); };
+                auto run_materialized = [&](const std::string& key) {
+                    layer = pfx + "/bn1-relu";
+                    timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, c->p("ry1n" + sfx), (long)B * Ho * Wo, cout, s); });
+                    conv_bn(c->p("ry1n" + sfx), Ho, Wo, cout, l2, 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, key);
+                };
+                if (c->tuning && !rc) {
+                    run_prologue();
+                    const float t_pro = c->plan[l2].us;
+                    (void)hipEventRecord(c->tune_e0, s);
+                    (void)bn_apply_relu_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, c->p("ry1n" + sfx), (long)B * Ho * Wo, cout, s);
+                    (void)hipEventRecord(c->tune_e1, s);
+                    (void)hipEventSynchronize(c->tune_e1);
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, c->tune_e0, c->tune_e1);
+                    if (!rc && hipMemsetAsync(bn_acc(li), 0, (size_t)2 * cout * sizeof(double), s) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "memset failed");
+                    run_materialized(l2 + "#mat");
+                    const float t_mat = c->plan[l2 + "#mat"].us + ms * 1e3f;
+                    c->materialize[l2] = t_mat < t_pro;
+                    if (!c->materialize[l2] && !rc) {        // leave the prologue result in place
+                        if (hipMemsetAsync(bn_acc(li), 0, (size_t)2 * cout * sizeof(double), s) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "memset failed");
+                        c->tuning = false; run_prologue(); c->tuning = true;
+                    }
+                } else if (c->materialize.count(l2) && c->materialize[l2]) {
+                    run_materialized(l2 + "#mat");
+                } else {
+                    run_prologue();
+                }
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 layer = pfx + "/merge";
                 timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
@@ -782,6 +813,7 @@ int sagen_autotune_impl(sagen_ctx* c, const float* audio, const float* video, co
         SAGEN_HIP_CHECK(hipEventCreate(&c->tune_e1));
     }
     c->plan.clear();
+    c->materialize.clear();
     c->tuning = true;
     const int rc = sagen_forward_impl(c, audio, video, flow, out, s);
     c->tuning = false;
