@@ -32,7 +32,6 @@ namespace sagen {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MAX_TAPS = 128;
-constexpr int BK = 16;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int MAX_BN_C = 512;
 
@@ -70,20 +69,24 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int STG>
-__global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 4))) void igemm_kernel(const IgemmDesc d) {
+template <int BM, int BN, int WM, int WN, int STG, int BK>
+__global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK == 32 ? 2 : 3) : (BK == 32 ? 3 : 4)))) void igemm_kernel(const IgemmDesc d) {
+    static_assert(BK == 16 || BK == 32, "K tile of 16 or 32");
+    constexpr int CPR = BK / 4;            // 16-B chunks per LDS row
+    constexpr int RPI = 64 / CPR;          // rows covered by one DMA instruction (64 lanes x 16 B)
+    constexpr int RPBR = 64 / BK;          // rows per 256-B LDS bank row: the swizzle key is (row / RPBR) % CPR
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
-    constexpr int A_DMA = BM / 16, B_DMA = BN / 16;          // DMA instructions per tile (16 rows each)
+    constexpr int A_DMA = BM / RPI, B_DMA = BN / RPI;        // DMA instructions per tile (RPI rows each)
     constexpr int A_PW = (A_DMA + 3) / 4, B_PW = (B_DMA + 3) / 4;   // per wave
     constexpr int PER = A_PW + B_PW;                          // DMA instructions per wave per K tile
     // ring depth: 3 stages (two tiles in flight, counted vmcnt) when every wave issues the same number of
     // DMA instructions per tile; otherwise 2 stages with a full drain
     constexpr bool EVEN = (A_DMA % 4 == 0) && (B_DMA % 4 == 0);
     constexpr int STAGES = (EVEN && STG == 3) ? 3 : 2;
-    constexpr int NMFMA = 8 * MT * NT;                        // MFMAs per wave per K tile
+    constexpr int NMFMA = (BK / 2) * MT * NT;                 // MFMAs per wave per K tile
     constexpr int TILE_F = (BM + BN) * BK;                    // floats per stage
 
     __shared__ __attribute__((aligned(16))) float smem[STAGES * TILE_F];
@@ -163,14 +166,17 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 
     // ---- LDS-DMA loader state ----
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.x, 0, d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, d.w_bytes, 0x00020000);
-    const int src_chunk = (lane & 3) ^ (lane >> 4);          // logical 16-B chunk this lane fetches (XOR swizzle)
+    // LDS position of lane l of DMA instruction `inst`: row inst*RPI + l/CPR, physical chunk l%CPR; it must hold
+    // logical chunk (l%CPR) ^ ((row / RPBR) % CPR).  inst*RPI/RPBR is 0 mod CPR for BK=16 and 4*(inst&1) for BK=32,
+    // and inst = wave + 4j has the parity of the wave.
+    const int src_chunk = (lane % CPR) ^ (((BK == 32 ? 4 * (wave & 1) : 0) + (lane / CPR) / RPBR) % CPR);
     unsigned a_voff[A_PW], a_nmlo[A_PW], a_nmhi[A_PW], b_voff[B_PW];
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
         const int inst = wave + 4 * j;                       // wave-uniform
         a_voff[j] = OOB; a_nmlo[j] = 0xffffffffu; a_nmhi[j] = 0xffffffffu;
         if (inst < A_DMA) {
-            const RowInfo ri = s_row[inst * 16 + (lane >> 2)];
+            const RowInfo ri = s_row[inst * RPI + lane / CPR];
             a_voff[j] = ri.boff + 16u * src_chunk;
             a_nmlo[j] = ri.nmlo; a_nmhi[j] = ri.nmhi;
         }
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
         const int inst = wave + 4 * j;
-        const int n = n0 + inst * 16 + (lane >> 2);
+        const int n = n0 + inst * RPI + lane / CPR;
         b_voff[j] = (inst < B_DMA && n < d.N) ? (unsigned)((long)n * d.Kpad * 4) + 16u * src_chunk : OOB;
     }
 
@@ -233,11 +239,11 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 
                 const unsigned word = i_hi ? a_nmhi[g] : a_nmlo[g];
                 unsigned bad = (word >> i_bit) & 1u;
                 if (!uni) bad |= (i_kok ^ 1u);
-                dma16(x_rsrc, st + inst * 16 * BK, (a_voff[g] + i_tb) | (bad << 31), 0);
+                dma16(x_rsrc, st + inst * RPI * BK, (a_voff[g] + i_tb) | (bad << 31), 0);
             }
         } else {
             const int inst = wave + 4 * (g - A_PW);
-            if (EVEN || inst < B_DMA) dma16(w_rsrc, st + (BM + inst * 16) * BK, b_voff[g - A_PW], i_kbyte);
+            if (EVEN || inst < B_DMA) dma16(w_rsrc, st + (BM + inst * RPI) * BK, b_voff[g - A_PW], i_kbyte);
         }
     };
 
@@ -250,9 +256,8 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int li = lane & 31, kk = lane >> 5;
-    // fragment addressing: row (wm*WM + i*32 + li), physical chunk (2u + kk) ^ ((li >> 2) & 3)
-    const int fsw = (li >> 2) & 3;
-    const int f_off0 = 4 * ((kk) ^ fsw), f_off1 = 4 * ((2 + kk) ^ fsw);
+    // fragment addressing: row (wm*WM + i*32 + li), physical chunk (2u + kk) ^ ((row / RPBR) % CPR)
+    const int fsw = (li / RPBR) % CPR;
     // BN prologue state: inverted masks of this lane's fragment rows
     unsigned f_nmlo[MT], f_nmhi[MT];
 #pragma unroll
@@ -289,57 +294,62 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 
         if (more) begin_issue(kc + (STAGES - 1), istage);
         const float* Ab = smem + stage * TILE_F + (wm * WM + li) * BK;
         const float* Bb = smem + stage * TILE_F + (BM + wn * WN + li) * BK;
-        float4 af[2][MT], bf[2][NT];
+        // the K tile is contracted in halves of 16 (two 8-deep MFMA groups each), fragments re-read per half
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[u][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + (u ? f_off1 : f_off0));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[u][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + (u ? f_off1 : f_off0));
-        }
-        if (prologue) {
-            // relu(v*scale[c] + shift[c]) of the producer's batch-norm; padding / invalid rows stay 0
+        for (int hf = 0; hf < BK / 16; ++hf) {
+            float4 af[2][MT], bf[2][NT];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int c = p_c0 + 8 * u + 4 * kk;     // channel of af[u][.].x  (prologue => uniform taps)
-                const float4 sc = *reinterpret_cast<const float4*>(&s_bn[0][c]);
-                const float4 sh = *reinterpret_cast<const float4*>(&s_bn[1][c]);
+                const int foff = 4 * ((2 * (2 * hf + u) + kk) ^ fsw);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const unsigned word = p_tap < 32 ? f_nmlo[i] : f_nmhi[i];
-                    const bool ok = ((word >> (p_tap & 31)) & 1u) == 0;
-                    float4 v = af[u][i];
-                    v.x = ok ? fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
-                    v.y = ok ? fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
-                    v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
-                    v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
-                    af[u][i] = v;
+                for (int i = 0; i < MT; ++i) af[u][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * BK + foff);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[u][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * BK + foff);
+            }
+            if (prologue) {
+                // relu(v*scale[c] + shift[c]) of the producer's batch-norm; padding / invalid rows stay 0
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = p_c0 + 8 * (2 * hf + u) + 4 * kk;     // channel of af[u][.].x  (prologue => uniform taps)
+                    const float4 sc = *reinterpret_cast<const float4*>(&s_bn[0][c]);
+                    const float4 sh = *reinterpret_cast<const float4*>(&s_bn[1][c]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const unsigned word = p_tap < 32 ? f_nmlo[i] : f_nmhi[i];
+                        const bool ok = ((word >> (p_tap & 31)) & 1u) == 0;
+                        float4 v = af[u][i];
+                        v.x = ok ? fmaxf(fmaf(v.x, sc.x, sh.x), 0.f) : 0.f;
+                        v.y = ok ? fmaxf(fmaf(v.y, sc.y, sh.y), 0.f) : 0.f;
+                        v.z = ok ? fmaxf(fmaf(v.z, sc.z, sh.z), 0.f) : 0.f;
+                        v.w = ok ? fmaxf(fmaf(v.w, sc.w, sh.w), 0.f) : 0.f;
+                        af[u][i] = v;
+                    }
                 }
             }
-        }
-        TRC(1);
-        // MFMAs with the DMA issue of a later tile spread between them (it hides in the 64-cycle MFMA shadow)
+            if (hf == 0) TRC(1);
+            // MFMAs with the DMA issue of a later tile spread between them (it hides in the 64-cycle MFMA shadow)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const float a = r == 0 ? af[u][i].x : r == 1 ? af[u][i].y : r == 2 ? af[u][i].z : af[u][i].w;
-                        const float b = r == 0 ? bf[u][j].x : r == 1 ? bf[u][j].y : r == 2 ? bf[u][j].z : bf[u][j].w;
+                        for (int j = 0; j < NT; ++j) {
+                            const float a = r == 0 ? af[u][i].x : r == 1 ? af[u][i].y : r == 2 ? af[u][i].z : af[u][i].w;
+                            const float b = r == 0 ? bf[u][j].x : r == 1 ? bf[u][j].y : r == 2 ? bf[u][j].z : bf[u][j].w;
 #ifndef SAGEN_ABLATE_MFMA
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
 #else
-                        acc[i][j][0] += a * b;          // keeps the fragment reads alive
+                            acc[i][j][0] += a * b;          // keeps the fragment reads alive
 #endif
-                        const int idx = ((u * 4 + r) * MT + i) * NT + j;          // 0 .. NMFMA-1
-                        // after MFMA idx, issue DMA g when idx == (g+1)*NMFMA/(PER+1) - 1
+                            const int idx = (((hf * 2 + u) * 4 + r) * MT + i) * NT + j;          // 0 .. NMFMA-1
+                            // after MFMA idx, issue DMA g when idx == (g+1)*NMFMA/(PER+1) - 1
 #pragma unroll
-                        for (int g = 0; g < PER; ++g)
-                            if (idx == (g + 1) * NMFMA / (PER + 1) - 1 && more) issue_one(g);
-                    }
+                            for (int g = 0; g < PER; ++g)
+                                if (idx == (g + 1) * NMFMA / (PER + 1) - 1 && more) issue_one(g);
+                        }
+        }
         TRC(2);
         if (uni) {                                   // advance the consume-side tracker
             p_c0 += BK;
@@ -423,30 +433,45 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? 3 : 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STG>
+template <int BM, int BN, int WM, int WN, int STG, int BK>
 static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STG>), grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STG, BK>), grid, dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn; const char* name; };
+struct TileCfg { int bm, bn, bk; const char* name; };
 static const TileCfg kTiles[TILE_AUTO] = {
-    {128, 128, "igemm_kernel<128,128,64,64,3>"}, {128, 64, "igemm_kernel<128,64,64,32,3>"},
-    {256, 64, "igemm_kernel<256,64,64,64,3>"},   {64, 64, "igemm_kernel<64,64,32,32,3>"},
-    {128, 32, "igemm_kernel<128,32,32,32,2>"},   {32, 128, "igemm_kernel<32,128,32,32,2>"},
-    {128, 128, "igemm_kernel<128,128,64,64,2>"}, {128, 64, "igemm_kernel<128,64,64,32,2>"},
-    {256, 64, "igemm_kernel<256,64,64,64,2>"},   {64, 64, "igemm_kernel<64,64,32,32,2>"},
-    {64, 128, "igemm_kernel<64,128,32,64,3>"},   {64, 128, "igemm_kernel<64,128,32,64,2>"},
-    {64, 256, "igemm_kernel<64,256,64,64,3>"},   {64, 256, "igemm_kernel<64,256,64,64,2>"},
-    {256, 32, "igemm_kernel<256,32,64,32,2>"},
+    {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
+    {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
+    {128, 32, 16, "igemm_kernel<128,32,32,32,2,16>"},   {32, 128, 16, "igemm_kernel<32,128,32,32,2,16>"},
+    {128, 128, 16, "igemm_kernel<128,128,64,64,2,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,2,16>"},
+    {256, 64, 16, "igemm_kernel<256,64,64,64,2,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,2,16>"},
+    {64, 128, 16, "igemm_kernel<64,128,32,64,3,16>"},   {64, 128, 16, "igemm_kernel<64,128,32,64,2,16>"},
+    {64, 256, 16, "igemm_kernel<64,256,64,64,3,16>"},   {64, 256, 16, "igemm_kernel<64,256,64,64,2,16>"},
+    {256, 32, 16, "igemm_kernel<256,32,64,32,2,16>"},
+    {64, 64, 32, "igemm_kernel<64,64,32,32,2,32>"},     {64, 128, 32, "igemm_kernel<64,128,32,64,2,32>"},
+    {128, 64, 32, "igemm_kernel<128,64,64,32,2,32>"},   {128, 128, 32, "igemm_kernel<128,128,64,64,2,32>"},
+    {32, 128, 32, "igemm_kernel<32,128,32,32,2,32>"},   {128, 32, 32, "igemm_kernel<128,32,32,32,2,32>"},
 };
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
 static int tile_bn(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bn : 0; }
 int igemm_tile_bm(IgemmTile t) { return tile_bm(t); }
 int igemm_tile_bn(IgemmTile t) { return tile_bn(t); }
+int igemm_tile_bk(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bk : 0; }
 const char* igemm_tile_name(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].name : "igemm_kernel<?>"; }
+
+static bool uniform_taps_for(const IgemmDesc& d, int bk) {
+    return (d.ntaps > 1 ? (d.Cin % bk == 0) : true) && (d.K % bk == 0);
+}
+bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
+    if (t < 0 || t >= TILE_AUTO) return false;
+    const int bk = kTiles[t].bk;
+    if (d.Kpad % bk) return false;
+    if ((d.in_scale || d.bn_in.acc) && !uniform_taps_for(d, bk)) return false;
+    return true;
+}
 
 IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: IgemmTile index
@@ -498,30 +523,37 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
             inside = h_lo >= 0 && h_hi < d.Hin && w_lo >= 0 && w_hi < d.Win;
         }
         d.no_bounds = inside ? 1 : 0;
-        // wave-uniform tap per K tile: every 16-wide K tile lies inside one tap (and there is no ragged K tail)
-        d.uniform_taps = (d.ntaps > 1 ? (d.Cin % 16 == 0) : true) && (d.K % 16 == 0) ? 1 : 0;
-        if ((d.in_scale || d.bn_in.acc) && (!d.uniform_taps || d.ntaps == 1 || d.Cin > MAX_BN_C))
+        if ((d.in_scale || d.bn_in.acc) && (d.Cin % 16 || d.K % 16 || d.ntaps == 1 || d.Cin > MAX_BN_C))
             return fail(SAGEN_ERR_UNSUPPORTED, "igemm: input batch-norm needs a multi-tap conv with Cin %% 16 == 0 and Cin <= %d", MAX_BN_C);
         if (!inside && d.ntaps > 64) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: padded conv with %d taps (max 64)", d.ntaps);
     }
     if (tile == TILE_AUTO) tile = igemm_pick_tile(d);
+    if (!igemm_tile_ok(d, tile)) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %s cannot run this problem (Kpad=%d Cin=%d)", igemm_tile_name(tile), d.Kpad, d.Cin);
+    // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
+    d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
     switch (tile) {
-        case TILE_128x128: return launch_cfg<128, 128, 64, 64, 3>(d, s);
-        case TILE_128x64: return launch_cfg<128, 64, 64, 32, 3>(d, s);
-        case TILE_256x64: return launch_cfg<256, 64, 64, 64, 3>(d, s);
-        case TILE_64x64: return launch_cfg<64, 64, 32, 32, 3>(d, s);
-        case TILE_128x32: return launch_cfg<128, 32, 32, 32, 2>(d, s);
-        case TILE_32x128: return launch_cfg<32, 128, 32, 32, 2>(d, s);
-        case TILE_128x128_S2: return launch_cfg<128, 128, 64, 64, 2>(d, s);
-        case TILE_128x64_S2: return launch_cfg<128, 64, 64, 32, 2>(d, s);
-        case TILE_256x64_S2: return launch_cfg<256, 64, 64, 64, 2>(d, s);
-        case TILE_64x64_S2: return launch_cfg<64, 64, 32, 32, 2>(d, s);
-        case TILE_64x128: return launch_cfg<64, 128, 32, 64, 3>(d, s);
-        case TILE_64x128_S2: return launch_cfg<64, 128, 32, 64, 2>(d, s);
-        case TILE_64x256: return launch_cfg<64, 256, 64, 64, 3>(d, s);
-        case TILE_64x256_S2: return launch_cfg<64, 256, 64, 64, 2>(d, s);
-        case TILE_256x32: return launch_cfg<256, 32, 64, 32, 2>(d, s);
+        case TILE_128x128: return launch_cfg<128, 128, 64, 64, 3, 16>(d, s);
+        case TILE_128x64: return launch_cfg<128, 64, 64, 32, 3, 16>(d, s);
+        case TILE_256x64: return launch_cfg<256, 64, 64, 64, 3, 16>(d, s);
+        case TILE_64x64: return launch_cfg<64, 64, 32, 32, 3, 16>(d, s);
+        case TILE_128x32: return launch_cfg<128, 32, 32, 32, 2, 16>(d, s);
+        case TILE_32x128: return launch_cfg<32, 128, 32, 32, 2, 16>(d, s);
+        case TILE_128x128_S2: return launch_cfg<128, 128, 64, 64, 2, 16>(d, s);
+        case TILE_128x64_S2: return launch_cfg<128, 64, 64, 32, 2, 16>(d, s);
+        case TILE_256x64_S2: return launch_cfg<256, 64, 64, 64, 2, 16>(d, s);
+        case TILE_64x64_S2: return launch_cfg<64, 64, 32, 32, 2, 16>(d, s);
+        case TILE_64x128: return launch_cfg<64, 128, 32, 64, 3, 16>(d, s);
+        case TILE_64x128_S2: return launch_cfg<64, 128, 32, 64, 2, 16>(d, s);
+        case TILE_64x256: return launch_cfg<64, 256, 64, 64, 3, 16>(d, s);
+        case TILE_64x256_S2: return launch_cfg<64, 256, 64, 64, 2, 16>(d, s);
+        case TILE_256x32: return launch_cfg<256, 32, 64, 32, 2, 16>(d, s);
+        case TILE_64x64_K32: return launch_cfg<64, 64, 32, 32, 2, 32>(d, s);
+        case TILE_64x128_K32: return launch_cfg<64, 128, 32, 64, 2, 32>(d, s);
+        case TILE_128x64_K32: return launch_cfg<128, 64, 64, 32, 2, 32>(d, s);
+        case TILE_128x128_K32: return launch_cfg<128, 128, 64, 64, 2, 32>(d, s);
+        case TILE_32x128_K32: return launch_cfg<32, 128, 32, 32, 2, 32>(d, s);
+        case TILE_128x32_K32: return launch_cfg<128, 32, 32, 32, 2, 32>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "igemm: bad tile id %d", (int)tile);
     }
 }

@@ -68,6 +68,8 @@ enum IgemmTile {
     TILE_128x128 = 0, TILE_128x64, TILE_256x64, TILE_64x64, TILE_128x32, TILE_32x128,
     TILE_128x128_S2, TILE_128x64_S2, TILE_256x64_S2, TILE_64x64_S2,
     TILE_64x128, TILE_64x128_S2, TILE_64x256, TILE_64x256_S2, TILE_256x32,
+    // K tile of 32 (half the barriers per MFMA; needs Kpad % 32 == 0)
+    TILE_64x64_K32, TILE_64x128_K32, TILE_128x64_K32, TILE_128x128_K32, TILE_32x128_K32, TILE_128x32_K32,
     TILE_AUTO
 };
 
@@ -76,7 +78,9 @@ int igemm_grid_m(const IgemmDesc& d, IgemmTile tile);       // number of M tiles
 IgemmTile igemm_pick_tile(const IgemmDesc& d);
 const char* igemm_tile_name(IgemmTile t);
 int igemm_tile_bm(IgemmTile t);
-int igemm_tile_bn(IgemmTile t);              // instantiation name as rocprofv3 prints it
+int igemm_tile_bn(IgemmTile t);
+int igemm_tile_bk(IgemmTile t);
+bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the
 // per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)
 constexpr int SPLITK_RB = 16;

@@ -444,11 +444,12 @@ struct Fwd {
         Choice best = heuristic(d, rep, allow_split);
         best.us = 1e30f;
         const bool dense = dense_out(d);
-        const int nk = d.Kpad / 16;
         static const int SKS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
         for (int t = 0; t < (int)TILE_AUTO && !rc; ++t) {
             const IgemmTile tile = (IgemmTile)t;
             const int bm = igemm_tile_bm(tile), bn = igemm_tile_bn(tile);
+            if (!igemm_tile_ok(d, tile)) continue;
+            const int nk = d.Kpad / igemm_tile_bk(tile);
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;
             for (int sk : SKS) {
@@ -488,7 +489,8 @@ struct Fwd {
                 rc = fail(SAGEN_ERR_HIP, "autotune: memset failed");         // candidates polluted the accumulators
         } else if (it != c->plan.end()) {
             ch = it->second;
-            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || d.Kpad / 16 / ch.splitk < 1)) ch.splitk = 1;
+            if (!igemm_tile_ok(d, (IgemmTile)ch.tile)) ch = heuristic(d, rep, allow_split);
+            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || d.Kpad / igemm_tile_bk((IgemmTile)ch.tile) / ch.splitk < 1)) ch.splitk = 1;
         } else {
             ch = heuristic(d, rep, allow_split);
         }

@@ -161,7 +161,7 @@ def test_autotuned_plan_keeps_parity(T):
 
 
 @pytest.mark.parametrize('tile,splitk', [(0, 2), (1, 3), (2, 1), (3, 4), (0, 1), (4, 1), (5, 2), (6, 1), (7, 2), (8, 1),
-                                         (9, 3), (10, 1), (11, 2), (12, 1), (13, 2), (14, 1)])
+                                         (9, 3), (10, 1), (11, 2), (12, 1), (13, 2), (14, 1), (15, 1), (16, 2), (17, 1), (18, 2), (19, 3), (20, 1)])
 def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     """Pin every batch-norm conv of the trunk (and the dense decoder / FC layers) to one tile shape and split-K
     factor: exercises split-K partials + reduce-with-statistics and each kernel instantiation end to end."""

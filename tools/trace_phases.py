@@ -14,7 +14,7 @@ using namespace sagen;
 extern "C" int sagen_trace_conv(const float* x, const float* wp, float* y, float* stats, void* trace, int block,
                                 int B, int H, int W, int C, int tile, void* stream) {
     IgemmDesc d;
-    d.x = x; d.w = wp; d.y = y; d.stats = stats;
+    d.x = x; d.w = wp; d.y = y; d.stats = (double*)stats;
     d.M = B * H * W; d.N = C; d.K = 9 * C; d.Kpad = d.K; d.Hg = H; d.Wg = W; d.Hin = H; d.Win = W; d.Cin = C; d.ldx = C;
     d.x_bstride = (long)H * W * C; d.ntaps = 9; d.TW = 3; d.tap_h0 = -1; d.tap_w0 = -1; d.log2Cin = ilog2_exact(C);
     d.Cout = C; d.Hlim = H; d.Wlim = W; d.ldy = C; d.y_rstride = (long)W * C; d.y_bstride = (long)H * W * C;
