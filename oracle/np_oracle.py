@@ -371,9 +371,10 @@ def audio_pow_times(n_audio_files):
 
 def deploy_window_table(chunks_t, deploy_start=0., deploy_duration=10., audio_rate=48000,
                         video_rate=10, context=1.0, batch_size=10, num_audio_frames=None):
-    """(t, start_frame, pad_before, frame_idx, batch_id) per window, following
+    """(t, start_frame, pad_before, frame_idx, batch_id, read_start) per window, following
     feeder.py:228-231 (filters), deploy.py:106-107 (time shift), feeder.py:64-72 (audio start /
-    padding), feeder.py:121 (frame index), deploy.py:112-139 (groups of 10)."""
+    padding), feeder.py:79-82 (first sample actually read), feeder.py:121 (frame index),
+    deploy.py:112-139 (groups of 10)."""
     ts = list(chunks_t)
     if deploy_start > 0.5:
         ts = [t for t in ts if t >= deploy_start]
@@ -386,8 +387,10 @@ def deploy_window_table(chunks_t, deploy_start=0., deploy_duration=10., audio_ra
         start_time = t - context / 2
         start_frame = int(start_time * audio_rate)
         pad_before = abs(start_frame) if start_frame < 0 else 0
+        st = 0. if start_frame < 0 else start_time
+        read_start = int(st) * int(audio_rate) + int((st - int(st)) * audio_rate)          # feeder.py:79-82
         frame_idx = max(int(t * video_rate), 0)
-        rows.append((t, start_frame, pad_before, frame_idx, i // batch_size))
+        rows.append((t, start_frame, pad_before, frame_idx, i // batch_size, read_start))
     return rows
 
 

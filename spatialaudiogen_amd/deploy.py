@@ -60,20 +60,24 @@ def window_times(chunks_t, deploy_start, deploy_duration):
 
 
 def audio_window(audio, t, context, size, rate):
-    """AudioReader.get (feeder.py:64-90): `size` samples starting at int((t - context/2) * rate), zero
-    padded before/after.  audio: [n_samples, C]."""
+    """AudioReader.get (feeder.py:64-90) on one contiguous array: `size` samples for the window at time t, zero
+    padded before/after.  The padding is derived from start_frame = int((t - context/2) * rate), but the
+    samples are read from int(start)*rate + int((start - int(start)) * rate) (feeder.py:81) — one sample
+    earlier whenever the fractional part truncates differently (e.g. start = 1.2 -> 57599, not 57600).  Kept:
+    it is what the reference feeds the network.  audio: [n_samples, C]."""
     start_time = t - context / 2
     start_frame = int(start_time * rate)
-    num_frames = audio.shape[0]
+    num_frames = int(int(np.ceil(audio.shape[0] / float(rate))) * rate)      # AudioReader.num_frames = n_files * rate
     pad_before = pad_after = 0
     if start_frame < 0:
         pad_before = abs(start_frame)
         size -= pad_before
-        start_frame = 0
+        start_time, start_frame = 0., 0
     if start_frame + size > num_frames:
         pad_after = start_frame + size - num_frames
         size -= pad_after
-    chunk = audio[start_frame:start_frame + max(size, 0)]
+    read_start = int(start_time) * int(rate) + int((start_time - int(start_time)) * rate)
+    chunk = audio[read_start:read_start + max(size, 0)]
     if pad_before or pad_after:
         chunk = np.concatenate([np.zeros((pad_before, audio.shape[1]), audio.dtype), chunk,
                                 np.zeros((pad_after, audio.shape[1]), audio.dtype)], 0)
@@ -86,17 +90,41 @@ def frame_index(t, video_rate):
 
 
 class ClipArrays(object):
-    """An in-memory clip: the arrays SampleReader would read from <folder>/ambix, /video, /flow
-    (feeder.py:164-239).  audio [n, C>=1] float; video/flow [n_frames, 224, 448, 3] already
+    """An in-memory clip with SampleReader's interface (feeder.py:164-265): the arrays a reader would decode
+    from <folder>/ambix, /video, /flow.  audio [n, C>=1] float; video/flow [n_frames, 224, 448, 3] already
     preprocessed (x/255-0.5, myutils.py:88-89; flow de-quantised, feeder.py:147-161)."""
 
-    def __init__(self, audio, video=None, flow=None, audio_rate=48000, chunks_t=None, duration=0.1, context=1.0):
+    def __init__(self, audio, video=None, flow=None, audio_rate=48000, video_rate=10, chunks_t=None, duration=0.1,
+                 context=1.0, start_time=0.5, sample_duration=None):
         self.audio, self.video, self.flow = audio, video, flow
-        self.audio_rate = audio_rate
+        self.audio_rate, self.video_rate, self.context = audio_rate, video_rate, context
+        self.audio_size = int(duration * audio_rate) + int(context * audio_rate) - 1
         if chunks_t is None:   # audio_pow.lst times (scraping/preprocess.py:146-153), one 1-s wav chunk per second
             n_files = int(np.ceil(audio.shape[0] / float(audio_rate)))
             chunks_t = [float('%.12g' % (i / 10. + 0.5)) for i in range((n_files - 1) * 10)]
+        if start_time > 0.5:                                             # feeder.py:228-231
+            chunks_t = [t for t in chunks_t if t >= start_time]
+        if sample_duration is not None:
+            chunks_t = [t for t in chunks_t if t < start_time + sample_duration]
         self.chunks_t = chunks_t
+        self.head = -1
+
+    def windowed(self, start_time, sample_duration):
+        return ClipArrays(self.audio, self.video, self.flow, self.audio_rate, self.video_rate, None, 0.1, self.context,
+                          start_time, sample_duration)
+
+    def get(self):
+        self.head += 1
+        if self.head >= len(self.chunks_t):
+            return None
+        t = self.chunks_t[self.head]
+        out = {'id': 'clip ' + str(t), 'ambix': audio_window(self.audio, t, self.context, self.audio_size, self.audio_rate)}
+        fi = frame_index(t, self.video_rate)
+        if self.video is not None:
+            out['video'] = self.video[fi][np.newaxis]
+        if self.flow is not None:
+            out['flow'] = self.flow[fi][np.newaxis]
+        return out
 
 
 class W2XYZ(object):
@@ -123,39 +151,103 @@ class W2XYZ(object):
 
     @staticmethod
     def _load_variables(model_dir):
-        """Weights exported as one .npz keyed by the TF variable names (a TF1 tensor-bundle reader is
-        SURVEY 8f-1, not part of this round)."""
+        """Weights: the TF1 checkpoint of the model directory (tensor-bundle reader, checkpoint.py), or an
+        .npz keyed by the TF variable names."""
         fn = os.path.join(model_dir, 'variables.npz')
-        if not os.path.exists(fn):
-            raise IOError('%s not found: export the checkpoint variables to an .npz keyed by TF names' % fn)
-        with np.load(fn) as z:
-            return {k: z[k] for k in z.files}
+        if os.path.exists(fn):
+            with np.load(fn) as z:
+                return {k: z[k] for k in z.files}
+        from .checkpoint import latest_checkpoint, load_checkpoint
+        prefix = latest_checkpoint(model_dir)
+        if prefix is None:
+            raise IOError('no checkpoint (or variables.npz) found in %s' % model_dir)
+        return load_checkpoint(prefix)
 
-    def deploy(self, clip, deploy_start=0., deploy_duration=10.):
-        """deploy.py:90-152.  `clip` is a ClipArrays. Returns [n_windows*snd_dur, 4] = W,Y,Z,X."""
+    def _reader(self, source, deploy_start, deploy_duration):
+        p = self.params
+        if isinstance(source, ClipArrays):
+            return source.windowed(deploy_start, deploy_duration)
+        from .feeder import SampleReader, img_prep_fcn
+        return SampleReader(source, ambi_order=p.ambi_order, audio_rate=p.audio_rate, video_rate=p.video_rate,
+                            context=p.context, duration=self.duration, return_video=VIDEO in p.encoders,
+                            img_prep=img_prep_fcn(), return_flow=FLOW in p.encoders, start_time=deploy_start,
+                            sample_duration=deploy_duration, skip_silence_thr=None, shuffle=False,
+                            random_rotations=False, skip_rate=None)                   # deploy.py:91-105
+
+    def deploy(self, input_folder, deploy_start=0., deploy_duration=10., prefetch=True):
+        """deploy.py:90-152.  `input_folder` is a clip directory (or a ClipArrays).  Returns
+        [n_windows*snd_dur, 4] = W,Y,Z,X."""
         import torch
         from . import ops
+        from .feeder import BatchPrefetcher
         p, m = self.params, self.model
-        ts = window_times(clip.chunks_t, deploy_start, deploy_duration)
-        use_v, use_f = VIDEO in p.encoders, FLOW in p.encoders
-        outs = []
-        for g in range(0, len(ts), self.batch_size):
-            group = ts[g:g + self.batch_size]
-            n = len(group)
-            audio = np.zeros((self.batch_size, self.audio_size, 1), np.float32)       # zero rows = deploy.py:125-127
-            video = np.zeros((self.batch_size, 1, 224, 448, 3), np.float32) if use_v else None
-            flow = np.zeros((self.batch_size, 1, 224, 448, 3), np.float32) if use_f else None
-            for i, t in enumerate(group):
-                audio[i, :, 0] = audio_window(clip.audio, t, p.context, self.audio_size, p.audio_rate)[:, 0]
-                fi = frame_index(t, p.video_rate)
-                if use_v:
-                    video[i, 0] = clip.video[fi]
-                if use_f:
-                    flow[i, 0] = clip.flow[fi]
-            a_dev = torch.as_tensor(audio).to(m.device)
-            pred = m.inference_ops(a_dev, video, flow)                                 # deploy.py:141
-            wyzx = ops.assemble_wyzx(a_dev[:, :, 0].contiguous(), pred, m.snd_contx)   # deploy.py:143-152
-            outs.append(wyzx[:n].reshape(n * m.snd_dur, 4).cpu().numpy())
-        if not outs:
+        reader = self._reader(input_folder, deploy_start, deploy_duration)
+        if not reader.chunks_t:
             return np.zeros((0, 4), np.float32)
+        dt = reader.chunks_t[0] - deploy_start                           # deploy.py:106-107
+        reader.chunks_t = [t - dt for t in reader.chunks_t]
+        use_v, use_f = VIDEO in p.encoders, FLOW in p.encoders
+
+        def batches():                                                   # deploy.py:112-139
+            while True:
+                batch = []
+                for _ in range(self.batch_size):
+                    chunk = reader.get()
+                    if chunk is None:
+                        break
+                    batch.append(chunk)
+                if not batch:
+                    return
+                n = len(batch)
+                out = {'n': n}
+                audio = np.zeros((self.batch_size, self.audio_size, 1), np.float32)   # zero rows = deploy.py:125-127
+                audio[:n] = np.stack([b['ambix'] for b in batch], 0)[:, :, :1]
+                out['audio'] = audio
+                for key, on in (('video', use_v), ('flow', use_f)):
+                    if on:
+                        x = np.zeros((self.batch_size, 1, 224, 448, 3), np.float32)
+                        x[:n] = np.stack([b[key] for b in batch], 0)
+                        out[key] = x
+                yield out
+
+        src = BatchPrefetcher(batches(), depth=2, pin=True) if prefetch else batches()
+        outs = []
+        for b in src:
+            to_dev = lambda k: torch.as_tensor(b[k]).to(m.device, non_blocking=True) if k in b else None
+            a_dev = to_dev('audio')
+            pred = m.inference_ops(a_dev, to_dev('video'), to_dev('flow'))             # deploy.py:141
+            wyzx = ops.assemble_wyzx(a_dev[:, :, 0].contiguous(), pred, m.snd_contx)   # deploy.py:143-152
+            outs.append(wyzx[:b['n']].reshape(b['n'] * m.snd_dur, 4).cpu().numpy())
         return np.concatenate(outs, 0)
+
+
+def parse_arguments(argv=None):
+    """deploy.py:14-38 (the ffmpeg / 360-video outputs are outside this path; the ambisonic wav is written)."""
+    import argparse
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument('model_dir', help='Directory containing model snapshot.')
+    parser.add_argument('input_folder', default='', help='Folder with input sample.')
+    parser.add_argument('--deploy_start', default=0., type=float)
+    parser.add_argument('--deploy_duration', default=10., type=float)
+    parser.add_argument('--output_fn', default='output.wav', help='Output 4-channel (W,Y,Z,X) wav.')
+    parser.add_argument('--gpu', type=int, default=0, help='GPU id')
+    args = parser.parse_args(argv)
+    if args.deploy_duration <= 0:
+        args.deploy_duration = None
+    return args
+
+
+def main(argv=None):
+    """deploy.py:155-198 up to save_wav."""
+    import torch
+    from .feeder import save_wav
+    args = parse_arguments(argv)
+    torch.cuda.set_device(args.gpu)
+    model = W2XYZ(args.model_dir)
+    ambi_pred = model.deploy(args.input_folder, args.deploy_start, args.deploy_duration)
+    save_wav(args.output_fn, ambi_pred, model.params.audio_rate)
+    print('wrote %s: %d samples x 4 channels (ACN W,Y,Z,X / SN3D)' % (args.output_fn, ambi_pred.shape[0]))
+
+
+if __name__ == '__main__':
+    main()

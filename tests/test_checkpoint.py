@@ -1,0 +1,75 @@
+"""TF1 tensor-bundle checkpoint reader: on-disk structures checked against hand-assembled
+bytes (independent of the writer) and by round trips through the minimal writer."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from spatialaudiogen_amd import checkpoint as ck
+from spatialaudiogen_amd.weights import variable_specs, init_weights
+
+
+def test_varints_and_protobuf_fields():
+    for v in (0, 1, 127, 128, 300, 2 ** 32 + 5, 2 ** 63 - 1):
+        enc = ck._put_varint(v)
+        assert ck._varint(enc + b'\x99', 0) == (v, len(enc))
+    # BundleEntryProto by hand: dtype=DT_FLOAT(1), shape {dim{size:3} dim{size:5}}, shard 0, offset 300, size 60, crc fixed32
+    shape = b'\x12\x02\x08\x03' + b'\x12\x02\x08\x05'
+    msg = b'\x08\x01' + b'\x12' + bytes([len(shape)]) + shape + b'\x20\xac\x02' + b'\x28\x3c' + b'\x35' + struct.pack('<I', 0xdeadbeef)
+    e = ck._parse_entry(msg)
+    assert (e['dtype'], e['shape'], e['offset'], e['size'], e['crc32c'], e['shard_id']) == (1, (3, 5), 300, 60, 0xdeadbeef, 0)
+
+
+def test_prefix_compressed_block_by_hand():
+    # entries: "audio/conv1/biases"->b"A", "audio/conv1/weights"->b"BB", "audio/conv2/w"->b"C"; one restart at 0
+    e1 = bytes([0, 18, 1]) + b'audio/conv1/biases' + b'A'
+    e2 = bytes([12, 7, 2]) + b'weights' + b'BB'             # shares "audio/conv1/"
+    e3 = bytes([10, 3, 1]) + b'2/w' + b'C'                   # shares "audio/conv"
+    block = e1 + e2 + e3 + struct.pack('<I', 0) + struct.pack('<I', 1)
+    assert list(ck._block_entries(block)) == [(b'audio/conv1/biases', b'A'), (b'audio/conv1/weights', b'BB'), (b'audio/conv2/w', b'C')]
+
+
+def test_snappy_decoder_literals_and_copies():
+    # "abcdabcdabcdxyz": literal "abcd", copy(offset 4, len 8) with a 1-byte-offset tag, literal "xyz"
+    stream = ck._put_varint(15) + bytes([(4 - 1) << 2]) + b'abcd' + bytes([((8 - 4) << 2) | 1, 4]) + bytes([(3 - 1) << 2]) + b'xyz'
+    assert ck._snappy_decompress(stream) == b'abcdabcdabcdxyz'
+    # 2-byte-offset copy
+    stream = ck._put_varint(10) + bytes([(5 - 1) << 2]) + b'hello' + bytes([((5 - 1) << 2) | 2, 5, 0])
+    assert ck._snappy_decompress(stream) == b'hellohello'
+
+
+def test_crc32c_known_answers():
+    assert ck.crc32c(b'') == 0
+    assert ck.crc32c(b'123456789') == 0xE3069283
+    assert ck.crc32c(b'\x00' * 32) == 0x8A9136AA
+
+
+def test_round_trip_of_a_full_model_checkpoint(tmp_path):
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=11, mode='test')
+    extra = {'step': np.array(150000, np.int64), 'beta1_power': np.array(0.9, np.float32)}
+    for k in list(P)[:5]:
+        extra[k + '/Adam'] = np.zeros_like(P[k])
+        extra[k + '/Adam_1'] = np.ones_like(P[k])
+    allv = dict(P); allv.update(extra)
+    prefix = str(tmp_path / 'model.ckpt-150000')
+    ck.save_checkpoint(prefix, allv, block_entries=16)           # several data blocks + prefix compression
+    assert ck.latest_checkpoint(str(tmp_path)) == prefix
+    entries, header = ck.read_index(prefix + '.index')
+    assert header['num_shards'] == 1 and len(entries) == len(allv)
+    assert entries['separation/deconv1/weights']['shape'] == (7, 16, 32, 64)
+    got = ck.load_checkpoint(prefix)
+    assert set(got) == set(allv)
+    for k, v in allv.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    sub = ck.load_checkpoint(prefix, names={'localization/fc3/biases', 'step'})
+    assert set(sub) == {'localization/fc3/biases', 'step'} and sub['step'] == 150000
+
+
+def test_bad_files_are_rejected(tmp_path):
+    p = tmp_path / 'x.index'
+    p.write_bytes(b'\x00' * 100)
+    with pytest.raises(ValueError):
+        ck.read_index(str(p))
+    assert ck.latest_checkpoint(str(tmp_path)) is None

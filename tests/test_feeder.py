@@ -1,0 +1,93 @@
+"""On-disk readers: a synthetic clip directory in the reference's layout is read back
+through SampleReader and must give exactly what the in-memory ClipArrays path gives."""
+import os
+
+import numpy as np
+import pytest
+
+from spatialaudiogen_amd import feeder as F
+from spatialaudiogen_amd.deploy import ClipArrays, audio_window, frame_index
+from util import rng
+
+
+def make_clip(root, secs=3, flow=False, seed=0):
+    from PIL import Image
+    r = rng(seed)
+    os.makedirs(os.path.join(root, 'ambix')); os.makedirs(os.path.join(root, 'video'))
+    audio = np.clip(0.3 * r.normal(size=(secs * 48000, 4)), -1, 1)
+    for i in range(secs):
+        F.save_wav(os.path.join(root, 'ambix', '%06d.wav' % i), audio[i * 48000:(i + 1) * 48000], 48000)
+    frames = r.integers(0, 256, size=(secs * 10, 224, 448, 3)).astype(np.uint8)
+    frames = (frames // 32) * 32                                  # coarse levels survive JPEG poorly anyway: decode is the truth
+    for i, fr in enumerate(frames):
+        Image.fromarray(fr).save(os.path.join(root, 'video', '%06d.jpg' % i), quality=95)
+    with open(os.path.join(root, 'audio_pow.lst'), 'w') as f:
+        for i in range((secs - 1) * 10):
+            t = i / 10. + 0.5
+            f.write('{} {}\n'.format(t, 0.1 + 0.01 * i))
+    if flow:
+        os.makedirs(os.path.join(root, 'flow'))
+        for i in range(secs * 10):
+            Image.fromarray(frames[(i * 7) % len(frames)]).save(os.path.join(root, 'flow', '%06d.jpg' % i), quality=95)
+        np.save(os.path.join(root, 'flow', 'flow_limits.npy'), np.stack([np.zeros(secs * 10), np.linspace(1, 4, secs * 10)], 1))
+    return audio
+
+
+def test_wav_round_trip_is_pcm16(tmp_path):
+    x = np.clip(0.5 * rng(1).normal(size=(1000, 4)), -1, 1)
+    fn = str(tmp_path / 'a.wav')
+    F.save_wav(fn, x, 48000)
+    y, rate = F.load_wav(fn, 48000)
+    assert rate == 48000 and y.shape == x.shape
+    assert np.abs(y - x).max() <= 2.0 / 32768          # written x32767 (rounded), read /32768 like libsndfile
+    with pytest.raises(ValueError):
+        F.load_wav(fn, 44100)
+
+
+def test_sample_reader_matches_in_memory_clip(tmp_path):
+    root = str(tmp_path / 'clip0')
+    make_clip(root, secs=3, flow=True)
+    prep = F.img_prep_fcn()
+    rd = F.SampleReader(root, return_video=True, img_prep=prep, return_flow=True, shuffle=False, random_rotations=False,
+                        start_time=0., sample_duration=10.)
+    assert len(rd.chunks_t) == 20 and rd.chunks_t[:3] == [0.5, 0.6, 0.7]
+    # decoded truth
+    audio = np.concatenate([F.load_wav(os.path.join(root, 'ambix', '%06d.wav' % i))[0] for i in range(3)], 0)
+    video = np.stack([prep(F.imread(os.path.join(root, 'video', '%06d.jpg' % i))) for i in range(30)], 0)
+    clip = ClipArrays(audio, video, start_time=0., sample_duration=10.)
+    assert clip.chunks_t == rd.chunks_t
+    lims = np.load(os.path.join(root, 'flow', 'flow_limits.npy'))
+    for _ in range(20):
+        a, b = rd.get(), clip.get()
+        t = rd.cur_t
+        assert a['ambix'].shape == (52799, 4) and np.array_equal(a['ambix'], b['ambix'])
+        assert np.array_equal(a['ambix'], audio_window(audio, t, 1.0, 52799, 48000))
+        assert a['video'].shape == (1, 224, 448, 3) and np.array_equal(a['video'], b['video'])
+        fi = frame_index(t, 10)
+        raw = F.imread(os.path.join(root, 'flow', '%06d.jpg' % fi)).astype(np.float32)
+        mag = raw[..., 2] * (lims[fi, 1] - lims[fi, 0]) / 255. + lims[fi, 0]
+        ang = raw[..., 0] * (2 * np.pi) / 255.
+        assert np.allclose(a['flow'][0, ..., 2], mag) and np.allclose(a['flow'][0, ..., 0], mag * np.cos(ang), atol=1e-5)
+        assert np.allclose(a['flow'][0, ..., 1], mag * np.sin(ang), atol=1e-5)
+    assert rd.get() is None and clip.get() is None
+
+
+def test_reader_filters(tmp_path):
+    root = str(tmp_path / 'clip1')
+    make_clip(root, secs=4)
+    base = dict(return_video=False, shuffle=False, random_rotations=False)
+    assert len(F.SampleReader(root, **base).chunks_t) == 30
+    assert len(F.SampleReader(root, skip_rate=10, **base).chunks_t) == 3                       # eval: every 10th window
+    assert F.SampleReader(root, skip_silence_thr=0.25, **base).chunks_t[0] == pytest.approx(2.1)  # pow > thr
+    assert F.SampleReader(root, start_time=1.0, sample_duration=1.0, **base).chunks_t == pytest.approx([1.0 + 0.1 * i for i in range(10)])
+    parts = [F.SampleReader(root, num_threads=3, thread_id=i, **base).chunks_t for i in range(3)]
+    assert sum(parts, []) == F.SampleReader(root, **base).chunks_t
+    rot = F.AudioReader(os.path.join(root, 'ambix'), 48000).get(1.0, 100, rotation=np.pi / 2)
+    ref = F.AudioReader(os.path.join(root, 'ambix'), 48000).get(1.0, 100)
+    assert np.allclose(rot[:, 0], ref[:, 0]) and np.allclose(rot[:, 1], ref[:, 3]) and np.allclose(rot[:, 3], -ref[:, 1])
+
+
+def test_batch_prefetcher_preserves_order():
+    gen = ({'i': i, 'x': np.full((2, 2), i, np.float32)} for i in range(7))
+    got = [b['i'] for b in F.BatchPrefetcher(gen, depth=2)]
+    assert got == list(range(7))

@@ -40,7 +40,7 @@ def test_deploy_matches_oracle(encoders, secs, duration):
     for g in range(0, len(rows), 10):
         grp = rows[g:g + 10]
         a = np.zeros((10, 52799, 1)); v = np.zeros((10, 1, 224, 448, 3)) if video is not None else None
-        for i, (t, start, pad, fi, _) in enumerate(grp):
+        for i, (t, start, pad, fi, _, _) in enumerate(grp):
             a[i, :, 0] = audio_window(audio, t, 1.0, 52799, 48000)[:, 0]
             if v is not None:
                 v[i, 0] = video[fi]
@@ -50,3 +50,36 @@ def test_deploy_matches_oracle(encoders, secs, duration):
     assert np.array_equal(got[:, 0], ref[:, 0].astype(np.float32))                   # W is a bit-exact copy of the mono crop
     err = rms(got[:, 1:] - ref[:, 1:])
     assert err <= 1e-4 and err <= 1e-3 * rms(ref[:, 1:])
+
+
+def test_deploy_cli_from_disk(tmp_path):
+    """model_dir (train-params.txt + TF-format checkpoint) and a clip folder in the scraping/preprocess.py layout,
+    through the deploy CLI: the wav it writes equals the in-memory W2XYZ.deploy result (PCM16-quantised)."""
+    import torch
+    assert torch.cuda.is_available()
+    ensure_lib()
+    import os
+    from test_feeder import make_clip
+    from spatialaudiogen_amd import checkpoint as ck, feeder as F
+    from spatialaudiogen_amd.deploy import W2XYZ, ClipArrays, main
+    enc = ['audio', 'video']
+    model_dir = tmp_path / 'model'; model_dir.mkdir()
+    P = init_weights(variable_specs(enc), seed=8, mode='test')
+    extra = dict(P); extra['step'] = np.array(150000, np.int64)
+    ck.save_checkpoint(str(model_dir / 'model.ckpt-150000'), extra)
+    (model_dir / 'train-params.txt').write_text(
+        "encoders: ['audio', 'video']\nseparation: unet_mask\nambi_order: 1\naudio_rate: 48000\nvideo_rate: 10\n"
+        "context: 1.0\nsample_dur: 0.1\nnum_sep_tracks: 32\nloc_units: [512, 512]\nfft_window: 0.025\n"
+        "context_units: [64, 128, 128]\nfreq_mask_units: []\nlr: 0.0001\nbatch_size: 32\n")
+    clip_dir = str(tmp_path / 'clip'); make_clip(clip_dir, secs=3)
+    out_fn = str(tmp_path / 'out.wav')
+    main([str(model_dir), clip_dir, '--deploy_duration', '1.2', '--output_fn', out_fn])
+    wav, rate = F.load_wav(out_fn)
+    assert rate == 48000 and wav.shape == (12 * 4800, 4)
+
+    prep = F.img_prep_fcn()
+    audio = np.concatenate([F.load_wav(os.path.join(clip_dir, 'ambix', '%06d.wav' % i))[0] for i in range(3)], 0)
+    video = np.stack([prep(F.imread(os.path.join(clip_dir, 'video', '%06d.jpg' % i))) for i in range(30)], 0)
+    ref = W2XYZ(params=Params(enc), variables=P).deploy(ClipArrays(audio, video), 0., 1.2, prefetch=False)
+    assert ref.shape == wav.shape
+    assert np.abs(wav - np.clip(ref, -1, 1)).max() <= 2.0 / 32768
