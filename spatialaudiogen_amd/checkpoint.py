@@ -216,7 +216,7 @@ def load_checkpoint(prefix, names=None):
         if count * dt.itemsize != e['size']:
             raise ValueError('%s: size %d does not match shape %s' % (name, e['size'], e['shape']))
         raw = shards[sid][e['offset']:e['offset'] + e['size']]
-        out[name] = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e['shape'])
+        out[name] = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e['shape']).copy()
     return out
 
 

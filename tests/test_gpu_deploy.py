@@ -75,7 +75,7 @@ def test_deploy_cli_from_disk(tmp_path):
     out_fn = str(tmp_path / 'out.wav')
     main([str(model_dir), clip_dir, '--deploy_duration', '1.2', '--output_fn', out_fn])
     wav, rate = F.load_wav(out_fn)
-    assert rate == 48000 and wav.shape == (12 * 4800, 4)
+    assert rate == 48000 and wav.shape == (7 * 4800, 4)          # t in {0.5..1.1} < 0 + 1.2  (feeder.py:230-231)
 
     prep = F.img_prep_fcn()
     audio = np.concatenate([F.load_wav(os.path.join(clip_dir, 'ambix', '%06d.wav' % i))[0] for i in range(3)], 0)
