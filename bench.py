@@ -36,6 +36,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
+    ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
     return ap.parse_args()
 
@@ -115,7 +116,15 @@ def main():
             dist.all_reduce(metric)
 
     # untimed set-up: per-layer (tile, split-K) autotune on this rank's own batch, then W warm-up steps
-    plan = net.autotune(audio, video) if not args.no_autotune else []
+    plan = []
+    if args.plan_file and os.path.exists(args.plan_file):
+        net.inference_ops(audio, video, out=out)
+        net.load_plan(BATCH, args.plan_file)
+        plan = net.plan(BATCH)
+    elif not args.no_autotune:
+        plan = net.autotune(audio, video)
+        if args.plan_file and rank == 0:
+            net.save_plan(BATCH, args.plan_file)
     for _ in range(args.warmup):
         step()
     reduce_metric()                     # also loads the torch kernels it uses before the timed region

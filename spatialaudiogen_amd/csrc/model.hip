@@ -825,6 +825,12 @@ int sagen_autotune_impl(sagen_ctx* c, const float* audio, const float* video, co
 }
 
 int sagen_plan_set_impl(sagen_ctx* c, const char* layer, int tile, int splitk) {
+    const std::string name(layer);
+    const std::string sfx = "#materialize";       // pseudo-entry: apply the producer's BN+ReLU in its own pass?
+    if (name.size() > sfx.size() && name.compare(name.size() - sfx.size(), sfx.size(), sfx) == 0) {
+        c->materialize[name.substr(0, name.size() - sfx.size())] = splitk != 0;
+        return SAGEN_OK;
+    }
     if (tile < 0 || tile >= (int)TILE_AUTO || splitk < 1 || splitk > 64) return fail(SAGEN_ERR_SHAPE, "sagen_plan_set: tile=%d splitk=%d", tile, splitk);
     Choice ch;
     ch.tile = tile; ch.splitk = splitk;
@@ -841,9 +847,14 @@ int sagen_plan_describe_impl(sagen_ctx* c, char* buf, size_t buflen) {
                  kv.second.splitk, kv.second.us);
         out += line;
     }
+    int n = (int)c->plan.size();
+    for (const auto& kv : c->materialize) {
+        out += kv.first + "#materialize\t-\t" + (kv.second ? "1" : "0") + "\t0\n";
+        ++n;
+    }
     if (out.size() + 1 > buflen) return fail(SAGEN_ERR_WORKSPACE, "plan description needs %zu bytes", out.size() + 1);
     memcpy(buf, out.c_str(), out.size() + 1);
-    return (int)c->plan.size();
+    return n;
 }
 
 int sagen_profile_enable_impl(sagen_ctx* c, int on) {

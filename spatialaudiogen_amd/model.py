@@ -214,7 +214,34 @@ class SptAudioGen(object):
         return self.plan(B)
 
     def plan_set(self, batch, layer, tile, splitk):
-        check(_lib.lib().sagen_plan_set(self.context_for(batch).handle, layer.encode(), int(tile), int(splitk)))
+        check(_lib.lib().sagen_plan_set(self.context_for(batch).handle, layer.encode(), max(int(tile), 0), int(splitk)))
+
+    def save_plan(self, batch, fn):
+        """Persist the launch plan of this batch size (JSON) so later processes can replay it without tuning."""
+        import json
+        with open(fn, 'w') as f:
+            json.dump({'batch': batch, 'encoders': self.encoders, 'plan': self.plan(batch)}, f, indent=1)
+
+    def load_plan(self, batch, fn):
+        import json
+        from ._lib import SIGNATURES  # noqa: F401
+        with open(fn) as f:
+            doc = json.load(f)
+        if doc.get('batch') != batch or doc.get('encoders') != self.encoders:
+            raise ValueError('%s was tuned for batch %s / encoders %s' % (fn, doc.get('batch'), doc.get('encoders')))
+        names = self.tile_names()
+        for layer, tile, sk, _ in doc['plan']:
+            self.plan_set(batch, layer, names.index(tile) if tile in names else 0, sk)
+
+    @staticmethod
+    def tile_names():
+        return ['igemm_kernel<128,128,64,64,3,16>', 'igemm_kernel<128,64,64,32,3,16>', 'igemm_kernel<256,64,64,64,3,16>',
+                'igemm_kernel<64,64,32,32,3,16>', 'igemm_kernel<128,32,32,32,2,16>', 'igemm_kernel<32,128,32,32,2,16>',
+                'igemm_kernel<128,128,64,64,2,16>', 'igemm_kernel<128,64,64,32,2,16>', 'igemm_kernel<256,64,64,64,2,16>',
+                'igemm_kernel<64,64,32,32,2,16>', 'igemm_kernel<64,128,32,64,3,16>', 'igemm_kernel<64,128,32,64,2,16>',
+                'igemm_kernel<64,256,64,64,3,16>', 'igemm_kernel<64,256,64,64,2,16>', 'igemm_kernel<256,32,64,32,2,16>',
+                'igemm_kernel<64,64,32,32,2,32>', 'igemm_kernel<64,128,32,64,2,32>', 'igemm_kernel<128,64,64,32,2,32>',
+                'igemm_kernel<128,128,64,64,2,32>', 'igemm_kernel<32,128,32,32,2,32>', 'igemm_kernel<128,32,32,32,2,32>']
 
     def plan(self, batch):
         buf = C.create_string_buffer(1 << 16)

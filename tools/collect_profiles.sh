@@ -4,11 +4,18 @@
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
-BENCH="python $R/bench.py --no-cpu-baseline"
+# tune once OUTSIDE the profiler, then replay the saved plan so the traces hold steady-state launches only
+python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --plan-file $O/plan.json > $O/tune.log 2>&1
+BENCH="python $R/bench.py --no-cpu-baseline --plan-file $O/plan.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH --steps 20 --warmup 5 > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $BENCH --steps 2 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $BENCH --steps 2 --warmup 1 > $O/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- $BENCH --steps 2 --warmup 1 > $O/sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $O/sq2 -- $BENCH --steps 2 --warmup 1 > $O/sq2.log 2>&1
 grep -h '"metric"' $O/trace.log | tail -1 > $O/bench_under_trace.json
-find $O -name "*.csv" | wc -l
+# digest on the box, ship only the summaries (raw traces exceed gpurun's copy-back limit)
+python $R/tools/summarize_profiles.py $TAG $R/gpurun_out/profiles_$TAG > $O/summary.txt 2>&1
+cp $O/summary.txt $R/gpurun_out/profiles_$TAG/${TAG}_summary.txt
+cp $O/plan.json $R/gpurun_out/profiles_$TAG/${TAG}_plan.json
+rm -rf $O
+ls $R/gpurun_out/profiles_$TAG

@@ -3,7 +3,7 @@ import csv, glob, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
-dst = os.path.join(ROOT, 'profiles')
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 
 
