@@ -187,6 +187,16 @@ size_t sagen_mask_istft_mix_scratch_bytes(int batch);
 int sagen_mask_istft_mix(const float* dmask, const float* spec, const float* coeffs, int batch,
                          int ntracks, float* ambi_yzx, void* scratch, size_t scratch_bytes, void* stream);
 
+/* SptAudioGen.evaluation_ops (model.py:110-154) for 0.1 s windows at 48 kHz, first-order (3 predicted channels):
+ * per_sample [4][B][3] = stft distance (model.py:62-76; before the x100 and channel masking of :122-127), log-spectral
+ * distance on the 1200-point STFT (:78-94), temporal MSE (:96-99; before x5e3) and SNR (:101-108);
+ * power_sums[2] (fp64) = sum pred^2, sum target^2 over everything (-> pow/pred, pow/gt after /(3B)).
+ * scratch: >= sagen_eval_scratch_bytes(batch) bytes, initialised ONCE with sagen_eval_init (DFT matrix). */
+size_t sagen_eval_scratch_bytes(int batch);
+int sagen_eval_init(void* scratch, size_t scratch_bytes, int batch, void* stream);
+int sagen_eval_metrics(const float* pred_yzx, const float* target_yzx, int batch, float* per_sample,
+                       double* power_sums, void* scratch, size_t scratch_bytes, void* stream);
+
 /* AmbiDecoder.decode('projection') + RMS map (pyutils/ambisonics/decoder.py:24-28,
  * distance.py:41-52; SH matrix common.py:151-178, order 1 ACN/SN3D):
  * ambi_wyzx [T,4]; sh [P,4] device matrix; rms [P] = sqrt(mean_t (ambi . sh[p])^2).

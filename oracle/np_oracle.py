@@ -418,3 +418,75 @@ def power_map(ambi, angular_res):
     decoded = np.asarray(ambi, np.float64) @ Y.T
     rms = np.sqrt(np.mean(decoded ** 2, 0)).reshape(phi_mesh.shape)
     return np.flipud(rms)
+
+
+# ----------------------------------------------------------------------------------------
+# evaluation metrics on the graph (model.py:62-154, myutils.stft_for_loss myutils.py:151-178)
+# ----------------------------------------------------------------------------------------
+def stft_for_loss(signal, window, n_overlap):
+    """myutils.stft_for_loss (myutils.py:151-178). signal [BS, N, nC] -> complex [BS, nC, nW, window2]."""
+    BS, N, nC = signal.shape
+    window = int(2 ** np.ceil(np.log(window) / np.log(2)))
+    hann_window = (0.5 - (0.5 * np.cos(2 * np.pi / window * np.arange(window)))).astype(np.float32).astype(np.float64)
+    if n_overlap == 1:
+        nW = int(float(N) / window)
+        if nW > 1:
+            if N > window * nW:
+                signal = signal[:, :window * nW, :]
+            windows = signal.reshape(BS, nW, window, nC)
+        else:
+            windows = signal
+    else:
+        windows = []
+        stride = int(window / n_overlap)
+        for i in range(n_overlap):
+            nW = int(float(N - i * stride - 1) / window)
+            y = signal[:, (i * stride):(i * stride) + window * nW, :]
+            windows.append(y.reshape(BS, nW, window, nC))
+        windows = np.concatenate(windows, 1)
+    windows = windows.transpose(0, 3, 1, 2) * hann_window[None, None, None, :]
+    return np.fft.fft(windows, axis=-1)
+
+
+def evaluation_ops(preds, targets, mask_channels=None, snd_rate=48000, fft_window=0.025, fft_overlap=2):
+    """SptAudioGen.evaluation_ops (model.py:110-154): preds/targets [B, N, 3]; mask [B, 3].
+    Returns (metrics dict, stft_dist_ps, lsd_ps, mse_ps, snr_ps)."""
+    preds, targets = np.asarray(preds, np.float64), np.asarray(targets, np.float64)
+    B, _, nC = preds.shape
+    if mask_channels is None:
+        mask_channels = np.ones((B, nC))
+    mask_channels = np.asarray(mask_channels, np.float64)
+    num_masked = np.maximum(mask_channels.sum(axis=0), 1)
+    window = int(fft_window * snd_rate)
+    metrics = OrderedDict()
+    # _stft_mse_ops (model.py:62-76)
+    diff = np.abs(stft_for_loss(targets, window, fft_overlap) - stft_for_loss(preds, window, fft_overlap))
+    stft_ps = (diff ** 2).mean(axis=3).mean(axis=2)
+    stft_dist = (stft_ps * mask_channels).sum(axis=0) / num_masked * 100.
+    metrics['stft/avg'] = stft_dist.mean()
+    for i, ch in enumerate('YZX'):
+        metrics['stft/' + ch] = stft_dist[i]
+    # _lsd_ops (model.py:78-94)
+    EPS = 1e-2
+    s_gt = stft(targets.transpose(0, 2, 1), window, fft_overlap)
+    s_pr = stft(preds.transpose(0, 2, 1), window, fft_overlap)
+    ps = lambda x: 10 * np.log(np.abs(x) + EPS) / np.log(10.)
+    lsd_ps = np.sqrt(((ps(s_gt) - ps(s_pr)) ** 2).mean(axis=3)).mean(axis=2)
+    lsd = (lsd_ps * mask_channels).sum(axis=0) / num_masked
+    metrics['lsd/avg'] = lsd.mean()
+    for i, ch in enumerate('YZX'):
+        metrics['lsd/' + ch] = lsd[i]
+    # _temporal_mse_ops / _temporal_snr_ops (model.py:96-108)
+    mse_ps = ((targets - preds) ** 2).mean(axis=1)
+    mse = (mse_ps * mask_channels).sum(axis=0) / num_masked * 5e3
+    metrics['mse/avg'] = mse.mean()
+    for i, ch in enumerate('YZX'):
+        metrics['mse/' + ch] = mse[i]
+    snr_ps = 10. * np.log(((targets ** 2).sum(axis=1) + 1e-1) / (((targets - preds) ** 2).sum(axis=1) + 1e-1)) / np.log(10.)
+    snr = (snr_ps * mask_channels).sum(axis=0) / num_masked
+    metrics['snr/avg'] = snr.mean()
+    for i, ch in enumerate('YZX'):
+        metrics['snr/' + ch] = snr[i]
+    metrics['pow/pred'] = (preds ** 2).mean(axis=2).mean(axis=0).sum()
+    metrics['pow/gt'] = (targets ** 2).mean(axis=2).mean(axis=0).sum()
+    return metrics, stft_ps, lsd_ps, mse_ps, snr_ps

@@ -60,6 +60,9 @@ SIGNATURES = {
     'sagen_deconv2d': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _SZ, _P]),
     'sagen_mask_istft_mix_scratch_bytes': (_SZ, [_I]),
     'sagen_mask_istft_mix': (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    'sagen_eval_scratch_bytes': (_SZ, [_I]),
+    'sagen_eval_init': (C.c_int, [_P, _SZ, _I, _P]),
+    'sagen_eval_metrics': (C.c_int, [_P, _P, _I, _P, _P, _P, _SZ, _P]),
     'sagen_power_map': (C.c_int, [_P, _I64, _P, _I, _P, _P]),
 }
 

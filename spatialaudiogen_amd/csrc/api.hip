@@ -286,6 +286,24 @@ int sagen_mask_istft_mix(const float* dmask, const float* spec, const float* coe
                                  (hipStream_t)stream);
 }
 
+size_t sagen_eval_scratch_bytes(int batch) { return batch > 0 ? eval_scratch_floats(batch) * sizeof(float) : 0; }
+
+int sagen_eval_init(void* scratch, size_t scratch_bytes, int batch, void* stream) {
+    if (!scratch) return fail(SAGEN_ERR_NULL, "sagen_eval_init: null scratch");
+    if (batch <= 0 || scratch_bytes < sagen_eval_scratch_bytes(batch)) return fail(SAGEN_ERR_WORKSPACE, "sagen_eval_init: scratch too small");
+    return eval_init_launch((float*)scratch, (hipStream_t)stream);
+}
+
+int sagen_eval_metrics(const float* pred_yzx, const float* target_yzx, int batch, float* per_sample, double* power_sums,
+                       void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        if (!pred_yzx || !target_yzx || !per_sample || !power_sums || !scratch) return fail(SAGEN_ERR_NULL, "sagen_eval_metrics: null argument");
+        if (batch <= 0 || scratch_bytes < sagen_eval_scratch_bytes(batch)) return fail(SAGEN_ERR_WORKSPACE, "sagen_eval_metrics: scratch too small");
+        if (((uintptr_t)power_sums) % 8) return fail(SAGEN_ERR_SHAPE, "sagen_eval_metrics: power_sums must be 8-byte aligned");
+        return eval_metrics_launch(pred_yzx, target_yzx, batch, per_sample, power_sums, (float*)scratch, (hipStream_t)stream);
+    });
+}
+
 int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, float* rms, void* stream) {
     if (!ambi_wyzx || !sh || !rms) return fail(SAGEN_ERR_NULL, "sagen_power_map: null argument");
     if (t <= 0 || p <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_power_map: bad sizes");

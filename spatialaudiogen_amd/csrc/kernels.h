@@ -130,4 +130,12 @@ int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, 
                           const float* coeffs, int B, int ntracks, float* out, float* scratch,
                           hipStream_t s);
 
+// -----------------------------------------------------------------------------------------
+// evaluation metrics (eval.hip)
+// -----------------------------------------------------------------------------------------
+size_t eval_scratch_floats(int B);
+int eval_init_launch(float* scratch, hipStream_t s);                  // fills the DFT matrix once
+// ps [4][B][3] = per-sample stft distance, lsd, temporal mse, snr;  pw[2] = sum pred^2, sum gt^2 (fp64)
+int eval_metrics_launch(const float* pred, const float* gt, int B, float* ps, double* pw, float* scratch, hipStream_t s);
+
 }  // namespace sagen

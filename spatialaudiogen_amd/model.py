@@ -195,6 +195,43 @@ class SptAudioGen(object):
         check(_lib.lib().sagen_forward(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
         return out
 
+    # ---- evaluation metrics (model.py:110-154) -----------------------------------------------------
+    def evaluation_ops(self, preds_t, targets_t, w_t=None, mask_channels=None):
+        """preds/targets [B, snd_dur, 3] -> (metrics OrderedDict, stft_dist_ps, lsd_ps, mse_ps, snr_ps), the last four
+        [B, 3] device tensors exactly as the reference returns them.  `w_t` is accepted for signature parity (unused
+        by the reference too).  Per-sample values are computed by libsagen_hip.so; the masked channel means of
+        model.py:119-150 are a handful of scalar operations on [B,3] done here."""
+        pr = torch.as_tensor(preds_t).to(device=self.device, dtype=torch.float32).contiguous()
+        gt = torch.as_tensor(targets_t).to(device=self.device, dtype=torch.float32).contiguous()
+        B = pr.shape[0]
+        if tuple(pr.shape) != (B, self.snd_dur, 3) or tuple(gt.shape) != tuple(pr.shape):
+            raise ValueError('predictions / targets must be [B, %d, 3]' % self.snd_dur)
+        l = _lib.lib()
+        key = ('eval', B)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if key not in self._ctx:
+            nbytes = int(l.sagen_eval_scratch_bytes(B))
+            scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            check(l.sagen_eval_init(C.c_void_p(scratch.data_ptr()), scratch.numel() * 4, B, stream))
+            self._ctx[key] = scratch
+        scratch = self._ctx[key]
+        ps = torch.empty(4, B, 3, dtype=torch.float32, device=self.device)
+        pw = torch.zeros(2, dtype=torch.float64, device=self.device)
+        check(l.sagen_eval_metrics(C.c_void_p(pr.data_ptr()), C.c_void_p(gt.data_ptr()), B, C.c_void_p(ps.data_ptr()),
+                                   C.c_void_p(pw.data_ptr()), C.c_void_p(scratch.data_ptr()), scratch.numel() * 4, stream))
+        mask = torch.ones(B, 3, device=self.device) if mask_channels is None else \
+            torch.as_tensor(mask_channels).to(device=self.device, dtype=torch.float32)
+        num_masked = torch.clamp(mask.sum(0), min=1.0)
+        metrics = OrderedDict()
+        for name, idx, scale in (('stft', 0, 100.), ('lsd', 1, 1.), ('mse', 2, 5e3), ('snr', 3, 1.)):
+            v = (ps[idx].double() * mask.double()).sum(0) / num_masked.double() * scale
+            metrics[name + '/avg'] = float(v.mean())
+            for i, ch in enumerate('YZX'):
+                metrics[name + '/' + ch] = float(v[i])
+        metrics['pow/pred'] = float(pw[0]) / (3.0 * B)
+        metrics['pow/gt'] = float(pw[1]) / (3.0 * B)
+        return metrics, ps[0], ps[1], ps[2], ps[3]
+
     def intermediate(self, batch, name):
         return self.context_for(batch).intermediate(name)
 

@@ -83,3 +83,44 @@ def test_deploy_cli_from_disk(tmp_path):
     ref = W2XYZ(params=Params(enc), variables=P).deploy(ClipArrays(audio, video), 0., 1.2, prefetch=False)
     assert ref.shape == wav.shape
     assert np.abs(wav - np.clip(ref, -1, 1)).max() <= 2.0 / 32768
+
+
+def test_evaluate_driver_matches_oracle(tmp_path):
+    """evaluate.py (eval.py's on-graph loop): clip folders -> every 10th window -> batches of 16 -> metrics file + means."""
+    import torch, os
+    assert torch.cuda.is_available()
+    ensure_lib()
+    from test_feeder import make_clip
+    from spatialaudiogen_amd import feeder as F
+    from spatialaudiogen_amd.evaluate import evaluate, METRIC_KEYS
+    from spatialaudiogen_amd.deploy import audio_window
+    enc = ['audio']
+    P = init_weights(variable_specs(enc), seed=9, mode='test')
+    db = tmp_path / 'db'; db.mkdir()
+    model_dir = tmp_path / 'model'; model_dir.mkdir()
+    clips = {}
+    for i, name in enumerate(['clipA', 'clipB']):
+        make_clip(str(db / name), secs=3, seed=20 + i)
+        clips[name] = np.concatenate([F.load_wav(os.path.join(str(db / name), 'ambix', '%06d.wav' % k))[0] for k in range(3)], 0)
+    (tmp_path / 'layouts.txt').write_text('clipA WXYZ\nclipB WXY\n')
+    means, count = evaluate(str(model_dir), str(db), None, str(tmp_path / 'layouts.txt'), variables=P, params=Params(enc))
+    assert count == 4                                                # 20 windows per clip, every 10th -> 2 per clip
+    lines = open(str(model_dir / 'eval-detailed.txt')).read().splitlines()
+    assert lines[0] == 'SampleID | ' + ' '.join(METRIC_KEYS) and len(lines) == 5 and lines[1].startswith('clipA 0.5 |')
+
+    # oracle: same 4 windows, zero-padded to the batch of 16
+    amb = np.zeros((16, 52799, 4)); masks = np.ones((16, 4))
+    k = 0
+    for name in ('clipA', 'clipB'):
+        for t in (0.5, 1.5):
+            amb[k] = audio_window(clips[name], t, 1.0, 52799, 48000)
+            if name == 'clipB':
+                masks[k] = [1, 1, 0, 1]
+            k += 1
+    pred = O.SptAudioGenOracle(encoders=enc).inference_ops(amb[:, :, :1], P)
+    target = amb[:, 24000:28800, 1:]
+    _, stft_ps, lsd_ps, mse_ps, snr_ps = O.evaluation_ops(pred, target, masks[:, 1:])
+    ref = {'mse/avg': np.mean(mse_ps[:4] * 5e3), 'stft/avg': np.mean(stft_ps[:4] * 100.), 'lsd/avg': np.mean(lsd_ps[:4]),
+           'snr/avg': np.mean(snr_ps[:4]), 'stft/Z': np.mean(stft_ps[:4, 1] * 100.), 'amplitude/gt': np.mean(np.abs(target[:4]).max(axis=(1, 2)))}
+    for key, v in ref.items():
+        assert abs(means[key] - v) <= 2e-3 * max(1.0, abs(v)), (key, means[key], v)

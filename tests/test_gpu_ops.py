@@ -228,3 +228,27 @@ def test_assemble_wyzx_is_bit_exact(T):
     out = ops.assemble_wyzx(dev(T, audio), dev(T, yzx)).cpu().numpy()
     assert np.array_equal(out[:, :, 0], audio[:, 24000:28800])           # W = mono crop (deploy.py:149)
     assert np.array_equal(out[:, :, 1:], yzx)                            # then Y, Z, X (ACN 1,2,3)
+
+
+@pytest.mark.parametrize('B', [3, 16])
+def test_evaluation_metrics(T, B):
+    """SptAudioGen.evaluation_ops (model.py:110-154) on device vs the oracle's FFT-based restatement, including the
+    channel masks of the WXY-only videos (feeder.py:312-314)."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    r = rng(B)
+    gt = 0.3 * r.normal(size=(B, 4800, 3))
+    n = np.arange(4800)[None, :, None]
+    gt = gt + 0.2 * np.sin(2 * np.pi * r.uniform(200, 4000, size=(B, 1, 3)) * n / 48000.)
+    pred = gt * r.uniform(0.5, 1.1, size=(B, 1, 3)) + 0.05 * r.normal(size=gt.shape)
+    pred[0] = 0.0                                                    # silent prediction: exercises the EPS terms
+    mask = np.ones((B, 3)); mask[1, 1] = 0.0; mask[2, 1] = 0.0       # WXY layout: no Z
+    ref_m, ref_stft, ref_lsd, ref_mse, ref_snr = O.evaluation_ops(pred, gt, mask)
+    net = SptAudioGen(1, encoders=['audio'], separation='unet_mask')
+    m, stft_ps, lsd_ps, mse_ps, snr_ps = net.evaluation_ops(dev(T, pred), dev(T, gt), None, dev(T, mask))
+    assert rel_rms_err(stft_ps.cpu().numpy(), ref_stft) < 1e-5
+    assert rel_rms_err(mse_ps.cpu().numpy(), ref_mse) < 1e-5
+    assert np.abs(snr_ps.cpu().numpy() - ref_snr).max() < 1e-3
+    assert np.abs(lsd_ps.cpu().numpy() - ref_lsd).max() < 2e-3 * max(1.0, np.abs(ref_lsd).max())
+    assert list(m.keys()) == list(ref_m.keys())
+    for k in ref_m:
+        assert abs(m[k] - ref_m[k]) <= 2e-3 * max(1.0, abs(ref_m[k])), (k, m[k], ref_m[k])
