@@ -74,7 +74,7 @@ class Evaluator(object):
         S = [x.cpu().numpy() for x in (mse_ps, stft_ps, lsd_ps, snr_ps)]
         for i in range(n):
             row = [per[i, 0], per[i, 1]]
-            for arr, scale in zip(S, (5e3, 100., 1., 1.)):                       # eval.py:155-171 (raw per-sample values)
+            for arr in S:                       # eval.py:155-171 appends the RAW per-sample values (no x5e3 / x100)
                 v = arr[i]
                 row += [float(np.mean(v)), float(v[2]), float(v[0]), float(v[1])]   # avg, X, Y, Z  (channels are Y,Z,X)
             self.rows.append(row)

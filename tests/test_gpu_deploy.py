@@ -120,7 +120,8 @@ def test_evaluate_driver_matches_oracle(tmp_path):
     pred = O.SptAudioGenOracle(encoders=enc).inference_ops(amb[:, :, :1], P)
     target = amb[:, 24000:28800, 1:]
     _, stft_ps, lsd_ps, mse_ps, snr_ps = O.evaluation_ops(pred, target, masks[:, 1:])
-    ref = {'mse/avg': np.mean(mse_ps[:4] * 5e3), 'stft/avg': np.mean(stft_ps[:4] * 100.), 'lsd/avg': np.mean(lsd_ps[:4]),
-           'snr/avg': np.mean(snr_ps[:4]), 'stft/Z': np.mean(stft_ps[:4, 1] * 100.), 'amplitude/gt': np.mean(np.abs(target[:4]).max(axis=(1, 2)))}
+    # eval.py:155-171 logs the raw per-sample values (the x5e3 / x100 scalings exist only in the on-graph summaries)
+    ref = {'mse/avg': np.mean(mse_ps[:4]), 'stft/avg': np.mean(stft_ps[:4]), 'lsd/avg': np.mean(lsd_ps[:4]),
+           'snr/avg': np.mean(snr_ps[:4]), 'stft/Z': np.mean(stft_ps[:4, 1]), 'amplitude/gt': np.mean(np.abs(target[:4]).max(axis=(1, 2)))}
     for key, v in ref.items():
-        assert abs(means[key] - v) <= 2e-3 * max(1.0, abs(v)), (key, means[key], v)
+        assert abs(means[key] - v) <= 2e-3 * max(1e-3, abs(v)) + 1e-6, (key, means[key], v)
