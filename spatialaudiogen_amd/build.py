@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libsagen_hip.so')
-SOURCES = ['igemm.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip']
+SOURCES = ['igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'kernels.h'),
            os.path.join(HERE, '..', 'include', 'sagen.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

@@ -25,49 +25,12 @@
 //    after the LDS read (padding stays exactly zero through the per-row masks).
 //  * epilogue: bias / ReLU, depth-to-space scatter (transposed convs), per-channel (sum, sumsq)
 //    accumulated with fp64 atomics for batch-norm, or raw split-K partials.
-#include "kernels.h"
+#include "igemm_common.h"
 #include <cstdlib>
 
 namespace sagen {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int MAX_TAPS = 128;
-constexpr unsigned OOB = 0x80000000u;
-constexpr int MAX_BN_C = 512;
-
-struct RowInfo {        // per output-grid row of the tile, shared through LDS
-    unsigned boff;      // byte offset of x[b, a*in_sh, bb*in_sw, 0] (mod 2^32)
-    unsigned nmlo, nmhi;  // INVERTED tap-validity mask (bit t set = tap t reads padding / row invalid)
-    int hrem, wrem;     // valid depth-to-space extents
-    int pad;
-    long rowoff;        // element offset of the output pixel
-};
-
-// one LDS-DMA instruction: 64 lanes x 16 B, global (buffer, bounds-checked) -> LDS at `lds` + lane*16.
-// (kept out of the kernel template: the builtin silently blocks host-side stub instantiation otherwise)
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voff, unsigned soff) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SAGEN_ABLATE_DMA)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
-#endif
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// workgroup barrier that does NOT drain the LDS-DMA queue (hipcc's __syncthreads() would emit vmcnt(0))
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
+// (row tables, DMA helpers and the epilogue live in igemm_common.h)
 
 template <int BM, int BN, int WM, int WN, int STG, int BK>
 __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK == 32 ? 2 : 3) : (BK == 32 ? 3 : 4)))) void igemm_kernel(const IgemmDesc d) {
@@ -113,55 +76,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK 
     const int z = blockIdx.z;
     const bool uni = d.uniform_taps != 0;
 
-    // ---- per-row geometry, once per workgroup ----
-    const int HgWg = d.Hg * d.Wg;
-    if (!uni)
-        for (int t = tid; t < d.ntaps; t += 256) {
-            const int th = t / d.TW;
-            s_tapb[t] = (((th * d.tap_sh + d.tap_h0) * d.Win + ((t - th * d.TW) * d.tap_sw + d.tap_w0)) * d.ldx) * 4;
-        }
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        RowInfo ri;
-        ri.boff = 0; ri.nmlo = 0xffffffffu; ri.nmhi = 0xffffffffu; ri.hrem = 0; ri.wrem = 0; ri.pad = 0; ri.rowoff = 0;
-        if (m < d.M) {
-            const int b = m / HgWg;
-            const int rem = m - b * HgWg;
-            const int ia = rem / d.Wg;
-            const int a = d.g_h0 + ia, bb = d.g_w0 + (rem - ia * d.Wg);
-            const int hi0 = a * d.in_sh, wi0 = bb * d.in_sw;
-            ri.boff = (unsigned)(((long)b * d.x_bstride + ((long)hi0 * d.Win + wi0) * d.ldx) * 4);
-            ri.rowoff = (long)b * d.y_bstride + (long)(a * d.dsh) * d.y_rstride + (long)(bb * d.dsw) * d.ldy;
-            ri.hrem = d.Hlim - a * d.dsh;
-            ri.wrem = d.Wlim - bb * d.dsw;
-            if (d.no_bounds) {
-                ri.nmlo = 0; ri.nmhi = 0;
-            } else {
-                unsigned lo = 0, hi = 0;
-                for (int t = 0; t < d.ntaps; ++t) {
-                    const int th = t / d.TW;
-                    const int hh = hi0 + th * d.tap_sh + d.tap_h0, ww = wi0 + (t - th * d.TW) * d.tap_sw + d.tap_w0;
-                    const unsigned bad = ((unsigned)hh < (unsigned)d.Hin && (unsigned)ww < (unsigned)d.Win) ? 0u : 1u;
-                    if (t < 32) lo |= bad << t; else hi |= bad << (t - 32);
-                }
-                ri.nmlo = lo; ri.nmhi = hi;
-            }
-        }
-        s_row[r] = ri;
-    }
-    if (d.bn_in.acc != nullptr) {          // producer's batch statistics -> scale / shift (replaces a finalize launch)
-        for (int ch = tid; ch < d.Cin; ch += 256) {
-            const double mean = d.bn_in.acc[ch] * d.bn_in.inv_count;
-            double var = d.bn_in.acc[d.Cin + ch] * d.bn_in.inv_count - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            const double sc = (double)d.bn_in.gamma[ch] / sqrt(var + (double)d.bn_in.eps);
-            s_bn[0][ch] = (float)sc;
-            s_bn[1][ch] = (float)((double)d.bn_in.beta[ch] - mean * sc);
-        }
-    } else if (d.in_scale != nullptr) {
-        for (int ch = tid; ch < d.Cin; ch += 256) { s_bn[0][ch] = d.in_scale[ch]; s_bn[1][ch] = d.in_shift[ch]; }
-    }
-    __syncthreads();
+    igemm_setup<BM>(d, m0, tid, uni, s_row, s_tapb, s_bn);
 
     // ---- LDS-DMA loader state ----
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.x, 0, d.x_bytes, 0x00020000);
@@ -239,11 +154,15 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK 
                 const unsigned word = i_hi ? a_nmhi[g] : a_nmlo[g];
                 unsigned bad = (word >> i_bit) & 1u;
                 if (!uni) bad |= (i_kok ^ 1u);
+#ifndef SAGEN_ABLATE_A
                 dma16(x_rsrc, st + inst * RPI * BK, (a_voff[g] + i_tb) | (bad << 31), 0);
+#endif
             }
         } else {
             const int inst = wave + 4 * (g - A_PW);
+#ifndef SAGEN_ABLATE_B
             if (EVEN || inst < B_DMA) dma16(w_rsrc, st + (BM + inst * RPI) * BK, b_voff[g - A_PW], i_kbyte);
+#endif
         }
     };
 
@@ -341,7 +260,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK 
 #ifndef SAGEN_ABLATE_MFMA
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
 #else
-                            acc[i][j][0] += a * b;          // keeps the fragment reads alive
+                            asm volatile("" ::"v"(a), "v"(b));       // keeps the fragment reads alive, no instructions
 #endif
                             const int idx = (((hf * 2 + u) * 4 + r) * MT + i) * NT + j;          // 0 .. NMFMA-1
                             // after MFMA idx, issue DMA g when idx == (g+1)*NMFMA/(PER+1) - 1
@@ -363,74 +282,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK 
         stage = stage + 1 == STAGES ? 0 : stage + 1;
     }
 
-    // ---------------- epilogue ----------------
-    // C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int dswC = d.dsw * d.Cout;
-    const bool to_ws = d.splitk_ws != nullptr;     // raw partials for the split-K / replicate reduce
-    float csum[NT], csq[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        csum[j] = 0.f;
-        csq[j] = 0.f;
-        const int n = n0 + wn * WN + j * 32 + li;
-        const bool nok = n < d.N;
-        int ry = 0, rx = 0, o = n;
-        if (d.dsh * d.dsw > 1) {
-            ry = n / dswC;
-            const int rem = n - ry * dswC;
-            rx = rem / d.Cout;
-            o = rem - rx * d.Cout;
-        }
-        const long coloff = (long)ry * d.y_rstride + (long)rx * d.ldy + o;
-        const float bias = (d.bias && nok && !to_ws) ? d.bias[o] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                const int m = m0 + row;
-                float v = acc[i][j][e];
-                if (to_ws) {
-                    if (nok && m < d.M) d.splitk_ws[((long)z * d.M + m) * d.N + n] = v;
-                } else {
-                    const bool ok = nok && ry < s_row[row].hrem && rx < s_row[row].wrem;
-                    if (ok) {
-                        csum[j] += v;
-                        csq[j] += v * v;
-                        v += bias;
-                        if (d.relu_out) v = fmaxf(v, 0.f);
-                        d.y[s_row[row].rowoff + coloff] = v;
-                    }
-                }
-            }
-        }
-    }
-    if (d.stats != nullptr) {
-        // per-tile per-channel partial sums of the raw conv output (pre-bias; BN convs have none)
-        __syncthreads();                       // (the K loop already ended with a barrier; kept for clarity)
-        float* red = smem;                     // [2][WAVES_M][BN]
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float s = csum[j] + __shfl_xor(csum[j], 32);
-            float q = csq[j] + __shfl_xor(csq[j], 32);
-            if (kk == 0) {
-                const int col = wn * WN + j * 32 + li;
-                red[(0 * WAVES_M + wm) * BN + col] = s;
-                red[(1 * WAVES_M + wm) * BN + col] = q;
-            }
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * BN; t += 256) {
-            const int which = t / BN, col = t - which * BN;
-            const int n = n0 + col;
-            if (n < d.N) {
-                float s = 0.f;
-#pragma unroll
-                for (int w2 = 0; w2 < WAVES_M; ++w2) s += red[(which * WAVES_M + w2) * BN + col];
-                atomicAdd(&d.stats[(long)which * d.N + n], (double)s);      // fp64 accumulator [2][N], zeroed per forward
-            }
-        }
-    }
+    igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
 }
 
 template <int BM, int BN, int WM, int WN, int STG, int BK>
@@ -441,7 +293,7 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn, bk; const char* name; };
+struct TileCfg { int bm, bn, bk; const char* name; bool split = false; };
 static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
     {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
@@ -454,7 +306,13 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {64, 64, 32, "igemm_kernel<64,64,32,32,2,32>"},     {64, 128, 32, "igemm_kernel<64,128,32,64,2,32>"},
     {128, 64, 32, "igemm_kernel<128,64,64,32,2,32>"},   {128, 128, 32, "igemm_kernel<128,128,64,64,2,32>"},
     {32, 128, 32, "igemm_kernel<32,128,32,32,2,32>"},   {128, 32, 32, "igemm_kernel<128,32,32,32,2,32>"},
+    // fp32-equivalent bf16x3 kernels (igemm3.hip)
+    {128, 128, 16, "igemm3_kernel<128,128,64,64>", true}, {128, 64, 16, "igemm3_kernel<128,64,64,32>", true},
+    {256, 64, 16, "igemm3_kernel<256,64,64,64>", true},   {64, 64, 16, "igemm3_kernel<64,64,32,32>", true},
+    {64, 128, 16, "igemm3_kernel<64,128,32,64>", true},   {64, 256, 16, "igemm3_kernel<64,256,64,64>", true},
+    {32, 128, 16, "igemm3_kernel<32,128,32,32>", true},   {128, 32, 16, "igemm3_kernel<128,32,32,32>", true},
 };
+bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].split; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
 static int tile_bn(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bn : 0; }
 int igemm_tile_bm(IgemmTile t) { return tile_bm(t); }
@@ -469,6 +327,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     if (t < 0 || t >= TILE_AUTO) return false;
     const int bk = kTiles[t].bk;
     if (d.Kpad % bk) return false;
+    if (kTiles[t].split && !d.w_split) return false;
     if ((d.in_scale || d.bn_in.acc) && !uniform_taps_for(d, bk)) return false;
     return true;
 }
@@ -511,7 +370,7 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     {   // 32-bit buffer addressing + exact host-side bounds analysis of the taps
         const int nb = d.M / (d.Hg * d.Wg) + (d.M % (d.Hg * d.Wg) ? 1 : 0);
         const long xb = (long)nb * d.x_bstride * 4, wb = (long)d.N * d.Kpad * 4;
-        if (xb >= (1L << 31) || wb >= (1L << 31))
+        if (xb >= (1L << 31) || wb >= (1L << 31) || (d.w_split && wb / 2 * 3 >= (1L << 31)))
             return fail(SAGEN_ERR_UNSUPPORTED, "igemm: operand of %ld bytes exceeds 2 GiB buffer addressing (use a smaller batch)", xb > wb ? xb : wb);
         d.x_bytes = (unsigned)xb;
         d.w_bytes = (unsigned)wb;
@@ -532,6 +391,7 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
+    if (kTiles[tile].split) return igemm3_dispatch(d, tile, s);
     switch (tile) {
         case TILE_128x128: return launch_cfg<128, 128, 64, 64, 3, 16>(d, s);
         case TILE_128x64: return launch_cfg<128, 64, 64, 32, 3, 16>(d, s);

@@ -1,0 +1,184 @@
+// Pieces shared by the contraction kernels (igemm.hip: exact fp32 MFMA; igemm3.hip: fp32-equivalent bf16x3 MFMA):
+// per-row geometry tables, batch-norm coefficient setup, LDS-DMA helpers and the output epilogue.
+#pragma once
+#include "kernels.h"
+
+namespace sagen {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MAX_TAPS = 128;
+constexpr unsigned OOB = 0x80000000u;
+constexpr int MAX_BN_C = 512;
+
+struct RowInfo {        // per output-grid row of the tile, shared through LDS
+    unsigned boff;      // byte offset of x[b, a*in_sh, bb*in_sw, 0] (mod 2^32)
+    unsigned nmlo, nmhi;  // INVERTED tap-validity mask (bit t set = tap t reads padding / row invalid)
+    int hrem, wrem;     // valid depth-to-space extents
+    int pad;
+    long rowoff;        // element offset of the output pixel
+};
+
+// one LDS-DMA instruction: 64 lanes x 16 B, global (buffer, bounds-checked) -> LDS at `lds` + lane*16.
+// (kept out of the kernel template: the builtin silently blocks host-side stub instantiation otherwise)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SAGEN_ABLATE_DMA)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// workgroup barrier that does NOT drain the LDS-DMA queue (hipcc's __syncthreads() would emit vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+
+// ---- per-row geometry + tap table + producer batch-norm coefficients, once per workgroup (ends with a barrier) ----
+template <int BM>
+__device__ __forceinline__ void igemm_setup(const IgemmDesc& d, int m0, int tid, bool uni, RowInfo* s_row, int* s_tapb,
+                                            float (*s_bn)[MAX_BN_C]) {
+    // ---- per-row geometry, once per workgroup ----
+    const int HgWg = d.Hg * d.Wg;
+    if (!uni)
+        for (int t = tid; t < d.ntaps; t += 256) {
+            const int th = t / d.TW;
+            s_tapb[t] = (((th * d.tap_sh + d.tap_h0) * d.Win + ((t - th * d.TW) * d.tap_sw + d.tap_w0)) * d.ldx) * 4;
+        }
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        RowInfo ri;
+        ri.boff = 0; ri.nmlo = 0xffffffffu; ri.nmhi = 0xffffffffu; ri.hrem = 0; ri.wrem = 0; ri.pad = 0; ri.rowoff = 0;
+        if (m < d.M) {
+            const int b = m / HgWg;
+            const int rem = m - b * HgWg;
+            const int ia = rem / d.Wg;
+            const int a = d.g_h0 + ia, bb = d.g_w0 + (rem - ia * d.Wg);
+            const int hi0 = a * d.in_sh, wi0 = bb * d.in_sw;
+            ri.boff = (unsigned)(((long)b * d.x_bstride + ((long)hi0 * d.Win + wi0) * d.ldx) * 4);
+            ri.rowoff = (long)b * d.y_bstride + (long)(a * d.dsh) * d.y_rstride + (long)(bb * d.dsw) * d.ldy;
+            ri.hrem = d.Hlim - a * d.dsh;
+            ri.wrem = d.Wlim - bb * d.dsw;
+            if (d.no_bounds) {
+                ri.nmlo = 0; ri.nmhi = 0;
+            } else {
+                unsigned lo = 0, hi = 0;
+                for (int t = 0; t < d.ntaps; ++t) {
+                    const int th = t / d.TW;
+                    const int hh = hi0 + th * d.tap_sh + d.tap_h0, ww = wi0 + (t - th * d.TW) * d.tap_sw + d.tap_w0;
+                    const unsigned bad = ((unsigned)hh < (unsigned)d.Hin && (unsigned)ww < (unsigned)d.Win) ? 0u : 1u;
+                    if (t < 32) lo |= bad << t; else hi |= bad << (t - 32);
+                }
+                ri.nmlo = lo; ri.nmhi = hi;
+            }
+        }
+        s_row[r] = ri;
+    }
+    if (d.bn_in.acc != nullptr) {          // producer's batch statistics -> scale / shift (replaces a finalize launch)
+        for (int ch = tid; ch < d.Cin; ch += 256) {
+            const double mean = d.bn_in.acc[ch] * d.bn_in.inv_count;
+            double var = d.bn_in.acc[d.Cin + ch] * d.bn_in.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double sc = (double)d.bn_in.gamma[ch] / sqrt(var + (double)d.bn_in.eps);
+            s_bn[0][ch] = (float)sc;
+            s_bn[1][ch] = (float)((double)d.bn_in.beta[ch] - mean * sc);
+        }
+    } else if (d.in_scale != nullptr) {
+        for (int ch = tid; ch < d.Cin; ch += 256) { s_bn[0][ch] = d.in_scale[ch]; s_bn[1][ch] = d.in_shift[ch]; }
+    }
+    __syncthreads();
+
+}
+
+// ---- epilogue: bias / ReLU / depth-to-space scatter, split-K partials, batch-norm statistics ----
+// acc: MFMA 32x32 C/D layout per (i, j) sub-tile; `red` = scratch of >= 2 * (BM / WM) * BN floats (the tile ring)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)[WM / 32][WN / 32], const RowInfo* s_row,
+                                               float* red, int m0, int n0, int z, int tid) {
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, kk = lane >> 5;
+    // ---------------- epilogue ----------------
+    // C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int dswC = d.dsw * d.Cout;
+    const bool to_ws = d.splitk_ws != nullptr;     // raw partials for the split-K / replicate reduce
+    float csum[NT], csq[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        csum[j] = 0.f;
+        csq[j] = 0.f;
+        const int n = n0 + wn * WN + j * 32 + li;
+        const bool nok = n < d.N;
+        int ry = 0, rx = 0, o = n;
+        if (d.dsh * d.dsw > 1) {
+            ry = n / dswC;
+            const int rem = n - ry * dswC;
+            rx = rem / d.Cout;
+            o = rem - rx * d.Cout;
+        }
+        const long coloff = (long)ry * d.y_rstride + (long)rx * d.ldy + o;
+        const float bias = (d.bias && nok && !to_ws) ? d.bias[o] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                const int m = m0 + row;
+                float v = acc[i][j][e];
+                if (to_ws) {
+                    if (nok && m < d.M) d.splitk_ws[((long)z * d.M + m) * d.N + n] = v;
+                } else {
+                    const bool ok = nok && ry < s_row[row].hrem && rx < s_row[row].wrem;
+                    if (ok) {
+                        csum[j] += v;
+                        csq[j] += v * v;
+                        v += bias;
+                        if (d.relu_out) v = fmaxf(v, 0.f);
+                        d.y[s_row[row].rowoff + coloff] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (d.stats != nullptr) {
+        // per-tile per-channel partial sums of the raw conv output (pre-bias; BN convs have none)
+        __syncthreads();                       // (the K loop already ended with a barrier; kept for clarity)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32);
+            float q = csq[j] + __shfl_xor(csq[j], 32);
+            if (kk == 0) {
+                const int col = wn * WN + j * 32 + li;
+                red[(0 * WAVES_M + wm) * BN + col] = s;
+                red[(1 * WAVES_M + wm) * BN + col] = q;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int which = t / BN, col = t - which * BN;
+            const int n = n0 + col;
+            if (n < d.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WAVES_M; ++w2) s += red[(which * WAVES_M + w2) * BN + col];
+                atomicAdd(&d.stats[(long)which * d.N + n], (double)s);      // fp64 accumulator [2][N], zeroed per forward
+            }
+        }
+    }
+}
+
+}  // namespace sagen

@@ -26,7 +26,8 @@ struct BnRef {
 
 struct IgemmDesc {
     const float* x = nullptr;         // input, channel offset already applied
-    const float* w = nullptr;         // packed filter [Npad][Kpad], k contiguous, zero padded
+    const float* w = nullptr;         // packed filter [N][Kpad], k contiguous, zero padded
+    int w_split = 0;                  // 1: the bf16x3 planes, tiled [Kpad/16][3][N][16] (pack_split_launch), follow the fp32 filter at w + N*Kpad
     float* y = nullptr;               // output, channel / row offset already applied
     const float* bias = nullptr;      // [Cout] or null
     const float* in_scale = nullptr;  // [Cin] or null
@@ -70,6 +71,9 @@ enum IgemmTile {
     TILE_64x128, TILE_64x128_S2, TILE_64x256, TILE_64x256_S2, TILE_256x32,
     // K tile of 32 (half the barriers per MFMA; needs Kpad % 32 == 0)
     TILE_64x64_K32, TILE_64x128_K32, TILE_128x64_K32, TILE_128x128_K32, TILE_32x128_K32, TILE_128x32_K32,
+    // fp32-equivalent bf16x3 operand split on the bf16 matrix cores (needs IgemmDesc::w_split)
+    TILE_B3_128x128, TILE_B3_128x64, TILE_B3_256x64, TILE_B3_64x64, TILE_B3_64x128, TILE_B3_64x256, TILE_B3_32x128,
+    TILE_B3_128x32,
     TILE_AUTO
 };
 
@@ -80,6 +84,8 @@ const char* igemm_tile_name(IgemmTile t);
 int igemm_tile_bm(IgemmTile t);
 int igemm_tile_bn(IgemmTile t);
 int igemm_tile_bk(IgemmTile t);
+bool igemm_tile_split(IgemmTile t);                   // bf16x3 variant (igemm3.hip)?
+int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // launch only; igemm_launch validates
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the
 // per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)
@@ -91,6 +97,9 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
 // conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src)
 int pack_conv_launch(const float* w_hwio, int ntaps, int cin_src, int cin_pad, int cout,
                      float* wp, int Npad, int Kpad, hipStream_t s);
+// appends the bf16x3 planes of a packed filter: wp must have room for N*Kpad floats + 3*N*Kpad bf16
+int pack_split_launch(float* wp, int N, int Kpad, hipStream_t s);
+inline size_t packed_split_floats(size_t n_fp32) { return n_fp32 + (3 * n_fp32 + 1) / 2; }
 // deconv as depth-to-space conv: n = (ry, rx, o), k = (dp, dq, c);
 // Wp[n][k] = W[ry + sh*dp][rx + sw*dq][o][c] (0 when outside the kh x kw kernel)
 int pack_deconv_launch(const float* w_hwoi, int kh, int kw, int cout, int cin, int sh, int sw,

@@ -59,6 +59,7 @@ struct sagen_ctx {
     std::map<std::string, Choice> plan;
     std::map<std::string, bool> materialize;     // conv_2 layers: apply the producer's BN+ReLU in a separate pass?
     bool tuning = false;
+    bool fp32_only = false;                      // SAGEN_FP32_ONLY=1: never use the bf16x3 tiles
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
     hipStream_t aux = nullptr;
@@ -180,6 +181,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         if (cfg->loc_units[i] <= 0 || cfg->loc_units[i] % 4) return fail(SAGEN_ERR_UNSUPPORTED, "loc_units[%d]=%d must be a positive multiple of 4", i, cfg->loc_units[i]);
 
     sagen_ctx* c = new sagen_ctx();
+
+    c->fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
@@ -261,7 +264,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         } else {
             n = packed_floats(vs.shape[1], vs.shape[0]);
         }
-        c->alloc("pk:" + vs.name, n);
+        c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
     }
     // activations
     c->alloc("mag", (size_t)B * 127 * 1024);
@@ -353,14 +356,17 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
             const int N = sh * sw * (int)vs.shape[2], K = taps * (int)vs.shape[3];
             rc = pack_deconv_launch(src, (int)vs.shape[0], (int)vs.shape[1], (int)vs.shape[2], (int)vs.shape[3], sh, sw, dst,
                                     N, (K + 15) / 16 * 16, s);
+            if (!rc) rc = pack_split_launch(dst, N, (K + 15) / 16 * 16, s);
         } else if (vs.ndim == 4) {
             int cin = (int)vs.shape[2], cinp = cin == 3 ? 4 : cin, taps = (int)(vs.shape[0] * vs.shape[1]);
             if (cin == 1) { cin = cinp = (int)vs.shape[1]; taps = (int)vs.shape[0]; }
             const int K = taps * cinp;
             rc = pack_conv_launch(src, taps, cin, cinp, (int)vs.shape[3], dst, (int)vs.shape[3], (K + 15) / 16 * 16, s);
+            if (!rc) rc = pack_split_launch(dst, (int)vs.shape[3], (K + 15) / 16 * 16, s);
         } else {
             const int K = (int)vs.shape[0], N = (int)vs.shape[1];
             rc = pack_conv_launch(src, 1, K, K, N, dst, N, (K + 15) / 16 * 16, s);
+            if (!rc) rc = pack_split_launch(dst, N, (K + 15) / 16 * 16, s);
         }
         if (rc) return rc;
     }
@@ -474,8 +480,10 @@ struct Fwd {
         return best;
     }
 
-    int contract(const IgemmDesc& d, int rep = 1, bool allow_split = true) {
+    int contract(const IgemmDesc& d_in, int rep = 1, bool allow_split = true) {
         if (rc) return 0;
+        IgemmDesc d = d_in;
+        d.w_split = c->fp32_only ? 0 : 1;          // every bound filter carries its bf16x3 planes
         if (rep > 1 && !dense_out(d)) { rc = fail(SAGEN_ERR_UNSUPPORTED, "replicated store needs a dense plain epilogue"); return 0; }
         Choice ch;
         auto it = c->plan.find(layer);

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 csrc = os.path.join(ROOT, 'spatialaudiogen_amd', 'csrc')
-srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'elementwise.hip', 'fft.hip', 'model.hip', 'api.hip')]
+srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip')]
 extra = '/tmp/ablate_entry.hip'
 open(extra, 'w').write('''
 #include "%s/kernels.h"
@@ -20,7 +20,10 @@ extern "C" int sagen_dbg_conv(const float* x, const float* wp, float* y, int B, 
 }
 ''' % csrc)
 libs = {}
-for name, flag in (('full', []), ('no_dma', ['-DSAGEN_ABLATE_DMA']), ('no_mfma', ['-DSAGEN_ABLATE_MFMA'])):
+VARIANTS = (('full', []), ('no_dma', ['-DSAGEN_ABLATE_DMA']), ('no_mfma', ['-DSAGEN_ABLATE_MFMA']),
+            ('A_only', ['-DSAGEN_ABLATE_MFMA', '-DSAGEN_ABLATE_B']), ('B_only', ['-DSAGEN_ABLATE_MFMA', '-DSAGEN_ABLATE_A']),
+            ('mfma+A', ['-DSAGEN_ABLATE_B']), ('mfma+B', ['-DSAGEN_ABLATE_A']))
+for name, flag in VARIANTS:
     out = '/tmp/libsagen_%s.so' % name
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared'] + flag + srcs + [extra, '-o', out])
     libs[name] = C.CDLL(out)
@@ -34,7 +37,7 @@ fl = 2.0 * B * H * W * N * 9 * Cc
 names = ['128x128', '128x64', '256x64', '64x64', '128x32', '32x128', '128x128s2', '128x64s2', '256x64s2', '64x64s2', '64x128', '64x128s2', '64x256', '64x256s2', '256x32']
 for t in tiles:
     res = []
-    for name in ('full', 'no_dma', 'no_mfma'):
+    for name, _ in VARIANTS:
         lib = libs[name]
         for _ in range(3):
             assert lib.sagen_dbg_conv(p(x), p(wp), p(y), B, H, W, Cc, N, t, None) == 0
@@ -45,4 +48,4 @@ for t in tiles:
             e0.record(); lib.sagen_dbg_conv(p(x), p(wp), p(y), B, H, W, Cc, N, t, None); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         res.append(np.median(ts))
-    print('tile %-10s full %7.1f us (%.1f TF)   no_dma %7.1f us (%.1f TF-equiv)   no_mfma %7.1f us' % (names[t], res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[2]), flush=True)
+    print('tile %-10s ' % (names[t] if t < len(names) else t) + '  '.join('%s %6.1f' % (n, r) for (n, _), r in zip(VARIANTS, res)) + '  us  (full = %.1f TF)' % (fl / res[0] / 1e6), flush=True)

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 csrc = os.path.join(ROOT, 'spatialaudiogen_amd', 'csrc')
 out = '/tmp/libsagen_trace.so'
-srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'elementwise.hip', 'fft.hip', 'model.hip', 'api.hip')]
+srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip')]
 extra = os.path.join('/tmp', 'trace_entry.hip')
 open(extra, 'w').write('''
 #include "%s/kernels.h"
@@ -19,16 +19,19 @@ extern "C" int sagen_trace_conv(const float* x, const float* wp, float* y, float
     d.x_bstride = (long)H * W * C; d.ntaps = 9; d.TW = 3; d.tap_h0 = -1; d.tap_w0 = -1; d.log2Cin = ilog2_exact(C);
     d.Cout = C; d.Hlim = H; d.Wlim = W; d.ldy = C; d.y_rstride = (long)W * C; d.y_bstride = (long)H * W * C;
     d.trace = trace; d.trace_block = block;
+    if (igemm_tile_split((IgemmTile)tile)) { d.w_split = 1; int rc = pack_split_launch((float*)wp, d.N, d.Kpad, (hipStream_t)stream); if (rc) return rc; }
     return igemm_launch(d, (IgemmTile)tile, (hipStream_t)stream);
 }
 ''' % csrc)
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSAGEN_TRACE'] + srcs + [extra, '-o', out]
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSAGEN_TRACE'] + os.environ.get('EXTRA_FLAGS', '').split() + srcs + [extra, '-o', out]
 subprocess.check_call(cmd)
 lib = C.CDLL(out)
-B, H, W, Cc = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 64, 128, 64
+# usage: trace_phases.py B tile block [H W C]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-x = torch.randn(B, H, W, Cc, device='cuda'); wp = torch.randn(Cc, 9 * Cc, device='cuda') * 0.05
+H, W, Cc = [int(v) for v in sys.argv[4:7]] if len(sys.argv) > 6 else (64, 128, 64)
+x = torch.randn(B, H, W, Cc, device='cuda'); wp = torch.randn(3 * Cc, 9 * Cc, device='cuda') * 0.05    # room for the bf16x3 planes
 y = torch.empty(B, H, W, Cc, device='cuda'); stats = torch.zeros(1 << 20, device='cuda')
 trace = torch.zeros(4 * 64 * 8, dtype=torch.int64, device='cuda')
 p = lambda t: C.c_void_p(t.data_ptr())
@@ -38,7 +41,7 @@ for _ in range(3):
 assert rc == 0, rc
 t = trace.cpu().numpy().reshape(4, 64, 8)
 for w in range(4):
-    tw = t[w, :36, :5].astype(np.int64)
+    nt = min(36, 9 * Cc // 16); tw = t[w, :nt, :5].astype(np.int64)
     print('wave', w, 'total per tile (median):', int(np.median(np.diff(tw[:, 0]))))
     d = np.stack([tw[:, 1] - tw[:, 0], tw[:, 2] - tw[:, 1], tw[:, 3] - tw[:, 2], tw[:, 4] - tw[:, 3]], 1)
     print('   load-issue, ds_read+MFMA, store(+vmcnt wait), barrier : median', np.median(d, 0).astype(int), ' tile 5:', d[5], ' tile 20:', d[20])
