@@ -47,7 +47,8 @@ static int guarded(F&& f) {
     }
 }
 
-static size_t pk_bytes(long N, long K) { return align_up((size_t)N * ((K + 15) / 16 * 16) * sizeof(float), 256); }
+// packed fp32 filter + its bf16x3 planes (igemm3.hip)
+static size_t pk_bytes(long N, long K) { return align_up(packed_split_floats((size_t)N * ((K + 15) / 16 * 16)) * sizeof(float), 256); }
 
 }  // namespace sagen
 
@@ -180,7 +181,9 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
             d.K = kh * kw * cin; d.Kpad = (d.K + 15) / 16 * 16;
             rc = pack_conv_launch(w_hwio, kh * kw, cin, cin, cout, wp, cout, d.Kpad, s);
         }
+        if (!rc) rc = pack_split_launch(wp, cout, d.Kpad, s);
         if (rc) return rc;
+        d.w_split = 1;
         if (bn_stats) SAGEN_HIP_CHECK(hipMemsetAsync(bn_stats, 0, (size_t)2 * cout * sizeof(double), s));
         return igemm_launch(d, TILE_AUTO, s);
     });
@@ -270,7 +273,9 @@ int sagen_deconv2d(const float* x, int batch, int h, int w, int cin, const float
         d.dsh = sh; d.dsw = sw; d.Cout = cout; d.Hlim = Hout; d.Wlim = Wout;
         d.ldy = cout; d.y_rstride = (long)Wout * cout; d.y_bstride = (long)Hout * Wout * cout;
         int rc = pack_deconv_launch(w_hwoi, kh, kw, cout, cin, sh, sw, (float*)scratch, d.N, d.Kpad, s);
+        if (!rc) rc = pack_split_launch((float*)scratch, d.N, d.Kpad, s);
         if (rc) return rc;
+        d.w_split = 1;
         return igemm_launch(d, TILE_AUTO, s);
     });
 }

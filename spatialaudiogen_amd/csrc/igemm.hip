@@ -307,10 +307,13 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 32, "igemm_kernel<128,64,64,32,2,32>"},   {128, 128, 32, "igemm_kernel<128,128,64,64,2,32>"},
     {32, 128, 32, "igemm_kernel<32,128,32,32,2,32>"},   {128, 32, 32, "igemm_kernel<128,32,32,32,2,32>"},
     // fp32-equivalent bf16x3 kernels (igemm3.hip)
-    {128, 128, 16, "igemm3_kernel<128,128,64,64>", true}, {128, 64, 16, "igemm3_kernel<128,64,64,32>", true},
-    {256, 64, 16, "igemm3_kernel<256,64,64,64>", true},   {64, 64, 16, "igemm3_kernel<64,64,32,32>", true},
-    {64, 128, 16, "igemm3_kernel<64,128,32,64>", true},   {64, 256, 16, "igemm3_kernel<64,256,64,64>", true},
-    {32, 128, 16, "igemm3_kernel<32,128,32,32>", true},   {128, 32, 16, "igemm3_kernel<128,32,32,32>", true},
+    {128, 128, 16, "igemm3_kernel<128,128,64,64,1>", true}, {128, 64, 16, "igemm3_kernel<128,64,64,32,1>", true},
+    {256, 64, 16, "igemm3_kernel<256,64,64,64,1>", true},   {64, 64, 16, "igemm3_kernel<64,64,32,32,1>", true},
+    {64, 128, 16, "igemm3_kernel<64,128,32,64,1>", true},   {64, 256, 16, "igemm3_kernel<64,256,64,64,1>", true},
+    {32, 128, 16, "igemm3_kernel<32,128,32,32,1>", true},   {128, 32, 16, "igemm3_kernel<128,32,32,32,1>", true},
+    {128, 64, 16, "igemm3_kernel<128,64,64,32,2>", true},   {64, 64, 16, "igemm3_kernel<64,64,32,32,2>", true},
+    {64, 128, 16, "igemm3_kernel<64,128,32,64,2>", true},   {32, 128, 16, "igemm3_kernel<32,128,32,32,2>", true},
+    {128, 32, 16, "igemm3_kernel<128,32,32,32,2>", true},
 };
 bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].split; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
@@ -335,10 +338,19 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
 IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: IgemmTile index
     if (force && d.M > 128 && d.N >= 64) return (IgemmTile)atoi(force);
-    if (d.M <= 32) return TILE_32x128;
-    if (d.N <= 32) return TILE_128x32;
+    static const bool fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
     auto blocks = [&](IgemmTile t) { return (long)cdiv(d.M, tile_bm(t)) * cdiv(d.N, tile_bn(t)) * d.splitk; };
     const long want = 2 * 256;                 // >= 2 workgroups per CU
+    if (d.w_split && !fp32_only) {             // the bf16x3 kernels are the faster family wherever their planes exist
+        if (d.M <= 32) return TILE_B3_32x128;
+        if (d.N <= 32) return TILE_B3_128x32;
+        if (d.N <= 64) return blocks(TILE_B3_128x64) >= want ? TILE_B3_128x64 : TILE_B3_64x64;
+        if (blocks(TILE_B3_128x128) >= 256 + 128) return TILE_B3_128x128;
+        if (blocks(TILE_B3_64x128) >= want) return TILE_B3_64x128_K2;
+        return TILE_B3_64x64_K2;
+    }
+    if (d.M <= 32) return TILE_32x128;
+    if (d.N <= 32) return TILE_128x32;
     if (d.N <= 64) {
         if (blocks(TILE_256x64) >= want) return TILE_256x64;
         if (blocks(TILE_128x64) >= want) return TILE_128x64;

@@ -57,7 +57,9 @@ __device__ __forceinline__ unsigned split_pair(float& a, float& b) {
     return pk;
 }
 
-template <int BM, int BN, int WM, int WN>
+// KS = K tiles of 16 per barrier step (small tiles amortise the barrier and the loop overhead over 2 tiles);
+// PRO = the producer's batch-norm + ReLU is applied to the activations on the way in.
+template <int BM, int BN, int WM, int WN, int KS, bool PRO>
 __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -66,9 +68,9 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
     constexpr int NCH = BM >= 64 ? BM / 64 : 1;        // 16-B activation chunks per thread per K tile (BM*4 chunks / 256 threads)
     constexpr int NBC = (6 * BN + 255) / 256;           // 16-B filter chunks per thread per K tile (3 planes x BN rows x 2)
     constexpr int A_PL = BM * 8, B_PL = BN * 8;         // floats per plane per stage (rows of 32 B)
-    constexpr int STAGE_F = 3 * A_PL + 3 * B_PL;
-    constexpr int NMFMA = 6 * MT * NT;
-    constexpr int NSIDE = NBC + NCH + 3 * NCH + NBC;    // side jobs spread between the MFMAs: loads, converts, stores
+    constexpr int SUB_F = 3 * A_PL + 3 * B_PL;          // one K tile of 16: three A planes + three filter planes
+    constexpr int STAGE_F = KS * SUB_F;
+    constexpr int NJOB = NBC + NBC + NCH + 3 * NCH;     // side jobs per K tile: filter stores / loads, activation loads, convert jobs
 
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_F];
     __shared__ RowInfo s_row[BM];
@@ -135,7 +137,6 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
     const int kc0 = z * nk_per;
     const int kc1 = min(nk, kc0 + nk_per);
     const int ntiles = kc1 - kc0;
-    const bool prologue = d.in_scale != nullptr || d.bn_in.acc != nullptr;
 
     // SGPR tracker of the (tap, channel) position of the next tile to LOAD
     int q_tap = 0, q_th = 0, q_tw = 0, q_c0 = 0;
@@ -145,18 +146,21 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
         else q_c0 = k0;
     }
 
-    // two register sets for the chunks in flight: tile t+1 (landed, converted / stored during step t) sits in set
-    // (t+1)&1 while the loads of tile t+2 fill set t&1
-    f32x4 araw[2][NCH], braw[2][NBC];
-    unsigned abad[2][NCH];
-    int ac0[2] = {0, 0};                              // first channel of the tile in each set (batch-norm coefficients)
+    // two register sets for the chunks in flight: the tiles of step t+1 (landed, converted / stored during step t)
+    // sit in set (t+1)&1 while the loads of step t+2 fill set t&1
+    f32x4 araw[2][KS][NCH], braw[2][KS][NBC];
+    unsigned abad[2][KS][NCH];
+    int ac0[2][KS];                                   // first channel of each tile in flight (batch-norm coefficients)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) { araw[p][c] = f32x4{0.f, 0.f, 0.f, 0.f}; abad[p][c] = 1; }
+        for (int ks = 0; ks < KS; ++ks) {
+            ac0[p][ks] = 0;
 #pragma unroll
-        for (int c = 0; c < NBC; ++c) braw[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+            for (int c = 0; c < NCH; ++c) { araw[p][ks][c] = f32x4{0.f, 0.f, 0.f, 0.f}; abad[p][ks][c] = 1; }
+#pragma unroll
+            for (int c = 0; c < NBC; ++c) braw[p][ks][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     // per-tile load state (wave-uniform in the uniform-tap mode); `past` = 1 for tiles beyond this split's range
     unsigned i_tb = 0, i_bit = 0, i_kok = 1, i_past = 0, i_kbyte = 0;
@@ -204,11 +208,11 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
     };
     // conversion of one activation chunk in three jobs (one bf16 plane each): [batch-norm + ReLU], split level,
     // ds_write_b64.  cv[c] carries the running fp32 residuals between the jobs.
-    float cv[NCH][4];
-    auto convert_job = [&](int c, int level, const f32x4& src, unsigned bad, int c0, float* st) {
+    float cv[KS][NCH][4];
+    auto convert_job = [&](int ks, int c, int level, const f32x4& src, unsigned bad, int c0, float* st) {
         if (level == 0) {
             f32x4 v = src;
-            if (prologue) {
+            if (PRO) {
                 const int cc = c0 + 4 * kc4;
                 const float4 sc = *reinterpret_cast<const float4*>(&s_bn[0][cc]);
                 const float4 sh = *reinterpret_cast<const float4*>(&s_bn[1][cc]);
@@ -218,11 +222,11 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
                 v[2] = ok ? fmaxf(fmaf(v[2], sc.z, sh.z), 0.f) : 0.f;
                 v[3] = ok ? fmaxf(fmaf(v[3], sc.w, sh.w), 0.f) : 0.f;
             }
-            cv[c][0] = v[0]; cv[c][1] = v[1]; cv[c][2] = v[2]; cv[c][3] = v[3];
+            cv[ks][c][0] = v[0]; cv[ks][c][1] = v[1]; cv[ks][c][2] = v[2]; cv[ks][c][3] = v[3];
         }
         u32x2 pk;
-        pk[0] = split_pair(cv[c][0], cv[c][1]);
-        pk[1] = split_pair(cv[c][2], cv[c][3]);
+        pk[0] = split_pair(cv[ks][c][0], cv[ks][c][1]);
+        pk[1] = split_pair(cv[ks][c][2], cv[ks][c][3]);
         if (a_active) *reinterpret_cast<u32x2*>(st + level * A_PL + a_wofs[c]) = pk;
     };
 
@@ -237,87 +241,123 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
     const int li = lane & 31, kk = lane >> 5;
     const int foff = 4 * (kk ^ ((li >> 3) & 1));          // this lane's 16-B half of a 32-B plane row
 
-    // ---- pipeline fill: tile 0 into LDS stage 0, tile 1 in flight into register set 1 ----
-    begin_load(kc0, ac0[0]);
+    // one side job of K tile `ks` of a step: stores / converts move register set PS into LDS stage `st`, loads fill
+    // register set PL (begin_load for that tile must have run)
+    auto side_job = [&](int job, int ks, auto pl_tag, float* st) {
+        constexpr int PL = decltype(pl_tag)::value, PS = PL ^ 1;
+        float* sub = st + ks * SUB_F;
+        if (job < NBC) store_b(job, braw[PS][ks][job], sub);
+        else if (job < 2 * NBC) load_b(job - NBC, braw[PL][ks][job - NBC]);
+        else if (job < 2 * NBC + NCH) load_a(job - 2 * NBC, araw[PL][ks][job - 2 * NBC], abad[PL][ks][job - 2 * NBC]);
+        else {
+            const int cj = job - 2 * NBC - NCH, c = cj / 3;
+            convert_job(ks, c, cj - 3 * c, araw[PS][ks][c], abad[PS][ks][c], ac0[PS][ks], sub);
+        }
+    };
+
+#ifdef SAGEN_TRACE
+    unsigned long long* trc = (d.trace && tile_m == d.trace_block && blockIdx.y == 0) ? (unsigned long long*)d.trace + (size_t)wave * 64 * 8 : nullptr;
+#define TRC3(ph) do { if (trc && lane == 0 && t < 64) trc[t * 8 + (ph)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRC3(ph) do { } while (0)
+#endif
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // the six products: hh, hm, mh, hl, lh, mm
+    const int nsteps = (ntiles + KS - 1) / KS;
+    // ---- pipeline fill: step 0 into LDS stage 0, step 1 in flight into register set 1 ----
 #pragma unroll
-    for (int c = 0; c < NBC; ++c) load_b(c, braw[0][c]);
+    for (int ks = 0; ks < KS; ++ks) {
+        begin_load(kc0 + ks, ac0[0][ks]);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) load_a(c, araw[0][c], abad[0][c]);
-    begin_load(kc0 + 1, ac0[1]);
+        for (int c = 0; c < NBC; ++c) load_b(c, braw[0][ks][c]);
 #pragma unroll
-    for (int c = 0; c < NBC; ++c) load_b(c, braw[1][c]);
+        for (int c = 0; c < NCH; ++c) load_a(c, araw[0][ks][c], abad[0][ks][c]);
+    }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) load_a(c, araw[1][c], abad[1][c]);
+    for (int ks = 0; ks < KS; ++ks) {
+        begin_load(kc0 + KS + ks, ac0[1][ks]);
 #pragma unroll
-    for (int c = 0; c < NBC; ++c) store_b(c, braw[0][c], smem);
+        for (int c = 0; c < NBC; ++c) load_b(c, braw[1][ks][c]);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < NCH; ++c) load_a(c, araw[1][ks][c], abad[1][ks][c]);
+    }
 #pragma unroll
-        for (int lv = 0; lv < 3; ++lv) convert_job(c, lv, araw[0][c], abad[0][c], ac0[0], smem);
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int c = 0; c < NBC; ++c) store_b(c, braw[0][ks][c], smem + ks * SUB_F);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int lv = 0; lv < 3; ++lv) convert_job(ks, c, lv, araw[0][ks][c], abad[0][ks][c], ac0[0][ks], smem + ks * SUB_F);
+    }
     lds_barrier();
 
-    // one K tile; P = t & 1 (compile time): consume LDS stage P, fill stage P^1 from register set P^1, load into set P
+    // one step; P = step & 1 (compile time): consume LDS stage P, fill stage P^1 from register set P^1, load into set P
     auto step = [&](auto parity, int t) {
         constexpr int P = decltype(parity)::value;
         const float* cur = smem + P * STAGE_F;
         float* nxt = smem + (P ^ 1) * STAGE_F;
-        begin_load(kc0 + t + 2, ac0[P]);
-
-        bf16x8 aq[3][MT], bq[3][NT];
+            TRC3(0);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int ks = 0; ks < KS; ++ks) {
+            begin_load(kc0 + (t + 2) * KS + ks, ac0[P][ks]);
+            bf16x8 aq[3][MT], bq[3][NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                aq[pl][i] = *reinterpret_cast<const bf16x8*>(cur + pl * A_PL + (wm * WM + i * 32 + li) * 8 + foff);
+            for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bq[pl][j] = *reinterpret_cast<const bf16x8*>(cur + 3 * A_PL + pl * B_PL + (wn * WN + j * 32 + li) * 8 + foff);
-        }
-        // six products, smallest first; side jobs in between: loads of tile t+2, convert / store of tile t+1
-        constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+                for (int i = 0; i < MT; ++i)
+                    aq[pl][i] = *reinterpret_cast<const bf16x8*>(cur + ks * SUB_F + pl * A_PL + (wm * WM + i * 32 + li) * 8 + foff);
 #pragma unroll
-        for (int tt = 0; tt < 6; ++tt)
+                for (int j = 0; j < NT; ++j)
+                    bq[pl][j] = *reinterpret_cast<const bf16x8*>(cur + ks * SUB_F + 3 * A_PL + pl * B_PL + (wn * WN + j * 32 + li) * 8 + foff);
+            }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
 #ifndef SAGEN_ABLATE_MFMA
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[TA[tt]][i], bq[TB[tt]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[TA[tt]][i], bq[TB[tt]][j], acc[i][j], 0, 0, 0);
 #else
-                    asm volatile("" ::"v"(aq[TA[tt]][i]), "v"(bq[TB[tt]][j]));
+                        asm volatile("" ::"v"(aq[TA[tt]][i]), "v"(bq[TB[tt]][j]));
 #endif
-                    const int idx = (tt * MT + i) * NT + j;
+                        // side jobs of this K tile, spread over its MFMAs
+                        constexpr int NM1 = 6 * MT * NT;
+                        const int idx = (tt * MT + i) * NT + j;
 #pragma unroll
-                    for (int g = 0; g < NSIDE; ++g)
-                        if (idx == (g * NMFMA / NSIDE < NMFMA ? g * NMFMA / NSIDE : NMFMA - 1)) {
-                            if (g < NBC) store_b(g, braw[P ^ 1][g], nxt);                       // tile t+1 (landed long ago)
-                            else if (g < 2 * NBC) load_b(g - NBC, braw[P][g - NBC]);             // tile t+2
-                            else if (g < 2 * NBC + NCH) load_a(g - 2 * NBC, araw[P][g - 2 * NBC], abad[P][g - 2 * NBC]);
-                            else {
-                                const int job = g - 2 * NBC - NCH, c = job / 3;
-                                convert_job(c, job - 3 * c, araw[P ^ 1][c], abad[P ^ 1][c], ac0[P ^ 1], nxt);
-                            }
-                        }
-                }
+                        for (int g = 0; g < NJOB; ++g)
+                            if (idx == (g * NM1 / NJOB < NM1 ? g * NM1 / NJOB : NM1 - 1)) side_job(g, ks, std::integral_constant<int, P>{}, nxt);
+#ifdef SAGEN_TRACE
+                        if (ks == 0 && idx == 0) TRC3(1);
+                        if (ks == KS - 1 && idx == NM1 - 1) TRC3(2);
+#endif
+                    }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TRC3(3);
         lds_barrier();
+        TRC3(4);
     };
-    for (int t = 0; t < ntiles; t += 2) {
+    for (int t = 0; t < nsteps; t += 2) {
         step(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntiles) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 1 < nsteps) step(std::integral_constant<int, 1>{}, t + 1);
     }
 
     igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KS, bool PRO>
 __global__ __launch_bounds__(256, 2) void igemm3_kernel(const IgemmDesc d) {
-    igemm3_body<BM, BN, WM, WN>(d);
+    igemm3_body<BM, BN, WM, WN, KS, PRO>(d);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KS>
 static int launch_cfg3(const IgemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
-    hipLaunchKernelGGL((igemm3_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
+    if (d.in_scale != nullptr || d.bn_in.acc != nullptr)
+        hipLaunchKernelGGL((igemm3_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(256), 0, s, d);
+    else
+        hipLaunchKernelGGL((igemm3_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -325,14 +365,19 @@ static int launch_cfg3(const IgemmDesc& d, hipStream_t s) {
 // called by igemm_launch (igemm.hip) after the shared validation
 int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s) {
     switch (tile) {
-        case TILE_B3_128x128: return launch_cfg3<128, 128, 64, 64>(d, s);
-        case TILE_B3_128x64: return launch_cfg3<128, 64, 64, 32>(d, s);
-        case TILE_B3_256x64: return launch_cfg3<256, 64, 64, 64>(d, s);
-        case TILE_B3_64x64: return launch_cfg3<64, 64, 32, 32>(d, s);
-        case TILE_B3_64x128: return launch_cfg3<64, 128, 32, 64>(d, s);
-        case TILE_B3_64x256: return launch_cfg3<64, 256, 64, 64>(d, s);
-        case TILE_B3_32x128: return launch_cfg3<32, 128, 32, 32>(d, s);
-        case TILE_B3_128x32: return launch_cfg3<128, 32, 32, 32>(d, s);
+        case TILE_B3_128x128: return launch_cfg3<128, 128, 64, 64, 1>(d, s);
+        case TILE_B3_128x64: return launch_cfg3<128, 64, 64, 32, 1>(d, s);
+        case TILE_B3_256x64: return launch_cfg3<256, 64, 64, 64, 1>(d, s);
+        case TILE_B3_64x64: return launch_cfg3<64, 64, 32, 32, 1>(d, s);
+        case TILE_B3_64x128: return launch_cfg3<64, 128, 32, 64, 1>(d, s);
+        case TILE_B3_64x256: return launch_cfg3<64, 256, 64, 64, 1>(d, s);
+        case TILE_B3_32x128: return launch_cfg3<32, 128, 32, 32, 1>(d, s);
+        case TILE_B3_128x32: return launch_cfg3<128, 32, 32, 32, 1>(d, s);
+        case TILE_B3_128x64_K2: return launch_cfg3<128, 64, 64, 32, 2>(d, s);
+        case TILE_B3_64x64_K2: return launch_cfg3<64, 64, 32, 32, 2>(d, s);
+        case TILE_B3_64x128_K2: return launch_cfg3<64, 128, 32, 64, 2>(d, s);
+        case TILE_B3_32x128_K2: return launch_cfg3<32, 128, 32, 32, 2>(d, s);
+        case TILE_B3_128x32_K2: return launch_cfg3<128, 32, 32, 32, 2>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "igemm3: bad tile id %d", (int)tile);
     }
 }

@@ -74,6 +74,8 @@ enum IgemmTile {
     // fp32-equivalent bf16x3 operand split on the bf16 matrix cores (needs IgemmDesc::w_split)
     TILE_B3_128x128, TILE_B3_128x64, TILE_B3_256x64, TILE_B3_64x64, TILE_B3_64x128, TILE_B3_64x256, TILE_B3_32x128,
     TILE_B3_128x32,
+    // ... with two K tiles of 16 per barrier step
+    TILE_B3_128x64_K2, TILE_B3_64x64_K2, TILE_B3_64x128_K2, TILE_B3_32x128_K2, TILE_B3_128x32_K2,
     TILE_AUTO
 };
 

@@ -279,10 +279,13 @@ class SptAudioGen(object):
                 'igemm_kernel<64,256,64,64,3,16>', 'igemm_kernel<64,256,64,64,2,16>', 'igemm_kernel<256,32,64,32,2,16>',
                 'igemm_kernel<64,64,32,32,2,32>', 'igemm_kernel<64,128,32,64,2,32>', 'igemm_kernel<128,64,64,32,2,32>',
                 'igemm_kernel<128,128,64,64,2,32>', 'igemm_kernel<32,128,32,32,2,32>', 'igemm_kernel<128,32,32,32,2,32>',
-                # fp32-equivalent bf16x3 kernels (csrc/igemm3.hip)
-                'igemm3_kernel<128,128,64,64>', 'igemm3_kernel<128,64,64,32>', 'igemm3_kernel<256,64,64,64>',
-                'igemm3_kernel<64,64,32,32>', 'igemm3_kernel<64,128,32,64>', 'igemm3_kernel<64,256,64,64>',
-                'igemm3_kernel<32,128,32,32>', 'igemm3_kernel<128,32,32,32>']
+                # fp32-equivalent bf16x3 kernels (csrc/igemm3.hip); the last template argument = K tiles per barrier step.
+                # (rocprofv3 appends the batch-norm-prologue flag: ",true>" / ",false>")
+                'igemm3_kernel<128,128,64,64,1>', 'igemm3_kernel<128,64,64,32,1>', 'igemm3_kernel<256,64,64,64,1>',
+                'igemm3_kernel<64,64,32,32,1>', 'igemm3_kernel<64,128,32,64,1>', 'igemm3_kernel<64,256,64,64,1>',
+                'igemm3_kernel<32,128,32,32,1>', 'igemm3_kernel<128,32,32,32,1>', 'igemm3_kernel<128,64,64,32,2>',
+                'igemm3_kernel<64,64,32,32,2>', 'igemm3_kernel<64,128,32,64,2>', 'igemm3_kernel<32,128,32,32,2>',
+                'igemm3_kernel<128,32,32,32,2>']
 
     def plan(self, batch):
         buf = C.create_string_buffer(1 << 16)

@@ -16,11 +16,12 @@ extern "C" int sagen_dbg_conv(const float* x, const float* wp, float* y, int B, 
     d.M = B * H * W; d.N = N; d.K = 9 * C; d.Kpad = d.K; d.Hg = H; d.Wg = W; d.Hin = H; d.Win = W; d.Cin = C; d.ldx = C;
     d.x_bstride = (long)H * W * C; d.ntaps = 9; d.TW = 3; d.tap_h0 = -1; d.tap_w0 = -1; d.log2Cin = ilog2_exact(C);
     d.Cout = N; d.Hlim = H; d.Wlim = W; d.ldy = N; d.y_rstride = (long)W * N; d.y_bstride = (long)H * W * N;
+    if (igemm_tile_split((IgemmTile)tile)) { d.w_split = 1; static int packed = 0; if (!packed) { packed = 1; int rc = pack_split_launch((float*)wp, d.N, d.Kpad, (hipStream_t)stream); if (rc) return rc; } }
     return igemm_launch(d, (IgemmTile)tile, (hipStream_t)stream);
 }
 ''' % csrc)
 libs = {}
-VARIANTS = (('full', []), ('no_dma', ['-DSAGEN_ABLATE_DMA']), ('no_mfma', ['-DSAGEN_ABLATE_MFMA']),
+VARIANTS = (('full', []), ('no_dma', ['-DSAGEN_ABLATE_DMA', '-DSAGEN_ABLATE_A', '-DSAGEN_ABLATE_B']), ('no_mfma', ['-DSAGEN_ABLATE_MFMA']),
             ('A_only', ['-DSAGEN_ABLATE_MFMA', '-DSAGEN_ABLATE_B']), ('B_only', ['-DSAGEN_ABLATE_MFMA', '-DSAGEN_ABLATE_A']),
             ('mfma+A', ['-DSAGEN_ABLATE_B']), ('mfma+B', ['-DSAGEN_ABLATE_A']))
 for name, flag in VARIANTS:
@@ -30,7 +31,7 @@ for name, flag in VARIANTS:
 B, H, W, Cc = [int(v) for v in sys.argv[1:5]]
 N = Cc
 tiles = [int(v) for v in sys.argv[5:]]
-x = torch.randn(B, H, W, Cc, device='cuda'); wp = torch.randn(N, 9 * Cc, device='cuda') * 0.05
+x = torch.randn(B, H, W, Cc, device='cuda'); wp = torch.randn(3 * N, 9 * Cc, device='cuda') * 0.05   # room for the bf16x3 planes
 y = torch.empty(B, H, W, N, device='cuda')
 p = lambda t: C.c_void_p(t.data_ptr())
 fl = 2.0 * B * H * W * N * 9 * Cc

@@ -49,9 +49,19 @@ for k, v in keep.items():
 json.dump(traffic, open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1, sort_keys=True)
 # bench.py reads profiles/pmc_traffic.json keyed by the runtime's kernel label
 label = {}
+wsum = collections.defaultdict(lambda: [0.0, 0.0])
 for k, v in traffic.items():
     if k.startswith('igemm_kernel<'):
         label[k.replace(' ', '')] = round(v['hbm_bytes_fetch_x2'])
+    elif k.startswith('igemm3_kernel<'):
+        # the runtime labels the bf16x3 kernels without their last template argument (batch-norm prologue flag):
+        # launch-weighted mean over the two instantiations
+        base = k.replace(' ', '').rsplit(',', 1)[0] + '>'
+        n = keep[k].get('launches_fetch', 1)
+        wsum[base][0] += v['hbm_bytes_fetch_x2'] * n
+        wsum[base][1] += n
+for base, (tot, n) in wsum.items():
+    label[base] = round(tot / n)
 json.dump(label, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 b = os.path.join(src, 'bench_under_trace.json')
 if os.path.exists(b):

@@ -44,4 +44,4 @@ for w in range(4):
     nt = min(36, 9 * Cc // 16); tw = t[w, :nt, :5].astype(np.int64)
     print('wave', w, 'total per tile (median):', int(np.median(np.diff(tw[:, 0]))))
     d = np.stack([tw[:, 1] - tw[:, 0], tw[:, 2] - tw[:, 1], tw[:, 3] - tw[:, 2], tw[:, 4] - tw[:, 3]], 1)
-    print('   load-issue, ds_read+MFMA, store(+vmcnt wait), barrier : median', np.median(d, 0).astype(int), ' tile 5:', d[5], ' tile 20:', d[20])
+    print('   [igemm: load-issue, ds_read+MFMA, vmcnt wait, barrier | igemm3: frag reads->1st MFMA, MFMAs+jobs, LDS drain, barrier] median', np.median(d, 0).astype(int), ' tile 5:', d[5], ' tile 20:', d[20])
