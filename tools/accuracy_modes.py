@@ -1,0 +1,26 @@
+"""Dev helper (GPU box): end-to-end error of the HIP path against the fp64 oracle, in the default arithmetic (bf16x3
+contractions) and with SAGEN_FP32_ONLY=1 (exact fp32 MFMA).  Prints one JSON line per (mode, encoders, seed)."""
+import sys, os, json, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == 'child':
+    import numpy as np, torch
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    from spatialaudiogen_amd.model import SptAudioGen
+    from oracle.np_oracle import SptAudioGenOracle
+    mode = 'fp32_only' if os.environ.get('SAGEN_FP32_ONLY') else 'bf16x3'
+    for enc in (['audio'], ['audio', 'video'], ['audio', 'video', 'flow']):
+        for seed in (0, 1):
+            P = init_weights(variable_specs(enc), seed=seed, mode='test')
+            inp = synth_inputs(4, enc, seed=100 + seed)
+            ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp.get('video'), flow=inp.get('flow'))
+            net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+            net.load_variables(P)
+            out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow')).cpu().numpy().astype(np.float64)
+            err = float(np.sqrt(np.mean((out - ref) ** 2))); rms = float(np.sqrt(np.mean(ref ** 2)))
+            print(json.dumps({'mode': mode, 'encoders': '+'.join(e[0].upper() for e in enc), 'seed': seed, 'rms_err': err,
+                              'out_rms': rms, 'rel': err / rms, 'max_abs_err': float(np.abs(out - ref).max())}), flush=True)
+else:
+    for env in ({}, {'SAGEN_FP32_ONLY': '1'}):
+        e = dict(os.environ); e.update(env)
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), 'child'], env=e)
