@@ -293,7 +293,7 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn, bk; const char* name; bool split = false; };
+struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; };
 static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
     {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
@@ -314,7 +314,18 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 16, "igemm3_kernel<128,64,64,32,2>", true},   {64, 64, 16, "igemm3_kernel<64,64,32,32,2>", true},
     {64, 128, 16, "igemm3_kernel<64,128,32,64,2>", true},   {32, 128, 16, "igemm3_kernel<32,128,32,32,2>", true},
     {128, 32, 16, "igemm3_kernel<128,32,32,32,2>", true},
+    {128, 128, 16, "igemm3dw_kernel<128,128,64,64,false>", true, true}, {128, 64, 16, "igemm3dw_kernel<128,64,64,32,false>", true, true},
+    {256, 64, 16, "igemm3dw_kernel<256,64,64,64,false>", true, true},   {64, 128, 16, "igemm3dw_kernel<64,128,32,64,false>", true, true},
+    {64, 64, 16, "igemm3dw_kernel<64,64,32,32,false>", true, true},     {64, 256, 16, "igemm3dw_kernel<64,256,64,64,false>", true, true},
+    {128, 64, 16, "igemm3dw_kernel<128,64,64,32,true>", true, true},    {256, 64, 16, "igemm3dw_kernel<256,64,64,64,true>", true, true},
+    {64, 64, 16, "igemm3dw_kernel<64,64,32,32,true>", true, true},      {64, 128, 16, "igemm3dw_kernel<64,128,32,64,true>", true, true},
 };
+// igemm3dw_kernel: dense 3x3 stride-1 SAME conv whose output pixel q reads input pixels q + dh*W + dw
+static bool dw3_ok(const IgemmDesc& d) {
+    return d.ntaps == 9 && d.TW == 3 && d.tap_sh == 1 && d.tap_sw == 1 && d.tap_h0 == -1 && d.tap_w0 == -1 && d.in_sh == 1 &&
+           d.in_sw == 1 && d.dsh * d.dsw == 1 && d.Hin == d.Hg && d.Win == d.Wg && d.g_h0 == 0 && d.g_w0 == 0 && d.Cin % 16 == 0 &&
+           d.K == 9 * d.Cin && d.Kpad == d.K && d.x_bstride == (long)d.Hin * d.Win * d.ldx && d.Hin >= 2 && d.Win >= 2;
+}
 bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].split; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
 static int tile_bn(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bn : 0; }
@@ -331,6 +342,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     const int bk = kTiles[t].bk;
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
+    if (kTiles[t].dw3 && !dw3_ok(d)) return false;
     if ((d.in_scale || d.bn_in.acc) && !uniform_taps_for(d, bk)) return false;
     return true;
 }
@@ -448,7 +460,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int i = 0; i < V; ++i) v[i] = 0.f;
     const long MN = (long)M * N;
     const float* p = ws + (long)m * N + n;
-    for (int zz = 0; zz < splitk; ++zz, p += MN) {
+    int zz = 0;
+    if (V == 4)
+        for (; zz + 4 <= splitk; zz += 4, p += 4 * MN) {          // four partials in flight
+            const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + MN);
+            const float4 t2 = *reinterpret_cast<const float4*>(p + 2 * MN), t3 = *reinterpret_cast<const float4*>(p + 3 * MN);
+            v[0] += (t0.x + t1.x) + (t2.x + t3.x); v[1 % V] += (t0.y + t1.y) + (t2.y + t3.y);
+            v[2 % V] += (t0.z + t1.z) + (t2.z + t3.z); v[3 % V] += (t0.w + t1.w) + (t2.w + t3.w);
+        }
+    for (; zz < splitk; ++zz, p += MN) {
         if (V == 4) {
             const float4 t = *reinterpret_cast<const float4*>(p);
             v[0] += t.x; v[1 % V] += t.y; v[2 % V] += t.z; v[3 % V] += t.w;
@@ -473,21 +493,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // (t / CN4) + i*(256 / CN4) of its row block; grid (row blocks, column blocks of 4*CN4).
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ ws, int splitk, int M, int N,
                                                                   float* __restrict__ y, int ldy, double* __restrict__ stats,
-                                                                  int CN4) {
+                                                                  int CN4, int RB) {
     __shared__ float4 red[2][256];
     const int tid = threadIdx.x;
     const int cl = tid % CN4, rl = tid / CN4, RL = 256 / CN4;
     const int n = (blockIdx.y * CN4 + cl) * 4;
-    const int r0 = blockIdx.x * SPLITK_RB;
+    const int r0 = blockIdx.x * RB;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     const long MN = (long)M * N;
     if (n < N) {
-        for (int r = rl; r < SPLITK_RB; r += RL) {
+        for (int r = rl; r < RB; r += RL) {
             const int m = r0 + r;
             if (m >= M) break;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const float* p = ws + (long)m * N + n;
-            for (int zz = 0; zz < splitk; ++zz, p += MN) {
+            int zz = 0;
+            for (; zz + 4 <= splitk; zz += 4, p += 4 * MN) {      // four partials in flight (a serial loop is latency-bound)
+                const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + MN);
+                const float4 t2 = *reinterpret_cast<const float4*>(p + 2 * MN), t3 = *reinterpret_cast<const float4*>(p + 3 * MN);
+                v.x += (t0.x + t1.x) + (t2.x + t3.x); v.y += (t0.y + t1.y) + (t2.y + t3.y);
+                v.z += (t0.z + t1.z) + (t2.z + t3.z); v.w += (t0.w + t1.w) + (t2.w + t3.w);
+            }
+            for (; zz < splitk; ++zz, p += MN) {
                 const float4 t = *reinterpret_cast<const float4*>(p);
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
@@ -518,8 +545,12 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
         if (N % 4 || ldy % 4 || rep != 1 || bias || relu)
             return fail(SAGEN_ERR_UNSUPPORTED, "split-K reduce with statistics needs N %% 4 == 0 and a plain epilogue");
         const int CN4 = N >= 256 ? 64 : (N >= 128 ? 32 : 16);         // 256 / 128 / 64 columns per workgroup
-        dim3 grid(cdiv(M, SPLITK_RB), cdiv(N, CN4 * 4));
-        hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, s, ws, splitk, M, N, y, ldy, stats, CN4);
+        // rows per workgroup: fatter workgroups for big M (fewer fp64 atomics), never fewer than ~2 workgroups per CU
+        const int ncb = cdiv(N, CN4 * 4);
+        int RB = SPLITK_RB;
+        while (RB < 128 && (long)cdiv(M, 2 * RB) * ncb >= 512) RB *= 2;
+        dim3 grid(cdiv(M, RB), ncb);
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, s, ws, splitk, M, N, y, ldy, stats, CN4, RB);
     } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0)) {
         hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, s, ws, splitk, M, N, bias,
                            relu, y, ldy, rep);

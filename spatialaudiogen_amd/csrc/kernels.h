@@ -76,6 +76,10 @@ enum IgemmTile {
     TILE_B3_128x32,
     // ... with two K tiles of 16 per barrier step
     TILE_B3_128x64_K2, TILE_B3_64x64_K2, TILE_B3_64x128_K2, TILE_B3_32x128_K2, TILE_B3_128x32_K2,
+    // bf16x3 for dense 3x3 stride-1 SAME convs: the three horizontal taps share one activation tile (igemm3dw_kernel)
+    TILE_B3DW_128x128, TILE_B3DW_128x64, TILE_B3DW_256x64, TILE_B3DW_64x128, TILE_B3DW_64x64, TILE_B3DW_64x256,
+    // ... the three taps also share one barrier step (narrow N)
+    TILE_B3DWM_128x64, TILE_B3DWM_256x64, TILE_B3DWM_64x64, TILE_B3DWM_64x128,
     TILE_AUTO
 };
 

@@ -285,7 +285,13 @@ class SptAudioGen(object):
                 'igemm3_kernel<64,64,32,32,1>', 'igemm3_kernel<64,128,32,64,1>', 'igemm3_kernel<64,256,64,64,1>',
                 'igemm3_kernel<32,128,32,32,1>', 'igemm3_kernel<128,32,32,32,1>', 'igemm3_kernel<128,64,64,32,2>',
                 'igemm3_kernel<64,64,32,32,2>', 'igemm3_kernel<64,128,32,64,2>', 'igemm3_kernel<32,128,32,32,2>',
-                'igemm3_kernel<128,32,32,32,2>']
+                'igemm3_kernel<128,32,32,32,2>',
+                # bf16x3, dense 3x3 stride-1 convs only: the three horizontal taps share one activation tile
+                # (last argument: do the three taps also share one barrier step?)
+                'igemm3dw_kernel<128,128,64,64,false>', 'igemm3dw_kernel<128,64,64,32,false>', 'igemm3dw_kernel<256,64,64,64,false>',
+                'igemm3dw_kernel<64,128,32,64,false>', 'igemm3dw_kernel<64,64,32,32,false>', 'igemm3dw_kernel<64,256,64,64,false>',
+                'igemm3dw_kernel<128,64,64,32,true>', 'igemm3dw_kernel<256,64,64,64,true>', 'igemm3dw_kernel<64,64,32,32,true>',
+                'igemm3dw_kernel<64,128,32,64,true>']
 
     def plan(self, batch):
         buf = C.create_string_buffer(1 << 16)

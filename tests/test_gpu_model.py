@@ -164,7 +164,9 @@ def test_autotuned_plan_keeps_parity(T):
 @pytest.mark.parametrize('tile,splitk', [(0, 2), (1, 3), (2, 1), (3, 4), (0, 1), (4, 1), (5, 2), (6, 1), (7, 2), (8, 1),
                                          (9, 3), (10, 1), (11, 2), (12, 1), (13, 2), (14, 1), (15, 1), (16, 2), (17, 1), (18, 2), (19, 3), (20, 1),
                                          # bf16x3 (fp32-equivalent split) tiles
-                                         (21, 1), (22, 2), (23, 1), (24, 3), (25, 1), (26, 2), (27, 1), (28, 2), (29, 1), (30, 3), (31, 1), (32, 2), (33, 1)])
+                                         (21, 1), (22, 2), (23, 1), (24, 3), (25, 1), (26, 2), (27, 1), (28, 2), (29, 1), (30, 3), (31, 1), (32, 2), (33, 1),
+                                         # bf16x3 with shared horizontal taps (3x3 stride-1 convs; other layers fall back)
+                                         (34, 1), (35, 1), (36, 1), (37, 2), (38, 3), (39, 1), (40, 1), (41, 1), (42, 2), (43, 1)])
 def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     """Pin every batch-norm conv of the trunk (and the dense decoder / FC layers) to one tile shape and split-K
     factor: exercises split-K partials + reduce-with-statistics and each kernel instantiation end to end."""
