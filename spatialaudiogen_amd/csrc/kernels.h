@@ -92,6 +92,7 @@ int igemm_tile_bn(IgemmTile t);
 int igemm_tile_bk(IgemmTile t);
 bool igemm_tile_split(IgemmTile t);                   // bf16x3 variant (igemm3.hip)?
 int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // launch only; igemm_launch validates
+int igemm3dw_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3dw.hip)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the
 // per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)

@@ -769,17 +769,26 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
 
-    // localization (model.py:241-271)
+    // localization (model.py:241-271).  With the mask decoder present the localisation FCs and the deconv chain are
+    // independent consumers of the bottleneck: second fork, the FCs go to the context's stream.
+    static const bool no_fork2 = getenv("SAGEN_NO_FORK2") != nullptr;
+    const bool fork2 = forked && c->freq_mask && !no_fork2;
+    if (fork2) {
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    }
     {
+        Fwd& w = fork2 ? g : f;
         const float* x = bott;
         int K = c->Cb;
         for (int i = 0; i < c->cfg.n_loc_units; ++i) {
             float* y = c->p("loc" + std::to_string(i + 1));
-            f.fc(x, B * 3, K, K, "localization/fc" + std::to_string(i + 1), c->cfg.loc_units[i], true, y, c->cfg.loc_units[i]);
+            w.fc(x, B * 3, K, K, "localization/fc" + std::to_string(i + 1), c->cfg.loc_units[i], true, y, c->cfg.loc_units[i]);
             x = y; K = c->cfg.loc_units[i];
         }
         const int nlast = 3 * (c->nsep + 1);
-        f.fc(x, B * 3, K, K, "localization/fc" + std::to_string(c->cfg.n_loc_units + 1), nlast, false, c->p("coeffs"), nlast);
+        w.fc(x, B * 3, K, K, "localization/fc" + std::to_string(c->cfg.n_loc_units + 1), nlast, false, c->p("coeffs"), nlast);
+        if (g.rc) return g.rc;
     }
 
     if (!c->freq_mask) {
@@ -797,6 +806,10 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     }
     // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16
     f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44);
+    if (fork2) {                                         // the mix needs the localisation coefficients
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
     f.layer = "separation/mask-istft-mix";
     f.timed("mask_istft_kernel+ola_mix_kernel", 0.0, [&] {
         return mask_istft_mix_launch(c->p("dmask"), 23L * 1024 * c->nsep, 1, c->p("spec"), c->p("coeffs"), B, c->nsep, out,
