@@ -324,7 +324,7 @@ static const TileCfg kTiles[TILE_AUTO] = {
 static bool dw3_ok(const IgemmDesc& d) {
     return d.ntaps == 9 && d.TW == 3 && d.tap_sh == 1 && d.tap_sw == 1 && d.tap_h0 == -1 && d.tap_w0 == -1 && d.in_sh == 1 &&
            d.in_sw == 1 && d.dsh * d.dsw == 1 && d.Hin == d.Hg && d.Win == d.Wg && d.g_h0 == 0 && d.g_w0 == 0 && d.Cin % 16 == 0 &&
-           d.K == 9 * d.Cin && d.Kpad == d.K && d.x_bstride == (long)d.Hin * d.Win * d.ldx && d.Hin >= 2 && d.Win >= 2;
+           d.K == 9 * d.Cin && d.Kpad == d.K && d.x_bstride == (long)d.Hin * d.Win * d.ldx && d.Hin >= 2 && d.Win >= 8;
 }
 bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].split; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }

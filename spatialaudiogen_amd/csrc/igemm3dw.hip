@@ -13,8 +13,9 @@ namespace sagen {
 // conv the input pixel of output pixel q under tap (dh, dw) is simply q + dh*W + dw in the flattened [B*H*W] pixel
 // index, so the tile for (dh, channel chunk) is staged ONCE with one halo pixel on either side (BM + 2 rows), and the
 // three dw taps read their fragments from it at row offsets 0 / 1 / 2.  What the flattened shift gets wrong - the
-// pixel left of column 0 and right of column W-1 is padding, not the neighbouring image row - is repaired on the
-// fragments: lanes whose output pixel sits on that image edge zero their A fragments for that tap.
+// pixel left of column 0 and right of column W-1 is padding, not the neighbouring image row - is repaired by the
+// LDS layout: the tile keeps one extra, permanently zero slot between consecutive image rows, so the shifted read of an
+// edge pixel lands on a zero without any per-fragment select.
 // K order: (dh, channel chunk, dw); loads / split work per MFMA drop 3x, the filter side is unchanged.
 // MERGE: the three taps of a group also share ONE barrier step (their three filter tiles are staged together):
 // 3x the MFMAs per barrier - for narrow N, where a single tap is only a few MFMAs per wave.
@@ -25,7 +26,7 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
     static_assert(WAVES_N * WAVES_M == 4 && BM >= 64, "4 waves per workgroup, BM >= 64");
     constexpr int NCH = BM / 64;                        // 16-B activation chunks per thread per tile (+1 halo chunk on wave 0)
     constexpr int NBC = (6 * BN + 255) / 256;
-    constexpr int AR = BM + 8;                          // rows allocated per A plane (BM + 2 used)
+    constexpr int AR = BM + 2 + BM / 8 + 2;             // slots per A plane: BM + 2 pixels + one zero gap per image row (W >= 8)
     constexpr int A_PL = AR * 8, B_PL = BN * 8;         // floats per plane
     constexpr int NTAP = MERGE ? 3 : 1;                 // filter tiles per stage
     constexpr int A_ST = 3 * A_PL, B_ST = NTAP * 3 * B_PL;   // floats per stage
@@ -53,7 +54,8 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
     const int n0 = blockIdx.y * BN;
     const int z = blockIdx.z;
 
-    igemm_setup<BM>(d, m0, tid, true, s_row, s_tapb, s_bn);
+    for (int i = tid; i < 2 * A_ST; i += 256) a_stage[i] = 0.f;      // the gap slots stay zero for the whole kernel
+    igemm_setup<BM>(d, m0, tid, true, s_row, s_tapb, s_bn);          // (ends with a barrier)
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.x, 0, d.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc =
@@ -62,6 +64,9 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
     // ---- activation loader: tile row rho <-> flattened pixel q = m0 - 1 + rho; chunk = 4 channels ----
     const int kc4 = tid & 3;
     const int W = d.Win, H = d.Hin;
+    // slot of flattened pixel q in the tile: its distance from pixel m0-1 plus one gap per image row crossed
+    const int rid0 = (m0 - 1 + W) / W - 1;              // row index (over the whole batch) of pixel m0-1; -1 for pixel -1
+    auto slot_of = [&](int q) { return (q - (m0 - 1)) + ((q + W) / W - 1 - rid0); };
     unsigned a_voff[NCH + 1], a_hbad[NCH + 1];          // byte offset of pixel q (+ chunk), validity bits per dh (-1, 0, +1)
     int a_wofs[NCH + 1];
     const bool halo_lane = tid < 8;                     // wave 0 also loads tile rows BM, BM+1
@@ -76,7 +81,8 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
         }
         a_hbad[c] = bad;
         a_voff[c] = (unsigned)((long)q * d.ldx * 4) + 16u * kc4;
-        a_wofs[c] = rho * 8 + 4 * ((kc4 >> 1) ^ ((rho >> 3) & 1)) + 2 * (kc4 & 1);
+        const int sl = slot_of(q);
+        a_wofs[c] = sl * 8 + 4 * ((kc4 >> 1) ^ ((sl >> 3) & 1)) + 2 * (kc4 & 1);
     }
     // ---- filter loader (as igemm3_body) ----
     unsigned b_voff[NBC];
@@ -192,17 +198,13 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
     const int li = lane & 31, kk = lane >> 5;
     // fragment addressing: output row r = wm*WM + i*32 + li reads tile row r + dwi (dwi = 0, 1, 2)
     int a_foff[3][MT];
-    bool at_left[MT], at_right[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int r = wm * WM + i * 32 + li;
-        const unsigned nm = s_row[r].nmlo;
-        at_left[i] = ((nm >> 3) & 1u) != 0;             // tap (dh 0, dw -1) is padding <=> w == 0 (or the row is past M)
-        at_right[i] = ((nm >> 5) & 1u) != 0;            // tap (dh 0, dw +1) is padding <=> w == W - 1
+        const int sc = slot_of(m0 + wm * WM + i * 32 + li);          // slot of the centre tap
 #pragma unroll
         for (int dwi = 0; dwi < 3; ++dwi) {
-            const int rho = r + dwi;
-            a_foff[dwi][i] = rho * 8 + 4 * (kk ^ ((rho >> 3) & 1));
+            const int sl = sc + dwi - 1;
+            a_foff[dwi][i] = sl * 8 + 4 * (kk ^ ((sl >> 3) & 1));
         }
     }
     const int b_foff = (wn * WN + li) * 8 + 4 * (kk ^ ((li >> 3) & 1));
@@ -254,18 +256,6 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         bq[pl][j] = *reinterpret_cast<const bf16x8*>(bcur + (dwi * 3 + pl) * B_PL + j * 32 * 8 + b_foff);
-                }
-                if (dwi != 1) {                           // image-edge repair
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const bool kill = dwi == 0 ? at_left[i] : at_right[i];
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
-                            u32x4 u = __builtin_bit_cast(u32x4, aq[pl][i]);
-                            u[0] = kill ? 0u : u[0]; u[1] = kill ? 0u : u[1]; u[2] = kill ? 0u : u[2]; u[3] = kill ? 0u : u[3];
-                            aq[pl][i] = __builtin_bit_cast(bf16x8, u);
-                        }
-                    }
                 }
 #pragma unroll
                 for (int tt = 0; tt < 6; ++tt)
@@ -339,18 +329,6 @@ __device__ __forceinline__ void igemm3dw_body(const IgemmDesc& d) {
                 }
     #pragma unroll
                 for (int j = 0; j < NT; ++j) bq[pl][j] = *reinterpret_cast<const bf16x8*>(bcur + pl * B_PL + j * 32 * 8 + b_foff);
-            }
-            if (DWI != 1) {                                  // image-edge repair: that neighbour is padding
-    #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const bool kill = DWI == 0 ? at_left[i] : at_right[i];
-    #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        u32x4 u = __builtin_bit_cast(u32x4, aq[pl][i]);
-                        u[0] = kill ? 0u : u[0]; u[1] = kill ? 0u : u[1]; u[2] = kill ? 0u : u[2]; u[3] = kill ? 0u : u[3];
-                        aq[pl][i] = __builtin_bit_cast(bf16x8, u);
-                    }
-                }
             }
             // side jobs: filter store (step s+1) and load (step s+2) on every step; activations of the NEXT group:
             // loads on tap 0, conversion split over taps 1 and 2
