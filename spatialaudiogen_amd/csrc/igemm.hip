@@ -293,7 +293,7 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; };
+struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; };
 static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
     {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
@@ -319,7 +319,15 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {64, 64, 16, "igemm3dw_kernel<64,64,32,32,false>", true, true},     {64, 256, 16, "igemm3dw_kernel<64,256,64,64,false>", true, true},
     {128, 64, 16, "igemm3dw_kernel<128,64,64,32,true>", true, true},    {256, 64, 16, "igemm3dw_kernel<256,64,64,64,true>", true, true},
     {64, 64, 16, "igemm3dw_kernel<64,64,32,32,true>", true, true},      {64, 128, 16, "igemm3dw_kernel<64,128,32,64,true>", true, true},
+    {256, 64, 16, "igemm3s2_kernel<256,64,64,64>", true, false, true},  {128, 64, 16, "igemm3s2_kernel<128,64,64,32>", true, false, true},
 };
+// igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
+static bool s2_ok(const IgemmDesc& d) {
+    return d.Cin == 4 && d.ldx == 4 && d.ntaps == 56 && d.TW == 8 && d.in_sh == 2 && d.in_sw == 2 && d.tap_sh == 1 && d.tap_sw == 1 &&
+           d.tap_h0 == 0 && d.tap_w0 == 0 && d.dsh * d.dsw == 1 && d.g_h0 == 0 && d.g_w0 == 0 && d.K == 224 && d.Kpad == 224 &&
+           d.in_scale == nullptr && d.bn_in.acc == nullptr && d.x_bstride == (long)d.Hin * d.Win * 4 && d.Wg >= 64 &&
+           (d.Wg - 1) * 2 + 8 <= d.Win && (d.Hg - 1) * 2 + 7 <= d.Hin;
+}
 // igemm3dw_kernel: dense 3x3 stride-1 SAME conv whose output pixel q reads input pixels q + dh*W + dw
 static bool dw3_ok(const IgemmDesc& d) {
     return d.ntaps == 9 && d.TW == 3 && d.tap_sh == 1 && d.tap_sw == 1 && d.tap_h0 == -1 && d.tap_w0 == -1 && d.in_sh == 1 &&
@@ -343,6 +351,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
     if (kTiles[t].dw3 && !dw3_ok(d)) return false;
+    if (kTiles[t].s2 && !s2_ok(d)) return false;
     if ((d.in_scale || d.bn_in.acc) && !uniform_taps_for(d, bk)) return false;
     return true;
 }
@@ -415,6 +424,7 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
+    if (kTiles[tile].s2) return igemm3s2_dispatch(d, tile, s);
     if (kTiles[tile].split) return igemm3_dispatch(d, tile, s);
     switch (tile) {
         case TILE_128x128: return launch_cfg<128, 128, 64, 64, 3, 16>(d, s);
@@ -566,23 +576,31 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
 // filter repacking
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, int ntaps, int cin_src, int cin_pad,
-                                                        int cout, float* __restrict__ wp, int Npad, int Kpad) {
+                                                        int cout, float* __restrict__ wp, int Npad, int Kpad, int tw_src,
+                                                        int tw_pad) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Npad * Kpad) return;
     const int n = (int)(idx / Kpad), k = (int)(idx - (long)n * Kpad);
     float v = 0.f;
     if (n < cout && k < ntaps * cin_pad) {
-        const int tap = k / cin_pad, c = k - tap * cin_pad;
-        if (c < cin_src) v = w[((long)tap * cin_src + c) * cout + n];
+        int tap = k / cin_pad;
+        const int c = k - tap * cin_pad;
+        bool ok = c < cin_src;
+        if (tw_pad > 0) {                      // packed tap rows of tw_pad over source rows of tw_src
+            const int th = tap / tw_pad, tw = tap - th * tw_pad;
+            ok = ok && tw < tw_src;
+            tap = th * tw_src + tw;
+        }
+        if (ok) v = w[((long)tap * cin_src + c) * cout + n];
     }
     wp[idx] = v;
 }
 
 int pack_conv_launch(const float* w_hwio, int ntaps, int cin_src, int cin_pad, int cout, float* wp, int Npad,
-                     int Kpad, hipStream_t s) {
+                     int Kpad, hipStream_t s, int tw_src, int tw_pad) {
     const long total = (long)Npad * Kpad;
     hipLaunchKernelGGL(pack_conv_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w_hwio, ntaps, cin_src, cin_pad,
-                       cout, wp, Npad, Kpad);
+                       cout, wp, Npad, Kpad, tw_src, tw_pad);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -80,6 +80,8 @@ enum IgemmTile {
     TILE_B3DW_128x128, TILE_B3DW_128x64, TILE_B3DW_256x64, TILE_B3DW_64x128, TILE_B3DW_64x64, TILE_B3DW_64x256,
     // ... the three taps also share one barrier step (narrow N)
     TILE_B3DWM_128x64, TILE_B3DWM_256x64, TILE_B3DWM_64x64, TILE_B3DWM_64x128,
+    // bf16x3 for the 7x7 stride-2 stem over the padded 4-channel image, K ordered (dh, dw padded to 8, c) (igemm3s2_kernel)
+    TILE_B3S2_256x64, TILE_B3S2_128x64,
     TILE_AUTO
 };
 
@@ -93,6 +95,7 @@ int igemm_tile_bk(IgemmTile t);
 bool igemm_tile_split(IgemmTile t);                   // bf16x3 variant (igemm3.hip)?
 int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // launch only; igemm_launch validates
 int igemm3dw_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3dw.hip)
+int igemm3s2_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3s2.hip)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the
 // per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)
@@ -101,9 +104,10 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
                          float* y, int ldy, int rep, double* stats, hipStream_t s);
 
 // filter repacking (pack.hip).  All produce [Npad][Kpad] with zero padding.
-// conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src)
+// conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src).  With tw_pad > tw_src > 0 the packed
+//         taps are rows of tw_pad (tap = th*tw_pad + tw) over a source of tw_src taps per row; tw >= tw_src packs zeros.
 int pack_conv_launch(const float* w_hwio, int ntaps, int cin_src, int cin_pad, int cout,
-                     float* wp, int Npad, int Kpad, hipStream_t s);
+                     float* wp, int Npad, int Kpad, hipStream_t s, int tw_src = 0, int tw_pad = 0);
 // appends the bf16x3 planes of a packed filter: wp must have room for N*Kpad floats + 3*N*Kpad bf16
 int pack_split_launch(float* wp, int N, int Kpad, hipStream_t s);
 inline size_t packed_split_floats(size_t n_fp32) { return n_fp32 + (3 * n_fp32 + 1) / 2; }

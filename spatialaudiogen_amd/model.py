@@ -291,7 +291,9 @@ class SptAudioGen(object):
                 'igemm3dw_kernel<128,128,64,64,false>', 'igemm3dw_kernel<128,64,64,32,false>', 'igemm3dw_kernel<256,64,64,64,false>',
                 'igemm3dw_kernel<64,128,32,64,false>', 'igemm3dw_kernel<64,64,32,32,false>', 'igemm3dw_kernel<64,256,64,64,false>',
                 'igemm3dw_kernel<128,64,64,32,true>', 'igemm3dw_kernel<256,64,64,64,true>', 'igemm3dw_kernel<64,64,32,32,true>',
-                'igemm3dw_kernel<64,128,32,64,true>']
+                'igemm3dw_kernel<64,128,32,64,true>',
+                # bf16x3, the 7x7 stride-2 ResNet stem only
+                'igemm3s2_kernel<256,64,64,64>', 'igemm3s2_kernel<128,64,64,32>']
 
     def plan(self, batch):
         buf = C.create_string_buffer(1 << 16)

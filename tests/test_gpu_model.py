@@ -166,7 +166,9 @@ def test_autotuned_plan_keeps_parity(T):
                                          # bf16x3 (fp32-equivalent split) tiles
                                          (21, 1), (22, 2), (23, 1), (24, 3), (25, 1), (26, 2), (27, 1), (28, 2), (29, 1), (30, 3), (31, 1), (32, 2), (33, 1),
                                          # bf16x3 with shared horizontal taps (3x3 stride-1 convs; other layers fall back)
-                                         (34, 1), (35, 1), (36, 1), (37, 2), (38, 3), (39, 1), (40, 1), (41, 1), (42, 2), (43, 1)])
+                                         (34, 1), (35, 1), (36, 1), (37, 2), (38, 3), (39, 1), (40, 1), (41, 1), (42, 2), (43, 1),
+                                         # stem kernel (conv1 only; other layers fall back)
+                                         (44, 1), (45, 1), (44, 2)])
 def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     """Pin every batch-norm conv of the trunk (and the dense decoder / FC layers) to one tile shape and split-K
     factor: exercises split-K partials + reduce-with-statistics and each kernel instantiation end to end."""

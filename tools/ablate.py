@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 csrc = os.path.join(ROOT, 'spatialaudiogen_amd', 'csrc')
-srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'igemm3.hip', 'igemm3dw.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip')]
+srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'igemm3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip')]
 extra = '/tmp/ablate_entry.hip'
 open(extra, 'w').write('''
 #include "%s/kernels.h"

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 csrc = os.path.join(ROOT, 'spatialaudiogen_amd', 'csrc')
 out = '/tmp/libsagen_trace.so'
-srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'igemm3.hip', 'igemm3dw.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip')]
+srcs = [os.path.join(csrc, f) for f in ('igemm.hip', 'igemm3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip')]
 extra = os.path.join('/tmp', 'trace_entry.hip')
 open(extra, 'w').write('''
 #include "%s/kernels.h"
