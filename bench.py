@@ -177,9 +177,9 @@ def main():
     except Exception:
         pass
     step_tflops = GFLOP_PER_WINDOW * BATCH / (float(np.median(step_ms)) * 1e-3) / 1e3
-    b3 = dom.startswith('igemm3_kernel')
+    b3 = dom.startswith('igemm3')            # igemm3_kernel / igemm3dw_kernel / igemm3s2_kernel: the bf16x3 family
     peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
-    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3_kernel'))
+    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3'))
     f32_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm_kernel'))
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),

@@ -51,9 +51,9 @@ json.dump(traffic, open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1
 label = {}
 wsum = collections.defaultdict(lambda: [0.0, 0.0])
 for k, v in traffic.items():
-    if k.startswith('igemm_kernel<'):
+    if k.startswith('igemm_kernel<') or k.startswith('igemm3s2_kernel<'):
         label[k.replace(' ', '')] = round(v['hbm_bytes_fetch_x2'])
-    elif k.startswith('igemm3_kernel<'):
+    elif k.startswith('igemm3_kernel<') or k.startswith('igemm3dw_kernel<'):
         # the runtime labels the bf16x3 kernels without their last template argument (batch-norm prologue flag):
         # launch-weighted mean over the two instantiations
         base = k.replace(' ', '').rsplit(',', 1)[0] + '>'
