@@ -116,9 +116,13 @@ int    sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const floa
 int    sagen_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow,
                       float* ambi_yzx, void* stream);
 int    sagen_plan_describe(sagen_ctx* ctx, char* buf, size_t buflen);
-/* pin one layer's launch: tile = index into the kernel's tile table (0..5 = 128x128, 128x64, 256x64, 64x64,
- * 128x32, 32x128 with the default LDS ring; 6.. = 2-stage and extra-aspect variants), splitk >= 1 */
+/* pin one layer's launch: tile = index into the contraction kernels' instantiation table (sagen_num_tiles /
+ * sagen_tile_name below), splitk >= 1.  An instantiation that cannot run the layer falls back to the heuristic. */
 int    sagen_plan_set(sagen_ctx* ctx, const char* layer, int tile, int splitk);
+/* the instantiation table: names as sagen_plan_describe / sagen_profile_report print them (host-only calls, no device
+ * needed): "igemm_kernel<...>" = exact fp32 MFMA, "igemm3*_kernel<...>" = fp32-equivalent bf16x3 */
+int         sagen_num_tiles(void);
+const char* sagen_tile_name(int tile);
 
 /* Measurement aid (the reference's only analogue is the samples/sec printout, myutils.py:15-26):
  * when enabled, every launch of the following sagen_forward calls is bracketed by a pair of

@@ -44,6 +44,8 @@ SIGNATURES = {
                                          C.POINTER(C.c_int64)]),
     'sagen_autotune': (C.c_int, [_P, _P, _P, _P, _P, _P]),
     'sagen_plan_set': (C.c_int, [_P, C.c_char_p, _I, _I]),
+    'sagen_num_tiles': (C.c_int, []),
+    'sagen_tile_name': (C.c_char_p, [_I]),
     'sagen_plan_describe': (C.c_int, [_P, C.c_char_p, _SZ]),
     'sagen_profile_enable': (C.c_int, [_P, _I]),
     'sagen_profile_report': (C.c_int, [_P, C.c_char_p, _SZ]),

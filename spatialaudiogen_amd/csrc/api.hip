@@ -85,6 +85,9 @@ int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float**
 int sagen_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {
     return guarded([&] { return sagen_autotune_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
 }
+int sagen_num_tiles(void) { return (int)TILE_AUTO; }
+const char* sagen_tile_name(int tile) { return (tile >= 0 && tile < (int)TILE_AUTO) ? igemm_tile_name((IgemmTile)tile) : nullptr; }
+
 int sagen_plan_set(sagen_ctx* ctx, const char* layer, int tile, int splitk) {
     if (!ctx || !layer) return fail(SAGEN_ERR_NULL, "sagen_plan_set: null argument");
     return guarded([&] { return sagen_plan_set_impl(ctx, layer, tile, splitk); });

@@ -272,28 +272,9 @@ class SptAudioGen(object):
 
     @staticmethod
     def tile_names():
-        return ['igemm_kernel<128,128,64,64,3,16>', 'igemm_kernel<128,64,64,32,3,16>', 'igemm_kernel<256,64,64,64,3,16>',
-                'igemm_kernel<64,64,32,32,3,16>', 'igemm_kernel<128,32,32,32,2,16>', 'igemm_kernel<32,128,32,32,2,16>',
-                'igemm_kernel<128,128,64,64,2,16>', 'igemm_kernel<128,64,64,32,2,16>', 'igemm_kernel<256,64,64,64,2,16>',
-                'igemm_kernel<64,64,32,32,2,16>', 'igemm_kernel<64,128,32,64,3,16>', 'igemm_kernel<64,128,32,64,2,16>',
-                'igemm_kernel<64,256,64,64,3,16>', 'igemm_kernel<64,256,64,64,2,16>', 'igemm_kernel<256,32,64,32,2,16>',
-                'igemm_kernel<64,64,32,32,2,32>', 'igemm_kernel<64,128,32,64,2,32>', 'igemm_kernel<128,64,64,32,2,32>',
-                'igemm_kernel<128,128,64,64,2,32>', 'igemm_kernel<32,128,32,32,2,32>', 'igemm_kernel<128,32,32,32,2,32>',
-                # fp32-equivalent bf16x3 kernels (csrc/igemm3.hip); the last template argument = K tiles per barrier step.
-                # (rocprofv3 appends the batch-norm-prologue flag: ",true>" / ",false>")
-                'igemm3_kernel<128,128,64,64,1>', 'igemm3_kernel<128,64,64,32,1>', 'igemm3_kernel<256,64,64,64,1>',
-                'igemm3_kernel<64,64,32,32,1>', 'igemm3_kernel<64,128,32,64,1>', 'igemm3_kernel<64,256,64,64,1>',
-                'igemm3_kernel<32,128,32,32,1>', 'igemm3_kernel<128,32,32,32,1>', 'igemm3_kernel<128,64,64,32,2>',
-                'igemm3_kernel<64,64,32,32,2>', 'igemm3_kernel<64,128,32,64,2>', 'igemm3_kernel<32,128,32,32,2>',
-                'igemm3_kernel<128,32,32,32,2>',
-                # bf16x3, dense 3x3 stride-1 convs only: the three horizontal taps share one activation tile
-                # (last argument: do the three taps also share one barrier step?)
-                'igemm3dw_kernel<128,128,64,64,false>', 'igemm3dw_kernel<128,64,64,32,false>', 'igemm3dw_kernel<256,64,64,64,false>',
-                'igemm3dw_kernel<64,128,32,64,false>', 'igemm3dw_kernel<64,64,32,32,false>', 'igemm3dw_kernel<64,256,64,64,false>',
-                'igemm3dw_kernel<128,64,64,32,true>', 'igemm3dw_kernel<256,64,64,64,true>', 'igemm3dw_kernel<64,64,32,32,true>',
-                'igemm3dw_kernel<64,128,32,64,true>',
-                # bf16x3, the 7x7 stride-2 ResNet stem only
-                'igemm3s2_kernel<256,64,64,64>', 'igemm3s2_kernel<128,64,64,32>']
+        """Names of the contraction-kernel instantiations, index = the `tile` argument of plan_set (sagen_tile_name)."""
+        L = _lib.lib()
+        return [L.sagen_tile_name(i).decode() for i in range(L.sagen_num_tiles())]
 
     def plan(self, batch):
         buf = C.create_string_buffer(1 << 16)

@@ -92,3 +92,17 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.lower().replace('np_oracle', 'oracle') or f == 'never', (f, 'mentions the oracle')
+
+
+def test_tile_table_is_exposed_and_consistent():
+    """sagen_num_tiles / sagen_tile_name (host-only): the table SptAudioGen.tile_names, plan files and forced plans index."""
+    from spatialaudiogen_amd import _lib
+    from spatialaudiogen_amd.model import SptAudioGen
+    L = _lib.lib()
+    n = L.sagen_num_tiles()
+    names = [L.sagen_tile_name(i).decode() for i in range(n)]
+    assert n >= 40 and len(set(names)) == n
+    assert L.sagen_tile_name(-1) is None and L.sagen_tile_name(n) is None
+    assert names == SptAudioGen.tile_names()
+    fams = {nm.split('<')[0] for nm in names}
+    assert fams == {'igemm_kernel', 'igemm3_kernel', 'igemm3dw_kernel', 'igemm3s2_kernel'}
