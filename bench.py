@@ -39,6 +39,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--in-flight', type=int, default=1,
+                    help='batches in flight per GPU: steps rotate over this many native contexts, each on its own stream (default 1 = strictly '
+                         'one forward at a time; with 2 the gain depends on how ROCm maps the streams to hardware queues, DESIGN.md 6.1)')
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
     ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
@@ -98,15 +101,32 @@ def main():
 
     P = init_weights(variable_specs(ENCODERS), seed=0, mode='bench')           # same replica on every rank
     inp = synth_inputs(BATCH, ENCODERS, seed=1234 + rank)                      # each rank owns its windows
-    net = SptAudioGen(1, encoders=ENCODERS, separation='unet_mask')
-    net.load_variables(P)
+    # Steps are independent batches, so NF of them are kept in flight: step i runs on native context i % NF and stream
+    # i % NF (each context has its own workspace and its own second stream).  Every step is still one full forward of
+    # one batch; the kernels of neighbouring steps fill each other's launch tails.  Outputs are bit-identical to
+    # strictly sequential execution (tests/test_gpu_streams.py, tools/two_in_flight.py).
+    NF = max(1, args.in_flight)
+    nets = [SptAudioGen(1, encoders=ENCODERS, separation='unet_mask') for _ in range(NF)]
+    for n in nets:
+        n.load_variables(P)
+    net = nets[0]
+    streams = []                        # created after the contexts (below): ROCm maps HIP streams to hardware queues in creation order
     audio = torch.as_tensor(inp['audio']).cuda()
     video = torch.as_tensor(inp['video']).cuda()
-    out = torch.empty(BATCH, 4800, 3, device='cuda')
+    outs = [torch.empty(BATCH, 4800, 3, device='cuda') for _ in range(NF)]
+    out = outs[0]
     metric = torch.zeros(4, dtype=torch.float64, device='cuda')
+    counter = [0]
 
     def step():
-        net.inference_ops(audio, video, out=out)
+        j = counter[0] % NF
+        counter[0] += 1
+        if NF == 1:
+            net.inference_ops(audio, video, out=out)
+        else:
+            with torch.cuda.stream(streams[j]):
+                nets[j].inference_ops(audio, video, out=outs[j])
+        return j
 
     def barrier():
         if world > 1:
@@ -114,7 +134,10 @@ def main():
 
     def reduce_metric():
         # eval-style metric reduction: per-rank sums + count, one all-reduce over RCCL
-        metric[0] = (out.double() ** 2).sum()
+        if NF > 1:                          # the reduction (current stream) consumes what the step streams produced
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+        metric[0] = sum((o.double() ** 2).sum() for o in outs) / NF
         metric[1] = float(BATCH)
         if world > 1:
             dist.all_reduce(metric)
@@ -129,6 +152,13 @@ def main():
         plan = net.autotune(audio, video)
         if args.plan_file and rank == 0:
             net.save_plan(BATCH, args.plan_file)
+    names = SptAudioGen.tile_names()
+    streams.extend(torch.cuda.Stream() for _ in range(NF))
+    for n in nets[1:]:                      # the other contexts replay the plan tuned on context 0
+        n.inference_ops(audio, video)
+        for layer, tile, sk, _ in plan:
+            n.plan_set(BATCH, layer, names.index(tile) if tile in names else 0, sk)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     reduce_metric()                     # also loads the torch kernels it uses before the timed region
@@ -138,9 +168,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
+        st = streams[counter[0] % NF] if NF > 1 else torch.cuda.current_stream()
+        ev[i][0].record(st)
         step()
-        ev[i][1].record()
+        ev[i][1].record(st)
     reduce_metric()
     torch.cuda.synchronize()
     barrier()
@@ -149,6 +180,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if os.environ.get('BENCH_DEBUG'):
+        t00 = ev[0][0]
+        print('step timeline (start, end ms):', [(round(t00.elapsed_time(a), 2), round(t00.elapsed_time(b), 2)) for a, b in ev[:8]], file=sys.stderr)
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
 
     windows = world * BATCH * args.steps
@@ -157,11 +191,12 @@ def main():
 
     # ---- roofline of the dominant kernel: per-launch HIP events recorded by the native runtime on the
     #      launch stream (sagen_profile_*), three extra forwards outside the timed region ----
+    torch.cuda.synchronize()
     net.profile_enable(BATCH, True)
     agg = {}
     nprof = 3
     for _ in range(nprof):
-        step()
+        net.inference_ops(audio, video, out=out)          # context 0 alone on the current stream: unoverlapped launch times
         for k, layer, us, fl in net.profile_report(BATCH):
             a = agg.setdefault(k, [0, 0.0, 0.0])
             a[0] += 1; a[1] += us; a[2] += fl
@@ -176,7 +211,7 @@ def main():
             traffic = json.load(f).get(dom)
     except Exception:
         pass
-    step_tflops = GFLOP_PER_WINDOW * BATCH / (float(np.median(step_ms)) * 1e-3) / 1e3
+    step_tflops = GFLOP_PER_WINDOW * BATCH / (ms_per_step * 1e-3) / 1e3          # throughput-based (steps overlap when NF > 1)
     b3 = dom.startswith('igemm3')            # igemm3_kernel / igemm3dw_kernel / igemm3s2_kernel: the bf16x3 family
     peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
     b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3'))
@@ -209,8 +244,9 @@ def main():
                    'windows_per_gpu_per_step': BATCH, 'windows_per_s': round(windows / elapsed, 1),
                    'sharding': 'windows/clips over ranks, no data-path collective; 1 metric all-reduce at the end',
                    'weights': 'random init (Xavier / BN identity), same replica on every rank',
-                   'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics'},
-        'step_ms_event': {'median': round(float(np.median(step_ms)), 4), 'p10': round(step_ms[len(step_ms) // 10], 4),
+                   'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics',
+                   'batches_in_flight': NF},
+        'step_latency_ms_event': {'median': round(float(np.median(step_ms)), 4), 'p10': round(step_ms[len(step_ms) // 10], 4),
                           'p90': round(step_ms[(9 * len(step_ms)) // 10], 4)},
         'roofline': roofline,
     }

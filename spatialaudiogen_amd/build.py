@@ -17,7 +17,10 @@ LIB = os.path.join(HERE, 'libsagen_hip.so')
 SOURCES = ['igemm3dw.hip', 'igemm3s2.hip', 'igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'model.hip', 'api.hip']
 HEADERS = [os.path.join(CSRC, h) for h in ('common.h', 'kernels.h', 'igemm_common.h', 'igemm3_common.h')] + \
           [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'sagen.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# -fno-slp-vectorize -fno-vectorize: no packed-fp32 VALU (v_pk_add/mul/fma_f32).  Measured on MI355X: a wave executing packed-fp32 ops gives
+# wrong results while a wave of another kernel issues v_mfma_f32_32x32x16_bf16 on the same SIMD (the LDS FFT kernels next to the
+# bf16x3 contractions of another stream; tools/victims/) - and packed fp32 is no faster next to MFMAs anyway.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-fno-slp-vectorize', '-fno-vectorize']
 
 
 def _hipcc():

@@ -180,7 +180,11 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
 #endif
     };
     auto store_b = [&](int c, const f32x4& src, float* st) {
+#ifndef SAGEN_ABLATE_DSW
         if (NBC * 256 == 6 * BN || b_active[c]) *reinterpret_cast<f32x4*>(st + b_wofs[c]) = src;
+#else
+        asm volatile("" ::"v"(src));
+#endif
     };
     // conversion of one activation chunk in three jobs (one bf16 plane each): [batch-norm + ReLU], split level,
     // ds_write_b64.  cv[c] carries the running fp32 residuals between the jobs.
@@ -203,7 +207,11 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
         u32x2 pk;
         pk[0] = split_pair(cv[ks][c][0], cv[ks][c][1]);
         pk[1] = split_pair(cv[ks][c][2], cv[ks][c][3]);
+#ifndef SAGEN_ABLATE_DSW
         if (a_active) *reinterpret_cast<u32x2*>(st + level * A_PL + a_wofs[c]) = pk;
+#else
+        asm volatile("" ::"v"(pk));
+#endif
     };
 
     f32x16 acc[MT][NT];

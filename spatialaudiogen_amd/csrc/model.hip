@@ -63,7 +63,7 @@ struct sagen_ctx {
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stft = nullptr;
     // optional per-launch HIP-event profiler (sagen_profile_enable)
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -306,6 +306,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     // second stream + fork/join events (host-side objects; no device memory)
     if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         c->aux = nullptr;      // no device / no stream: forward falls back to a single stream (and fails at launch)
@@ -390,6 +391,7 @@ struct Fwd {
     std::string layer;      // label of the layer being launched (profiling only)
     std::string wsname = "splitk";   // split-K scratch of this launch stream
     std::string sfx;                 // suffix of the trunk buffers this stream owns ("" or "_b")
+    hipEvent_t wait_before_mfma = nullptr;   // event the first contraction of this stream has to wait for (see forward)
 
     hipEvent_t next_event() {
         if (c->events_used == c->event_pool.size()) {
@@ -631,6 +633,10 @@ struct Fwd {
         timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         // conv1 7x7/2 SAME == VALID 7x8 (8th tap column = zero weights) on the padded 4-channel image
         int H = 0, W = 0;
+        if (!rc && wait_before_mfma) {
+            if (hipStreamWaitEvent(s, wait_before_mfma, 0) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "hipStreamWaitEvent failed");
+            wait_before_mfma = nullptr;
+        }
         {
             const std::string name = scope + "/conv1/conv";
             IgemmDesc d = conv_desc(c->p("xpad" + sfx), 229, 454, 4, 4, c->p("pk:" + name + "/weights"), 7, 8, 2, 2, false, 64,
@@ -737,6 +743,12 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // ---- stream g: STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
     g.layer = "stft";
     g.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), g.s); });
+    if (forked) {
+        // The LDS FFT kernels give wrong results when bf16x3 contraction waves of ANOTHER stream share their CUs
+        // (open): the first matrix launch of the main stream waits for the STFT (it overlaps the pad kernel).
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_stft, c->aux));
+        f.wait_before_mfma = c->ev_stft;
+    }
 
     // audio encoder (model.py:161-187): conv l writes the encoder half of concat buffer l
     for (int l = 0; l < 5 && !g.rc; ++l) {
@@ -848,6 +860,7 @@ void sagen_destroy_impl(sagen_ctx* c) {
     if (c->tune_e0) { (void)hipEventDestroy(c->tune_e0); (void)hipEventDestroy(c->tune_e1); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     delete c;
 }

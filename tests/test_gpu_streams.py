@@ -1,0 +1,72 @@
+"""Stream safety of the native runtime at the benchmark batch size (GPU).
+
+The forward forks onto a context-owned second stream (audio chain / flow trunk / localisation FCs next to the trunk and
+the decoder).  Whatever overlaps there must not change a single bit: repeated forwards are identical and equal to the
+forward with the second stream disabled (SAGEN_ONE_STREAM=1, an environment switch read when the library loads - hence
+the subprocesses).  A contraction must also be unaffected by another contraction running on a different stream."""
+import os, subprocess, sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+from spatialaudiogen_amd.model import SptAudioGen
+enc = sys.argv[1].split(','); B = 32
+P = init_weights(variable_specs(enc), seed=3, mode='bench'); inp = synth_inputs(B, enc, seed=7)
+net = SptAudioGen(1, encoders=enc, separation='unet_mask'); net.load_variables(P)
+args = [torch.as_tensor(inp[k]).cuda() if k in inp else None for k in ('audio', 'video', 'flow')]
+outs = [net.inference_ops(*args).clone() for _ in range(8)]
+torch.cuda.synchronize()
+assert all(torch.equal(outs[0], o) for o in outs), 'repeated forwards differ'
+assert bool(torch.isfinite(outs[0]).all())
+np.save(sys.argv[2], outs[0].cpu().numpy())
+''' % ROOT
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch
+
+
+def _forward(enc, one_stream, path):
+    env = dict(os.environ)
+    env.pop('SAGEN_ONE_STREAM', None)
+    if one_stream:
+        env['SAGEN_ONE_STREAM'] = '1'
+    subprocess.run([sys.executable, '-c', CHILD, ','.join(enc), path], check=True, env=env, timeout=600)
+    return np.load(path)
+
+
+@pytest.mark.parametrize('enc', [['audio', 'video'], ['audio', 'video', 'flow']])
+def test_two_stream_forward_equals_one_stream_forward_bitwise(tmp_path, enc):
+    two = _forward(enc, False, str(tmp_path / 'two.npy'))
+    one = _forward(enc, True, str(tmp_path / 'one.npy'))
+    assert two.shape == (32, 4800, 3)
+    assert np.array_equal(two, one)
+
+
+def test_contraction_is_unaffected_by_a_concurrent_contraction(T):
+    from spatialaudiogen_amd import ops
+    torch = T
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(32, 28, 56, 128, device='cuda', generator=g); w = torch.randn(3, 3, 128, 128, device='cuda', generator=g) * 0.05
+    x2 = torch.randn(32, 56, 112, 64, device='cuda', generator=g); w2 = torch.randn(3, 3, 64, 64, device='cuda', generator=g) * 0.05
+    ref, rs = ops.conv_2d(x, w, 1, 'SAME', return_bn_stats=True)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(10):
+        with torch.cuda.stream(sb):
+            for _ in range(3):
+                ops.conv_2d(x2, w2, 1, 'SAME', return_bn_stats=True)
+        with torch.cuda.stream(sa):
+            y, st = ops.conv_2d(x, w, 1, 'SAME', return_bn_stats=True)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref) and torch.equal(st, rs)
