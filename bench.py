@@ -39,9 +39,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--in-flight', type=int, default=1,
-                    help='batches in flight per GPU: steps rotate over this many native contexts, each on its own stream (default 1 = strictly '
-                         'one forward at a time; with 2 the gain depends on how ROCm maps the streams to hardware queues, DESIGN.md 6.1)')
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help='batches in flight per GPU: steps rotate over this many native contexts, each on its own stream, the streams '
+                         'probed to really run concurrently (DESIGN.md 6.1); 1 = strictly one forward at a time')
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
     ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
@@ -84,6 +84,9 @@ def main():
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    if args.in_flight > 1:
+        # several batches in flight: each context stays on its caller's stream (the other batch is the overlap)
+        os.environ['SAGEN_ONE_STREAM'] = '1'
     import torch
     import torch.distributed as dist
     from spatialaudiogen_amd.model import SptAudioGen
@@ -153,7 +156,8 @@ def main():
         if args.plan_file and rank == 0:
             net.save_plan(BATCH, args.plan_file)
     names = SptAudioGen.tile_names()
-    streams.extend(torch.cuda.Stream() for _ in range(NF))
+    from spatialaudiogen_amd.streams import pick_concurrent_streams
+    streams.extend(pick_concurrent_streams(NF))
     for n in nets[1:]:                      # the other contexts replay the plan tuned on context 0
         n.inference_ops(audio, video)
         for layer, tile, sk, _ in plan:

@@ -70,3 +70,37 @@ def test_contraction_is_unaffected_by_a_concurrent_contraction(T):
             y, st = ops.conv_2d(x, w, 1, 'SAME', return_bn_stats=True)
         torch.cuda.synchronize()
         assert torch.equal(y, ref) and torch.equal(st, rs)
+
+
+PIPE = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+from spatialaudiogen_amd.model import SptAudioGen
+from spatialaudiogen_amd.streams import pick_concurrent_streams
+enc = ['audio', 'video']; B = 32
+P = init_weights(variable_specs(enc), seed=3, mode='bench')
+batches = [synth_inputs(B, enc, seed=40 + i) for i in range(2)]
+dev = [[torch.as_tensor(b[k]).cuda() for k in ('audio', 'video')] for b in batches]
+nets = [SptAudioGen(1, encoders=enc, separation='unet_mask') for _ in range(2)]
+for n in nets: n.load_variables(P)
+seq = [nets[j].inference_ops(*dev[j]).clone() for j in range(2)]        # one after the other
+torch.cuda.synchronize()
+streams = pick_concurrent_streams(2)
+outs = [torch.empty_like(seq[0]) for _ in range(2)]
+for i in range(24):                                                      # two batches in flight
+    j = i %% 2
+    with torch.cuda.stream(streams[j]):
+        nets[j].inference_ops(*dev[j], out=outs[j])
+torch.cuda.synchronize()
+assert not torch.equal(seq[0], seq[1])                                   # different batches, different answers
+for j in range(2):
+    assert torch.equal(outs[j], seq[j]), 'context %%d: in-flight result differs from the sequential one' %% j
+''' % ROOT
+
+
+def test_two_batches_in_flight_reproduce_sequential_results():
+    """Two native contexts (single-stream mode) on two probed-concurrent streams, different inputs: bit-identical to
+    running them one after the other (the packed-fp32 / bf16-MFMA hazard of DESIGN.md 6.1 broke exactly this)."""
+    env = dict(os.environ); env['SAGEN_ONE_STREAM'] = '1'
+    subprocess.run([sys.executable, '-c', PIPE], check=True, env=env, timeout=600)

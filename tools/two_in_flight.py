@@ -8,8 +8,9 @@ enc = ['audio', 'video']; B = 32
 P = init_weights(variable_specs(enc), seed=0, mode='bench')
 inp = synth_inputs(B, enc, seed=1)
 a = torch.as_tensor(inp['audio']).cuda(); v = torch.as_tensor(inp['video']).cuda()
-nets = [SptAudioGen(1, encoders=enc, separation='unet_mask') for _ in range(3)]
-streams = [torch.cuda.Stream() for _ in range(3)]
+NN = int(os.environ.get('NNETS', '3'))
+nets = [SptAudioGen(1, encoders=enc, separation='unet_mask') for _ in range(NN)]
+streams = [torch.cuda.Stream() for _ in range(NN)]
 outs = []
 for n in nets:
     n.load_variables(P); outs.append(n.inference_ops(a, v))
@@ -33,18 +34,9 @@ seq = []
 for n in nets:
     seq.append(n.inference_ops(a, v).clone())
 torch.cuda.synchronize()
-print('sequential references: ctx1-ctx0 %g  ctx2-ctx0 %g' % (float((seq[1] - seq[0]).abs().max()), float((seq[2] - seq[0]).abs().max())))
-for k in (1, 2, 3, 1, 2):
+print('sequential references agree:', all(bool(torch.equal(seq[0], x)) for x in seq))
+for k in [kk for kk in (1, 2, 3, 1, 2) if kk <= NN]:
     v_, ms = run(k)
     d = [float((outs[j] - seq[j]).abs().max()) for j in range(k)]
     print('%d batch(es) in flight: %.1f ambisonic-s/s  (%.3f ms per batch)   max |out - sequential| per context: %s' % (k, v_, ms, d), flush=True)
 
-# which intermediate diverges under concurrency?
-names = ['mag', 'stft', 'audio_encoder/conv1', 'audio_encoder/conv5', 'bottleneck', 'localization/coeffs', 'separation/deconv1']
-for n in nets: n.inference_ops(a, v)
-torch.cuda.synchronize()
-refs = [{nm: n.intermediate(B, nm).clone() for nm in names} for n in nets]
-run(2)
-for j in range(2):
-    d = {nm: float((nets[j].intermediate(B, nm) - refs[j][nm]).abs().max()) for nm in names}
-    print('ctx%d after concurrent run:' % j, {k: ('%.3g' % x) for k, x in d.items()})
