@@ -188,3 +188,24 @@ def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
         if name.endswith('/weights'):
             net.plan_set(2, name[:-len('/weights')], tile, splitk)
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
+
+
+def test_full_benchmark_batch_against_the_independent_cpu_reference(T):
+    """BASELINE configs[1] at its real size (32 windows, audio + video): the heuristic launch plan AND the autotuned plan
+    against oracle/torch_ref.py in fp64 (an implementation independent of both the numpy oracle and the HIP code).
+    Catches anything that only shows at full tile counts: edge tiles, split-K ranges, the kernels the tuner picks."""
+    import torch
+    from oracle.torch_ref import TorchRef
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    B = 32
+    P = init_weights(variable_specs(enc), seed=11, mode='test')
+    inp = synth_inputs(B, enc, seed=77)
+    ref = TorchRef(P, enc, dtype=torch.float64).forward(inp['audio'], inp['video'])
+    ref = ref.numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
+    plan = net.autotune(inp['audio'], inp['video'])
+    assert any(row[1].startswith('igemm3') for row in plan)
+    check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
