@@ -363,6 +363,13 @@ IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     auto blocks = [&](IgemmTile t) { return (long)cdiv(d.M, tile_bm(t)) * cdiv(d.N, tile_bn(t)) * d.splitk; };
     const long want = 2 * 256;                 // >= 2 workgroups per CU
     if (d.w_split && !fp32_only) {             // the bf16x3 kernels are the faster family wherever their planes exist
+        const bool pro = d.in_scale != nullptr || d.bn_in.acc != nullptr;
+        if (s2_ok(d)) return TILE_B3S2_128x64;                                  // the 7x7/2 stem
+        if (dw3_ok(d) && (!pro || uniform_taps_for(d, 16))) {                   // 3x3 stride 1: shared horizontal taps
+            if (d.N <= 64) return blocks(TILE_B3DW_128x64) >= want ? TILE_B3DW_128x64 : TILE_B3DWM_64x64;
+            if (blocks(TILE_B3DW_128x128) >= 256 + 128) return TILE_B3DW_128x128;
+            return blocks(TILE_B3DWM_128x64) >= 256 + 128 ? TILE_B3DWM_128x64 : TILE_B3DWM_64x64;
+        }
         if (d.M <= 32) return TILE_B3_32x128;
         if (d.N <= 32) return TILE_B3_128x32;
         if (d.N <= 64) return blocks(TILE_B3_128x64) >= want ? TILE_B3_128x64 : TILE_B3_64x64;
