@@ -252,3 +252,57 @@ def test_evaluation_metrics(T, B):
     assert list(m.keys()) == list(ref_m.keys())
     for k in ref_m:
         assert abs(m[k] - ref_m[k]) <= 2e-3 * max(1.0, abs(ref_m[k])), (k, m[k], ref_m[k])
+
+
+def _dw_cases():
+    """Randomised 3x3 stride-1 SAME convolutions (the geometry igemm3dw_kernel takes over): odd / tiny images, ragged M
+    tails, N off the tile sizes, multi-image batches (image-edge and batch-edge gap slots), with the fused BN prologue."""
+    r = np.random.default_rng(20240917)
+    cases = []
+    for i in range(28):
+        H = int(r.integers(2, 24)); W = int(r.integers(8, 40))
+        B = int(r.integers(1, 6))
+        Cin = int(r.choice([16, 32, 64, 128]))
+        Cout = int(r.choice([8, 24, 32, 48, 64, 96, 128, 136]))
+        cases.append(('dw%02d' % i, B, H, W, Cin, Cout, bool(i % 3 == 0), bool(i % 2 == 0)))
+    cases += [('dw_w8', 3, 7, 8, 16, 64, True, True), ('dw_h2', 2, 2, 33, 32, 64, False, True),
+              ('dw_one_row_tile', 1, 3, 131, 16, 32, True, False), ('dw_many_images', 19, 4, 9, 16, 16, False, True)]
+    return cases
+
+
+@pytest.mark.parametrize('case', _dw_cases(), ids=lambda c: c[0])
+def test_conv3x3_stride1_randomised_geometry(T, case):
+    from spatialaudiogen_amd import ops
+    name, B, H, W, Cin, Cout, prologue, stats = case
+    r = rng(sum(map(ord, name)))
+    x = r.normal(size=(B, H, W, Cin))
+    w = r.normal(size=(3, 3, Cin, Cout)) / np.sqrt(9 * Cin)
+    sc = r.uniform(0.5, 1.5, size=(Cin,)) if prologue else None
+    sf = r.normal(size=(Cin,)) if prologue else None
+    xin = np.maximum(x * sc + sf, 0) if prologue else x
+    ref = O.nn_convolution(xin, w, (1, 1), 'SAME')
+    out = ops.conv_2d(dev(T, x), dev(T, w), (1, 1), 'SAME', None, False, dev(T, sc) if prologue else None,
+                      dev(T, sf) if prologue else None, return_bn_stats=stats)
+    y, st = out if stats else (out, None)
+    assert rel_rms_err(y.cpu().numpy(), ref) < TOL
+    if stats:
+        gamma, beta = np.ones(Cout), np.zeros(Cout)
+        scale, shift = ops.bn_finalize(st, y.shape, dev(T, gamma), dev(T, beta))
+        rs = 1.0 / np.sqrt(ref.var(axis=(0, 1, 2)) + 1e-3)
+        assert rel_rms_err(scale.cpu().numpy(), rs) < TOL
+        assert rel_rms_err(shift.cpu().numpy(), -ref.mean(axis=(0, 1, 2)) * rs) < 50 * TOL + 1e-5
+
+
+def test_every_dw_sharing_tile_on_odd_geometry(T):
+    """Re-run the randomised 3x3 cases once per igemm3dw instantiation (SAGEN_FORCE_TILE is read when the library loads,
+    hence one subprocess per tile; it applies to the cases with M > 128 and N >= 64, the others keep the heuristic)."""
+    import os, subprocess, sys
+    from spatialaudiogen_amd.model import SptAudioGen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tiles = [i for i, nm in enumerate(SptAudioGen.tile_names()) if nm.startswith('igemm3dw_kernel')]
+    assert len(tiles) >= 8
+    for t in tiles:
+        env = dict(os.environ); env['SAGEN_FORCE_TILE'] = str(t)
+        r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_ops.py'), '-m', 'gpu', '-q', '-x',
+                            '-k', 'conv3x3_stride1_randomised'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, 'tile %d (%s):\n%s' % (t, SptAudioGen.tile_names()[t], r.stdout[-2000:])
