@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libsagen_hip.so')
+LIB_PATH = os.environ.get('SAGEN_LIB') or os.path.join(HERE, 'libsagen_hip.so')     # SAGEN_LIB: developer override (A/B builds)
 
 SAGEN_ENC_AUDIO, SAGEN_ENC_VIDEO, SAGEN_ENC_FLOW = 1, 2, 4
 SAGEN_SEP_NONE, SAGEN_SEP_FREQ_MASK = 0, 1
