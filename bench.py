@@ -97,10 +97,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU implementation')
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # RCCL ('nccl') is the backend; SAGEN_DIST_BACKEND=gloo is a test hook for running several ranks on ONE GPU
+        dist.init_process_group(os.environ.get('SAGEN_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
 
     P = init_weights(variable_specs(ENCODERS), seed=0, mode='bench')           # same replica on every rank
     inp = synth_inputs(BATCH, ENCODERS, seed=1234 + rank)                      # each rank owns its windows
