@@ -367,7 +367,7 @@ int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s) {
 }
 
 // fp32 packed filter [N][Kpad] -> three bf16 planes (hi, mid, lo of the bf16x3 split), tiled [Kpad/16][3][N][16] so that
-// the 32 rows x 32 B one LDS-DMA instruction fetches are contiguous in memory.
+// the three planes of one K tile of 16 form one contiguous block (fully coalesced 16-byte loads).
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ wp, long total, int N, int Kpad,
                                                          __bf16* __restrict__ w3) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
