@@ -78,10 +78,10 @@ sys.path.insert(0, %r)
 from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
 from spatialaudiogen_amd.model import SptAudioGen
 from spatialaudiogen_amd.streams import pick_concurrent_streams
-enc = ['audio', 'video']; B = 32
+enc = sys.argv[1].split(','); B = 32
 P = init_weights(variable_specs(enc), seed=3, mode='bench')
 batches = [synth_inputs(B, enc, seed=40 + i) for i in range(2)]
-dev = [[torch.as_tensor(b[k]).cuda() for k in ('audio', 'video')] for b in batches]
+dev = [[torch.as_tensor(b[k]).cuda() if k in b else None for k in ('audio', 'video', 'flow')] for b in batches]
 nets = [SptAudioGen(1, encoders=enc, separation='unet_mask') for _ in range(2)]
 for n in nets: n.load_variables(P)
 seq = [nets[j].inference_ops(*dev[j]).clone() for j in range(2)]        # one after the other
@@ -99,8 +99,9 @@ for j in range(2):
 ''' % ROOT
 
 
-def test_two_batches_in_flight_reproduce_sequential_results():
+@pytest.mark.parametrize('enc', [['audio', 'video'], ['audio', 'video', 'flow']])
+def test_two_batches_in_flight_reproduce_sequential_results(enc):
     """Two native contexts (single-stream mode) on two probed-concurrent streams, different inputs: bit-identical to
     running them one after the other (the packed-fp32 / bf16-MFMA hazard of DESIGN.md 6.1 broke exactly this)."""
     env = dict(os.environ); env['SAGEN_ONE_STREAM'] = '1'
-    subprocess.run([sys.executable, '-c', PIPE], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, '-c', PIPE, ','.join(enc)], check=True, env=env, timeout=900)
