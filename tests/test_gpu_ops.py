@@ -306,3 +306,62 @@ def test_every_dw_sharing_tile_on_odd_geometry(T):
         r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_ops.py'), '-m', 'gpu', '-q', '-x',
                             '-k', 'conv3x3_stride1_randomised'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, 'tile %d (%s):\n%s' % (t, SptAudioGen.tile_names()[t], r.stdout[-2000:])
+
+
+def _generic_cases():
+    r = np.random.default_rng(777)
+    cases = []
+    for i in range(36):
+        kh, kw = int(r.choice([1, 2, 3, 5, 7])), int(r.choice([1, 3, 4, 5, 7]))
+        sh, sw = int(r.choice([1, 2, 3])), int(r.choice([1, 2, 4]))
+        Cin = int(r.choice([4, 8, 16, 32, 64]))
+        if kh * kw == 1:
+            Cin = int(r.choice([4, 12, 20, 36, 64]))              # 1x1: any multiple of 4
+        Cout = int(r.choice([4, 20, 32, 33, 64, 100, 128]))
+        H = int(r.integers(kh, kh + 20)); W = int(r.integers(kw, kw + 28)); B = int(r.integers(1, 5))
+        cases.append(('g%02d' % i, B, H, W, Cin, kh, kw, Cout, sh, sw, 'SAME' if i % 2 else 'VALID', bool(i % 3 == 0), bool(i % 4 == 1),
+                      bool(i % 5 == 0)))
+    return cases
+
+
+@pytest.mark.parametrize('case', _generic_cases(), ids=lambda c: c[0])
+def test_conv_2d_randomised_generic_geometry(T, case):
+    """Kernel sizes / strides / paddings / channel counts off the model's own: per-chunk taps (Cin < 16), ragged K tails,
+    N off the tile sizes, tiny M."""
+    from spatialaudiogen_amd import ops
+    name, B, H, W, Cin, kh, kw, Cout, sh, sw, padding, bias, relu, stats = case
+    r = rng(sum(map(ord, name)) + 13)
+    x = r.normal(size=(B, H, W, Cin))
+    w = r.normal(size=(kh, kw, Cin, Cout)) / np.sqrt(kh * kw * Cin)
+    b = r.normal(size=(Cout,)) if bias else None
+    ref = O.nn_convolution(x, w, (sh, sw), padding)
+    raw = ref.copy()
+    if bias:
+        ref = ref + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    out = ops.conv_2d(dev(T, x), dev(T, w), (sh, sw), padding, dev(T, b) if bias else None, relu, return_bn_stats=stats)
+    y, st = out if stats else (out, None)
+    assert y.shape == ref.shape
+    assert rel_rms_err(y.cpu().numpy(), ref) < TOL
+    if stats:
+        scale, shift = ops.bn_finalize(st, y.shape, dev(T, np.ones(Cout)), dev(T, np.zeros(Cout)))
+        rs = 1.0 / np.sqrt(raw.var(axis=(0, 1, 2)) + 1e-3)
+        assert rel_rms_err(scale.cpu().numpy(), rs) < TOL
+
+
+def _deconv_cases():
+    r = np.random.default_rng(4242)
+    cases = []
+    for i in range(20):
+        sh, sw = int(r.choice([1, 2, 3])), int(r.choice([1, 2, 4]))
+        kh, kw = sh + int(r.integers(0, 4)), sw + int(r.integers(0, 5))          # kernel >= stride
+        Cin = int(r.choice([4, 8, 16, 32, 64])); Cout = int(r.choice([4, 12, 32, 40, 64]))
+        cases.append((int(r.integers(1, 4)), int(r.integers(1, 9)), int(r.integers(1, 14)), Cin, kh, kw, Cout, sh, sw, bool(i % 2)))
+    return cases
+
+
+@pytest.mark.parametrize('case', _deconv_cases(), ids=lambda c: 'b%d_%dx%d_c%d_k%dx%d_o%d_s%dx%d' % c[:9])
+def test_deconv_2d_randomised_geometry(T, case):
+    """conv2d_transpose as a stride-1 conv with a depth-to-space epilogue, over random kernel / stride / channel combinations."""
+    test_deconv_2d(T, case)
