@@ -91,3 +91,41 @@ def test_batch_prefetcher_preserves_order():
     gen = ({'i': i, 'x': np.full((2, 2), i, np.float32)} for i in range(7))
     got = [b['i'] for b in F.BatchPrefetcher(gen, depth=2)]
     assert got == list(range(7))
+
+
+def test_prefetcher_reraises_producer_failures_in_order():
+    """A reader failure must surface in the consumer where it happened, not end the stream silently (a truncated deploy)."""
+    def gen():
+        yield {'i': 0}
+        yield {'i': 1}
+        raise IOError('frame 000002.jpg is missing')
+    it = iter(F.BatchPrefetcher(gen(), depth=1))
+    assert next(it)['i'] == 0 and next(it)['i'] == 1
+    with pytest.raises(IOError, match='000002'):
+        next(it)
+    # a failing FIRST batch raises the reader's error too
+    with pytest.raises(ZeroDivisionError):
+        list(F.BatchPrefetcher((1 // 0 for _ in range(1)), depth=1))
+
+
+def test_prefetcher_close_unblocks_the_producer():
+    p = F.BatchPrefetcher(({'i': i} for i in range(100)), depth=1)
+    assert next(iter(p))['i'] == 0
+    p.close()
+    assert not p.thread.is_alive()
+
+
+def test_window_table_matches_the_scalar_transcription():
+    """The vectorised window table against the scalar restatement of feeder.py:64-90,121 in deploy.py, over the deploy
+    times (t = chunks_t[i] - (chunks_t[0] - start), float64) and a grid of awkward ones."""
+    audio = rng(3).normal(size=(6 * 48000, 1))
+    times = [(0.5 + i / 10.) - 0.5 for i in range(50)] + [0.5 + i / 10. for i in range(45)] + [1.2, 2.3000000000000003, 4.999999, 5.45]
+    tab = F.window_table(times, 1.0, 52799, 48000, audio.shape[0], 10)
+    for k, t in enumerate(times):
+        ref = audio_window(audio, t, 1.0, 52799, 48000)
+        got = np.zeros((52799, 1))
+        n = int(tab.read_count[k])
+        got[int(tab.lead[k]):int(tab.lead[k]) + n] = audio[int(tab.read_from[k]):int(tab.read_from[k]) + n]
+        assert ref.shape == got.shape and np.array_equal(ref, got), t
+        assert int(tab.frame[k]) == frame_index(t, 10)
+        assert int(tab.lead[k]) + n + int(tab.trail[k]) == 52799
