@@ -2,6 +2,8 @@
 // no exceptions across the boundary.
 #include "kernels.h"
 #include <new>
+#include <cstdlib>
+#include <algorithm>
 
 struct sagen_ctx;
 int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg);
@@ -121,7 +123,9 @@ int sagen_stft_mag(const float* audio, int batch, int n_samples, int f0, int f1,
 
 size_t sagen_conv2d_scratch_bytes(int batch, int h, int w, int kh, int kw, int cin, int cout) {
     if (cin == 3) return pk_bytes(cout, (long)kh * kw * 4) + align_up((size_t)batch * (h + kh) * (w + kw) * 4 * sizeof(float), 256);
-    return pk_bytes(cout, (long)kh * kw * cin);
+    // 3x3 convs may run on pre-split activation planes (conv3p.hip): room for them behind the packed filter
+    const size_t planes = (kh == 3 && kw == 3 && cin % 16 == 0) ? align_up(p3_bytes(batch, h, w, cin), 256) : 0;
+    return pk_bytes(cout, (long)kh * kw * cin) + planes;
 }
 
 size_t sagen_bn_stats_floats(int batch, int hout, int wout, int cout) {
@@ -188,6 +192,23 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
         if (rc) return rc;
         d.w_split = 1;
         if (bn_stats) SAGEN_HIP_CHECK(hipMemsetAsync(bn_stats, 0, (size_t)2 * cout * sizeof(double), s));
+        static const bool no_p3 = getenv("SAGEN_NO_P3") != nullptr || getenv("SAGEN_FP32_ONLY") != nullptr;
+        if (!no_p3 && sh == 1 && sw == 1 && padding == 1 && cin % 16 == 0 && igemm_p3_eligible(d) &&
+            p3_bytes(batch, h, w, cin) < (1UL << 31)) {
+            // dense 3x3 stride-1 SAME: one elementwise pass applies the input BN+ReLU (if any) and writes the three bf16
+            // planes; the contraction then runs LDS-DMA -> MFMA only (conv3p.hip)
+            IgemmDesc e = d;
+            e.xp3 = (char*)scratch + pk_bytes(cout, (long)kh * kw * cin);
+            e.p3_np = batch * h * (w + 1);
+            e.xp3_cstride = (unsigned)((size_t)e.p3_np * 96);
+            e.xp3_bytes = (unsigned)p3_bytes(batch, h, w, cin);
+            const IgemmTile t = igemm_pick_tile(e);
+            if (igemm_tile_p3(t)) {
+                rc = p3_pack_launch(x, in_scale, in_shift, BnRef(), nullptr, in_scale ? 1 : 0, nullptr, (void*)e.xp3, batch, h, w, cin, s);
+                if (rc) return rc;
+                return igemm_launch(e, t, s);
+            }
+        }
         return igemm_launch(d, TILE_AUTO, s);
     });
 }

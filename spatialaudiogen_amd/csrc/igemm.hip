@@ -293,7 +293,7 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; };
+struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; bool p3 = false; };
 static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
     {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
@@ -320,6 +320,9 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 16, "igemm3dw_kernel<128,64,64,32,true>", true, true},    {256, 64, 16, "igemm3dw_kernel<256,64,64,64,true>", true, true},
     {64, 64, 16, "igemm3dw_kernel<64,64,32,32,true>", true, true},      {64, 128, 16, "igemm3dw_kernel<64,128,32,64,true>", true, true},
     {256, 64, 16, "igemm3s2_kernel<256,64,64,64>", true, false, true},  {128, 64, 16, "igemm3s2_kernel<128,64,64,32>", true, false, true},
+    {128, 64, 16, "conv3p_kernel<128,64,64,32,2>", true, true, false, true},   {128, 128, 16, "conv3p_kernel<128,128,64,64,2>", true, true, false, true},
+    {128, 128, 16, "conv3p_kernel<128,128,64,64,3>", true, true, false, true}, {256, 64, 16, "conv3p_kernel<256,64,64,64,3>", true, true, false, true},
+    {64, 64, 16, "conv3p_kernel<64,64,32,32,2>", true, true, false, true},     {64, 128, 16, "conv3p_kernel<64,128,32,64,2>", true, true, false, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -335,6 +338,8 @@ static bool dw3_ok(const IgemmDesc& d) {
            d.K == 9 * d.Cin && d.Kpad == d.K && d.x_bstride == (long)d.Hin * d.Win * d.ldx && d.Hin >= 2 && d.Win >= 8;
 }
 bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].split; }
+bool igemm_tile_p3(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].p3; }
+bool igemm_p3_eligible(const IgemmDesc& d) { return dw3_ok(d) && d.w_split && d.dsh * d.dsw == 1 && d.Cin <= MAX_BN_C; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
 static int tile_bn(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bn : 0; }
 int igemm_tile_bm(IgemmTile t) { return tile_bm(t); }
@@ -351,6 +356,9 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
     if (kTiles[t].dw3 && !dw3_ok(d)) return false;
+    if (kTiles[t].p3 && (d.xp3 == nullptr || d.splitk != 1)) return false;
+    if (!kTiles[t].p3 && d.xp3 != nullptr && d.x == nullptr) return false;      // only the planes were provided
+    if (kTiles[t].p3) return true;                                               // (the producer's BN+ReLU is already in the planes)
     if (kTiles[t].s2 && !s2_ok(d)) return false;
     if ((d.in_scale || d.bn_in.acc) && !uniform_taps_for(d, bk)) return false;
     return true;
@@ -358,13 +366,19 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
 
 IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: IgemmTile index
-    if (force && d.M > 128 && d.N >= 64) return (IgemmTile)atoi(force);
+    if (force && d.M > 128 && d.N >= 64 && igemm_tile_ok(d, (IgemmTile)atoi(force))) return (IgemmTile)atoi(force);
     static const bool fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
     auto blocks = [&](IgemmTile t) { return (long)cdiv(d.M, tile_bm(t)) * cdiv(d.N, tile_bn(t)) * d.splitk; };
     const long want = 2 * 256;                 // >= 2 workgroups per CU
     if (d.w_split && !fp32_only) {             // the bf16x3 kernels are the faster family wherever their planes exist
         const bool pro = d.in_scale != nullptr || d.bn_in.acc != nullptr;
         if (s2_ok(d)) return TILE_B3S2_128x64;                                  // the 7x7/2 stem
+        if (d.xp3 != nullptr && dw3_ok(d) && d.splitk == 1) {                   // pre-split activation planes: LDS-DMA -> MFMA only
+            const long np = d.p3_np;
+            if (d.N <= 64) return cdiv(np, 128) >= want ? TILE_P3_128x64 : TILE_P3_64x64;
+            if ((long)cdiv(np, 128) * cdiv(d.N, 64) >= want) return TILE_P3_128x64;
+            return TILE_P3_64x64;
+        }
         if (dw3_ok(d) && (!pro || uniform_taps_for(d, 16))) {                   // 3x3 stride 1: shared horizontal taps
             if (d.N <= 64) return blocks(TILE_B3DW_128x64) >= want ? TILE_B3DW_128x64 : TILE_B3DWM_64x64;
             if (blocks(TILE_B3DW_128x128) >= 256 + 128) return TILE_B3DW_128x128;
@@ -396,7 +410,7 @@ int igemm_grid_m(const IgemmDesc& d, IgemmTile tile) {
 
 int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     IgemmDesc d = d_in;
-    if (!d.x || !d.w || (!d.y && !d.splitk_ws)) return fail(SAGEN_ERR_NULL, "igemm: null operand");
+    if ((!d.x && !d.xp3) || !d.w || (!d.y && !d.splitk_ws)) return fail(SAGEN_ERR_NULL, "igemm: null operand");
     if (d.M <= 0 || d.N <= 0 || d.K <= 0) return fail(SAGEN_ERR_SHAPE, "igemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
     if (d.Kpad % 16 || d.Kpad < d.K) return fail(SAGEN_ERR_SHAPE, "igemm: Kpad=%d must be a multiple of 16 >= K=%d", d.Kpad, d.K);
     if (d.K % 4 || d.Cin % 4) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: Cin=%d / K=%d must be multiples of 4", d.Cin, d.K);
@@ -431,6 +445,7 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
+    if (kTiles[tile].p3) return conv3p_dispatch(d, tile, s);
     if (kTiles[tile].s2) return igemm3s2_dispatch(d, tile, s);
     if (kTiles[tile].split) return igemm3_dispatch(d, tile, s);
     switch (tile) {

@@ -57,6 +57,10 @@ struct IgemmDesc {
     unsigned x_bytes = 0, w_bytes = 0;
     int no_bounds = 0;
     int uniform_taps = 0;
+    // conv3p_kernel (conv3p.hip): the activation as pre-split bf16 planes [Cin/16][p3_np][3][16], p3_np = B*Hin*(Win+1)
+    const void* xp3 = nullptr;
+    unsigned xp3_bytes = 0, xp3_cstride = 0;
+    int p3_np = 0;
     // debug builds (-DSAGEN_TRACE): phase timeline of workgroup `trace_block`
     void* trace = nullptr;
     int trace_block = 0;
@@ -82,6 +86,8 @@ enum IgemmTile {
     TILE_B3DWM_128x64, TILE_B3DWM_256x64, TILE_B3DWM_64x64, TILE_B3DWM_64x128,
     // bf16x3 for the 7x7 stride-2 stem over the padded 4-channel image, K ordered (dh, dw padded to 8, c) (igemm3s2_kernel)
     TILE_B3S2_256x64, TILE_B3S2_128x64,
+    // bf16x3 for dense 3x3 stride-1 SAME convs over pre-split activation planes (conv3p_kernel; needs IgemmDesc::xp3)
+    TILE_P3_128x64, TILE_P3_128x128, TILE_P3_128x128_S3, TILE_P3_256x64_S3, TILE_P3_64x64, TILE_P3_64x128,
     TILE_AUTO
 };
 
@@ -96,6 +102,9 @@ bool igemm_tile_split(IgemmTile t);                   // bf16x3 variant (igemm3.
 int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // launch only; igemm_launch validates
 int igemm3dw_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3dw.hip)
 int igemm3s2_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3s2.hip)
+int conv3p_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3p.hip)
+bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
+bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the
 // per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)
@@ -136,6 +145,17 @@ int power_map_launch(const float* ambi, long T, const float* sh, int P, float* r
 // NO_SEPARATION decoder (model.py:274-280, 430): out[b,n,o] = w[b,step,o,0]*mono + bias
 int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B, int snd_size,
                      int snd_contx, int snd_dur, int num_out, hipStream_t s);
+
+// -----------------------------------------------------------------------------------------
+// P3 activation planes (p3.hip): [C/16][B*H*(W+1)][3][16] bf16, one zero pixel after every image row
+// -----------------------------------------------------------------------------------------
+size_t p3_bytes(int B, int H, int W, int C);
+// y = [relu](x*scale + shift [+ residual]) -> fp32 NHWC `y` (or null) and / or planes `p3` (or null)
+int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
+                   float* y, void* p3, int B, int H, int W, int C, hipStream_t s);
+// 3x3/2 SAME max-pool of relu(bn(x)) -> fp32 NHWC `y` (or null) and planes `p3` (or null) of the pooled tensor
+int p3_maxpool_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, void* p3, int B, int H,
+                      int W, int C, hipStream_t s);
 
 // -----------------------------------------------------------------------------------------
 // FFT family (fft.hip)

@@ -1,0 +1,203 @@
+// Producers of "P3" activation tensors: the operand format of conv3p_kernel (conv3p.hip).
+//
+// A P3 tensor holds an NHWC fp32 activation [B,H,W,C] (C % 16 == 0) as its three bf16 planes hi / mid / lo
+// (hi = rne(v), mid = rne(v - hi), lo = rne(v - hi - mid); both residuals exact in fp32; hi + mid + lo carries
+// 24 mantissa bits), laid out [C/16][NP][3][16] with NP = B*H*(W+1): every image row is followed by one ZERO pixel,
+// which serves as the right-hand SAME padding of its row and the left-hand padding of the next.  The split is done
+// here, once per element, by the HBM-bound pass that has to touch the tensor anyway:
+//   * p3_pack_kernel     y = [relu]( x*scale + shift [+ residual] )  ->  fp32 NHWC (optional) + P3 (optional)
+//                        = tf batch_norm(is_training) + ReLU of conv_1 and the residual merge (resnet.py:215-221, 230-235)
+//   * p3_maxpool_kernel  3x3/2 SAME max-pool of relu(bn(x)) (resnet.py:134-135) -> fp32 NHWC + P3
+// Each thread owns 8 consecutive channels of one pixel: two 16-byte loads, three 16-byte plane stores.
+#include "igemm3_common.h"
+
+namespace sagen {
+
+size_t p3_bytes(int B, int H, int W, int C) { return (size_t)(C / 16) * B * H * (W + 1) * 96; }
+
+// scale / shift of 4 consecutive channels (same derivation as elementwise.hip)
+__device__ __forceinline__ void p3_bn4(const float* scale, const float* shift, const BnRef& bn, int C, int c0, float4& sc, float4& sh) {
+    if (bn.acc != nullptr) {
+        float s4[4], h4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            const double mean = bn.acc[c] * bn.inv_count;
+            double var = bn.acc[C + c] * bn.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double a = (double)bn.gamma[c] / sqrt(var + (double)bn.eps);
+            s4[k] = (float)a;
+            h4[k] = (float)((double)bn.beta[c] - mean * a);
+        }
+        sc = make_float4(s4[0], s4[1], s4[2], s4[3]);
+        sh = make_float4(h4[0], h4[1], h4[2], h4[3]);
+    } else if (scale != nullptr) {
+        sc = *reinterpret_cast<const float4*>(scale + c0);
+        sh = *reinterpret_cast<const float4*>(shift + c0);
+    } else {
+        sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// 8 fp32 values -> the three bf16 planes (8 bf16 = 16 bytes each)
+__device__ __forceinline__ void p3_split8(float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hi[k] = split_pair(v[2 * k], v[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mid[k] = split_pair(v[2 * k], v[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lo[k] = split_pair(v[2 * k], v[2 * k + 1]);
+}
+
+__device__ __forceinline__ void p3_store(char* p3, long cstride, long pp, int c8, const u32x4& hi, const u32x4& mid, const u32x4& lo) {
+    char* dst = p3 + (long)(c8 >> 1) * cstride + pp * 96 + (c8 & 1) * 16;
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 32) = mid;
+    *reinterpret_cast<u32x4*>(dst + 64) = lo;
+}
+
+__global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const BnRef bn,
+                                                      const float* __restrict__ res, int relu, float* __restrict__ y,
+                                                      char* __restrict__ p3, long nrows, int W, int C) {
+    const int C8 = C >> 3;
+    const long total = nrows * (W + 1) * C8;             // padded pixels x channel octets (the grid stride is a multiple of C8)
+    const long cstride = nrows * (W + 1) * 96;
+    const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(t0 % C8);
+    float4 sc0, sh0, sc1, sh1;
+    p3_bn4(scale, shift, bn, C, 8 * c8, sc0, sh0);
+    p3_bn4(scale, shift, bn, C, 8 * c8 + 4, sc1, sh1);
+    for (long i = t0; i < total; i += (long)gridDim.x * 256) {
+        const long pp = i / C8;
+        const long row = pp / (W + 1);
+        const int w = (int)(pp - row * (W + 1));
+        float v[8];
+        if (w < W) {
+            const long e = (row * W + w) * C + 8 * c8;
+            const float4 a = *reinterpret_cast<const float4*>(x + e), b = *reinterpret_cast<const float4*>(x + e + 4);
+            v[0] = fmaf(a.x, sc0.x, sh0.x); v[1] = fmaf(a.y, sc0.y, sh0.y); v[2] = fmaf(a.z, sc0.z, sh0.z); v[3] = fmaf(a.w, sc0.w, sh0.w);
+            v[4] = fmaf(b.x, sc1.x, sh1.x); v[5] = fmaf(b.y, sc1.y, sh1.y); v[6] = fmaf(b.z, sc1.z, sh1.z); v[7] = fmaf(b.w, sc1.w, sh1.w);
+            if (res) {
+                const float4 ra = *reinterpret_cast<const float4*>(res + e), rb = *reinterpret_cast<const float4*>(res + e + 4);
+                v[0] += ra.x; v[1] += ra.y; v[2] += ra.z; v[3] += ra.w; v[4] += rb.x; v[5] += rb.y; v[6] += rb.z; v[7] += rb.w;
+            }
+            if (relu) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (y) {
+                *reinterpret_cast<float4*>(y + e) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(y + e + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        if (p3) {
+            u32x4 hi, mid, lo;
+            p3_split8(v, hi, mid, lo);
+            p3_store(p3, cstride, pp, c8, hi, mid, lo);
+        }
+    }
+}
+
+// grid whose stride (grid*256 threads) is a multiple of `unit_threads`, so per-thread channel groups are loop-invariant
+static int aligned_grid(long total, int unit_threads) {
+    long g = std::min<long>(cdiv(total, 256), 256L * 16);
+    long a = 256, b = unit_threads;
+    while (b) { const long t = a % b; a = b; b = t; }
+    const long unit = unit_threads / a;                  // smallest g with (g*256) % unit_threads == 0
+    g = std::max<long>(unit, g / unit * unit);
+    return (int)g;
+}
+
+int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
+                   float* y, void* p3, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 16) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: C=%d must be a multiple of 16", C);
+    if (!y && !p3) return fail(SAGEN_ERR_NULL, "p3_pack: no output");
+    const long nrows = (long)B * H;
+    if (p3_bytes(B, H, W, C) >= (1UL << 31)) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: tensor exceeds 2 GiB buffer addressing");
+    const long total = nrows * (W + 1) * (C / 8);
+    hipLaunchKernelGGL(p3_pack_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+                       (char*)p3, nrows, W, C);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// tf.nn.max_pool(x,[1,3,3,1],[1,2,2,1],'SAME') (resnet.py:135) of relu(bn(x)), -inf padding; see elementwise.hip
+__global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const BnRef bn, float* __restrict__ y,
+                                                         char* __restrict__ p3, int B, int H, int W, int C, int Ho, int Wo,
+                                                         int pt, int pl) {
+    const int C8 = C >> 3;
+    const long nrows = (long)B * Ho;
+    const long total = nrows * (Wo + 1) * C8;
+    const long cstride = nrows * (Wo + 1) * 96;
+    const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(t0 % C8);
+    float4 sc0, sh0, sc1, sh1;
+    p3_bn4(scale, shift, bn, C, 8 * c8, sc0, sh0);
+    p3_bn4(scale, shift, bn, C, 8 * c8 + 4, sc1, sh1);
+    const bool has_bn = scale != nullptr || bn.acc != nullptr;
+    for (long i = t0; i < total; i += (long)gridDim.x * 256) {
+        const long pp = i / C8;
+        const long row = pp / (Wo + 1);
+        const int wo = (int)(pp - row * (Wo + 1));
+        const int ho = (int)(row % Ho);
+        const long b = row / Ho;
+        float v[8];
+        if (wo < Wo) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = -INFINITY;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int h = ho * 2 + dy - pt;
+                if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int w = wo * 2 + dx - pl;
+                    if ((unsigned)w >= (unsigned)W) continue;
+                    const long e = ((b * H + h) * W + w) * C + 8 * c8;
+                    const float4 a = *reinterpret_cast<const float4*>(x + e), bq = *reinterpret_cast<const float4*>(x + e + 4);
+                    v[0] = fmaxf(v[0], fmaf(a.x, sc0.x, sh0.x)); v[1] = fmaxf(v[1], fmaf(a.y, sc0.y, sh0.y));
+                    v[2] = fmaxf(v[2], fmaf(a.z, sc0.z, sh0.z)); v[3] = fmaxf(v[3], fmaf(a.w, sc0.w, sh0.w));
+                    v[4] = fmaxf(v[4], fmaf(bq.x, sc1.x, sh1.x)); v[5] = fmaxf(v[5], fmaf(bq.y, sc1.y, sh1.y));
+                    v[6] = fmaxf(v[6], fmaf(bq.z, sc1.z, sh1.z)); v[7] = fmaxf(v[7], fmaf(bq.w, sc1.w, sh1.w));
+                }
+            }
+            if (has_bn) {           // relu commutes with max
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (y) {
+                const long e = (row * Wo + wo) * C + 8 * c8;
+                *reinterpret_cast<float4*>(y + e) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(y + e + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        if (p3) {
+            u32x4 hi, mid, lo;
+            p3_split8(v, hi, mid, lo);
+            p3_store(p3, cstride, pp, c8, hi, mid, lo);
+        }
+    }
+}
+
+int p3_maxpool_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, void* p3, int B, int H,
+                      int W, int C, hipStream_t s) {
+    if (C % 16) return fail(SAGEN_ERR_UNSUPPORTED, "p3_maxpool: C=%d must be a multiple of 16", C);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
+    const long total = (long)B * Ho * (Wo + 1) * (C / 8);
+    hipLaunchKernelGGL(p3_maxpool_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, y, (char*)p3, B, H,
+                       W, C, Ho, Wo, pth / 2, ptw / 2);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+}  // namespace sagen
