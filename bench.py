@@ -217,9 +217,9 @@ def main():
     except Exception:
         pass
     step_tflops = GFLOP_PER_WINDOW * BATCH / (ms_per_step * 1e-3) / 1e3          # throughput-based (steps overlap when NF > 1)
-    b3 = dom.startswith('igemm3')            # igemm3_kernel / igemm3dw_kernel / igemm3s2_kernel: the bf16x3 family
+    b3 = dom.startswith('igemm3') or dom.startswith('conv3p')   # igemm3 / igemm3dw / igemm3s2 / conv3p kernels: the bf16x3 family
     peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
-    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3'))
+    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3') or k.startswith('conv3p'))
     f32_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm_kernel'))
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),

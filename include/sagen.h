@@ -207,6 +207,12 @@ int sagen_eval_metrics(const float* pred_yzx, const float* target_yzx, int batch
  * The rms buffer must hold P + 24 floats (the tail is used for the 4x4 second-moment matrix). */
 int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, float* rms, void* stream);
 
+/* One map per chunk: SphericalAmbisonicsVisualizer.loop_frames (pyutils/ambisonics/distance.py:41-59) yields one RMS map
+ * per `window` seconds of audio; ambix_emd (distance.py:133-143, called at eval.py:190) compares them frame by frame.
+ * ambi_wyzx [nchunks, T, 4] (chunks back to back); rms [nchunks, P]; moments = caller scratch of nchunks*10 doubles. */
+int sagen_power_map_batched(const float* ambi_wyzx, int nchunks, int64_t t, const float* sh, int p, float* rms, double* moments,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

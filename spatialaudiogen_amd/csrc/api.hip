@@ -339,4 +339,13 @@ int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, f
     return power_map_launch(ambi_wyzx, t, sh, p, rms, (hipStream_t)stream);
 }
 
+int sagen_power_map_batched(const float* ambi_wyzx, int nchunks, int64_t t, const float* sh, int p, float* rms, double* moments,
+                            void* stream) {
+    if (!ambi_wyzx || !sh || !rms || !moments) return fail(SAGEN_ERR_NULL, "sagen_power_map_batched: null argument");
+    if (nchunks <= 0 || t <= 0 || p <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_power_map_batched: bad sizes");
+    if (((uintptr_t)moments) % 8 || ((uintptr_t)ambi_wyzx) % 16 || ((uintptr_t)sh) % 16)
+        return fail(SAGEN_ERR_SHAPE, "sagen_power_map_batched: ambi / sh must be 16-byte aligned, moments 8-byte aligned");
+    return power_map_batched_launch(ambi_wyzx, nchunks, t, sh, p, rms, moments, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
     constexpr int ST_BYTES = A_BYTES + B_BYTES;
     constexpr int NM1 = 6 * MT * NT;                       // MFMAs per tap
     constexpr int NMG = 3 * NM1;                           // MFMAs per group
-    constexpr int EPI_BYTES = BM * (int)sizeof(RowInfo) + 2 * WAVES_M * BN * 4;
+    constexpr int EPI_BYTES = BM * BN * 4 + BM * 4 + 2 * (256 / (BN / 4)) * BN * 4;
     constexpr int SMEM_BYTES = STAGES * ST_BYTES + 256 > EPI_BYTES ? STAGES * ST_BYTES + 256 : EPI_BYTES;   // +256: reads of the dropped rows
     // ONE shared object: a second __shared__ array makes hipcc drain vmcnt before the ds_reads of every step
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
@@ -62,6 +62,13 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int gm = gridDim.x;
+#ifdef SAGEN_TRACE      // dev builds: s_memtime stamps of every workgroup's wave 0 -> d.trace[block][16]
+    unsigned long long* trc = (d.trace && wave == 0 && blockIdx.y == 0) ? (unsigned long long*)d.trace + (size_t)blockIdx.x * 16 : nullptr;
+#define TRC(k) do { if (trc && lane == 0) trc[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TRC(k) do { } while (0)
+#endif
+    TRC(0);
     int tile_m;
     {   // XCD-aware remap: each XCD (own L2) owns a contiguous run of M tiles (neighbours share halo rows and the filter)
         const int bid = blockIdx.x;
@@ -78,26 +85,6 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
     const __amdgpu_buffer_rsrc_t w_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(d.w + (size_t)d.N * d.Kpad), 0, d.w_bytes / 2 * 3, 0x00020000);
 
-    // ---- activation DMA lanes: unit U of the stage image = (slot, plane, half); slot <-> padded pixel m0 - 1 + slot ----
-    unsigned a_v0[A_PW], a_v1[A_PW], a_v2[A_PW], a_cur[A_PW];     // per vertical tap dh = -1 / 0 / +1; the current one
-#pragma unroll
-    for (int j = 0; j < A_PW; ++j) {
-        const int inst = wave + 4 * j;
-        const int U = inst * 64 + lane;
-        const int slot = U / 6, rem = U - 6 * slot;
-        const int pl = rem >> 1, half = rem & 1;
-        const int p = m0 - 1 + slot;
-        unsigned bad = 7u;
-        if (inst < A_INST && p >= 0 && p < NP) {
-            const int h = (p / Wp) % H;
-            bad = (h == 0 ? 1u : 0u) | (h == H - 1 ? 4u : 0u);
-        }
-        const int base = p * 96 + pl * 32 + 16 * (half ^ ((slot >> 3) & 1));
-        a_v0[j] = (bad & 1u) ? OOB : (unsigned)(base - Wp * 96);
-        a_v1[j] = (bad & 2u) ? OOB : (unsigned)base;
-        a_v2[j] = (bad & 4u) ? OOB : (unsigned)(base + Wp * 96);
-        a_cur[j] = OOB;
-    }
     // ---- filter DMA lanes: per tap the image is [plane][BN rows][32 B] ----
     unsigned b_voff[B_PW];
     int b_tapoff[B_PW];                         // wave-uniform: byte offset of this slot's tap inside a (dh, chunk) group
@@ -110,6 +97,48 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
         b_voff[j] = (inst < B_INST && n0 + n < d.N) ? (unsigned)((pl * d.N + n0 + n) * 32 + 16 * (half ^ ((n >> 3) & 1))) : OOB;
         b_tapoff[j] = __builtin_amdgcn_readfirstlane(tap * nchunk * d.N * 96);
     }
+    // ---- K range of this split: groups (dh, chunk) ----
+    const int G = 3 * nchunk;
+    const int gper = (G + d.splitk - 1) / d.splitk;
+    const int g0 = z * gper;
+    const int g1 = min(G, g0 + gper);
+    const int ngroups = max(g1 - g0, 0);
+
+    // the filter tiles of the first group go out NOW: they only need n0 / lane, and fly while the activation lanes are set up
+    {
+        const int dh0 = g0 / nchunk, ch0 = g0 - dh0 * nchunk;
+        const unsigned bs0 = (unsigned)((dh0 * 3) * nchunk + ch0) * (unsigned)(d.N * 96);
+        if (ngroups > 0) {
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j) {
+                const int inst = wave + 4 * j;
+#ifndef P3_ABLATE_DMA
+                if (4 * (j + 1) <= B_INST || inst < B_INST) dma16(w_rsrc, (float*)(smem + A_BYTES + inst * 1024), b_voff[j], bs0 + (unsigned)b_tapoff[j]);
+#endif
+            }
+        }
+    }
+    // ---- activation DMA lanes: unit U of the stage image = (slot, plane, half); slot <-> padded pixel m0 - 1 + slot ----
+    unsigned a_v0[A_PW], a_v1[A_PW], a_v2[A_PW], a_cur[A_PW];     // per vertical tap dh = -1 / 0 / +1; the current one
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int inst = wave + 4 * j;
+        const int U = inst * 64 + lane;
+        const int slot = U / 6, rem = U - 6 * slot;
+        const int pl = rem >> 1, half = rem & 1;
+        const int p = m0 - 1 + slot;
+        unsigned bad = 7u;
+        if (inst < A_INST && p >= 0 && p < NP) {
+            const unsigned row = __umulhi((unsigned)p, d.p3_magic_wp);          // p / Wp  (exact: p * Wp < 2^32, conv3p_dispatch)
+            const int h = (int)(row - __umulhi(row, d.p3_magic_h) * (unsigned)H);
+            bad = (h == 0 ? 1u : 0u) | (h == H - 1 ? 4u : 0u);
+        }
+        const int base = p * 96 + pl * 32 + 16 * (half ^ ((slot >> 3) & 1));
+        a_v0[j] = (bad & 1u) ? OOB : (unsigned)(base - Wp * 96);
+        a_v1[j] = (bad & 2u) ? OOB : (unsigned)base;
+        a_v2[j] = (bad & 4u) ? OOB : (unsigned)(base + Wp * 96);
+        a_cur[j] = OOB;
+    }
     // number of DMA instructions this wave issues per group (wave-uniform; differs by at most 2 between waves)
     int my_cnt = 0;
 #pragma unroll
@@ -118,13 +147,6 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
     for (int j = 0; j < B_PW; ++j) my_cnt += (wave + 4 * j < B_INST) ? 1 : 0;
     my_cnt = __builtin_amdgcn_readfirstlane(my_cnt);
     constexpr int CNT_MAX = A_PW + B_PW;
-
-    // ---- K range of this split: groups (dh, chunk) ----
-    const int G = 3 * nchunk;
-    const int gper = (G + d.splitk - 1) / d.splitk;
-    const int g0 = z * gper;
-    const int g1 = min(G, g0 + gper);
-    const int ngroups = max(g1 - g0, 0);
 
     // issue state (SGPRs): the group being issued
     int q_dh = g0 / nchunk, q_ch = g0 - q_dh * nchunk, cur_dh = -1;
@@ -187,13 +209,15 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
 
     constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // hh, hm, mh, hl, lh, mm
 
+    TRC(1);
     // ---- pipeline fill ----
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < ngroups) {
             begin_issue(t);
 #pragma unroll
-            for (int s = 0; s < CNT_MAX; ++s) issue_one(s);
+            for (int s = 0; s < CNT_MAX; ++s)
+                if (t > 0 || s < A_PW) issue_one(s);          // (the first group's filter tiles were issued at kernel entry)
         }
 
     int stage = 0;
@@ -207,17 +231,27 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
         if (istage >= STAGES) istage -= STAGES;
         if (MORE) begin_issue(istage);
         const char* st = smem + stage * ST_BYTES;
-#pragma unroll
-        for (int dwi = 0; dwi < 3; ++dwi) {
-            bf16x8 aq[3][MT], bq[3][NT];
+        // fragments double-buffered over the three horizontal taps: the reads of tap t+1 are issued before the MFMAs of tap t,
+        // so only the first read burst after the barrier is exposed
+        bf16x8 aq[2][3][MT], bq[2][3][NT];
+        auto load_frags = [&](int buf, int dwi) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) aq[pl][i] = *reinterpret_cast<const bf16x8*>(st + a_foff[dwi][i] + pl * 32);
+                for (int i = 0; i < MT; ++i) aq[buf][pl][i] = *reinterpret_cast<const bf16x8*>(st + a_foff[dwi][i] + pl * 32);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    bq[pl][j] = *reinterpret_cast<const bf16x8*>(st + b_foff + (dwi * 3 + pl) * (BN * 32) + j * 32 * 32);
+                    bq[buf][pl][j] = *reinterpret_cast<const bf16x8*>(st + b_foff + (dwi * 3 + pl) * (BN * 32) + j * 32 * 32);
             }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int dwi = 0; dwi < 3; ++dwi) {
+            const int cb = dwi & 1;
+#ifndef P3_NO_SCHED
+            __builtin_amdgcn_sched_barrier(0);            // one scheduling region per tap (hipcc otherwise sinks the prefetch reads to their use)
+#endif
+            if (dwi < 2) load_frags(cb ^ 1, dwi + 1);
 #pragma unroll
             for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
@@ -225,9 +259,9 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
 #ifndef P3_ABLATE_MFMA
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[TA[tt]][i], bq[TB[tt]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[cb][TA[tt]][i], bq[cb][TB[tt]][j], acc[i][j], 0, 0, 0);
 #else
-                        asm volatile("" ::"v"(aq[TA[tt]][i]), "v"(bq[TB[tt]][j]));
+                        asm volatile("" ::"v"(aq[cb][TA[tt]][i]), "v"(bq[cb][TB[tt]][j]));
 #endif
                         const int idx = dwi * NM1 + (tt * MT + i) * NT + j;
                         // DMA slot s goes out after MFMA (s+1)*NMG/(CNT_MAX+1) - 1: spread over the group's MFMAs
@@ -241,36 +275,111 @@ __global__ __launch_bounds__(256, (STAGES == 2 && BM * 96 + BN * 288 <= 36 * 102
                             if (MORE && idx == (s + 1) * NMG / (CNT_MAX + 1) - 1) issue_one(s);
 #endif
                     }
+#ifndef P3_NO_SCHED
+            // issue order of the region: one fragment read of the next tap behind each of the first MFMAs, DMAs behind their MFMA
+#pragma unroll
+            for (int k = 0; k < NM1; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+                if (dwi < 2 && k < 3 * (MT + NT)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+#pragma unroll
+                for (int s = 0; s < CNT_MAX; ++s)
+                    if (MORE && dwi * NM1 + k == (s + 1) * NMG / (CNT_MAX + 1) - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
     };
     {
         const int nmore = max(ngroups - (STAGES - 1), 0);       // groups during which a later group is issued
         int it = 0;
-        for (; it < nmore; ++it) group(std::true_type{}, STAGES == 3);
+        TRC(2);
+        for (; it < nmore; ++it) { group(std::true_type{}, STAGES == 3); if (it == 0) TRC(3); }
         for (; it < ngroups; ++it) group(std::false_type{}, STAGES == 3 && it + 1 < ngroups);
     }
+    TRC(4);
     wait_vmcnt_n<0>();
     __syncthreads();
 
-    // ---- epilogue: per-row output geometry (pad pixels, the two overlap rows and rows >= NP are dropped) ----
-    RowInfo* s_row = reinterpret_cast<RowInfo*>(smem);
-    float* red = reinterpret_cast<float*>(smem + BM * sizeof(RowInfo));
+    // ---- epilogue: the tile goes through LDS so that every output row leaves as 16-byte coalesced stores ----
+    // (the element-wise MFMA-layout epilogue of igemm_common.h cost 15k cycles per 128x64 tile here - a third of the
+    //  workgroup's life at K = 576; this one ~2k.)  Pad pixels, the two overlap rows and rows >= NP are dropped.
+    constexpr int TPR = BN / 4;                    // threads per output row (one float4 each)
+    constexpr int RPP = 256 / TPR;                 // rows per pass
+    float* tile = reinterpret_cast<float*>(smem);                              // [BM][BN]
+    int* s_dense = reinterpret_cast<int*>(smem + BM * BN * 4);                 // [BM] dense pixel index or -1
+    float* red = reinterpret_cast<float*>(smem + BM * BN * 4 + BM * 4);        // [2][RPP][BN]
+    static_assert(BM * BN * 4 + BM * 4 + 2 * RPP * BN * 4 <= SMEM_BYTES, "epilogue staging must fit the tile ring");
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)          // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+                tile[(wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = acc[i][j][e];
     for (int r = tid; r < BM; r += 256) {
         const int p = m0 + r;
-        RowInfo ri;
-        ri.boff = 0; ri.nmlo = 0; ri.nmhi = 0; ri.hrem = 0; ri.wrem = 0; ri.pad = 0; ri.rowoff = 0;
+        int dense = -1;
         if (r < BME && p < NP) {
-            const int row = p / Wp, w = p - row * Wp;           // row = b*H + h
-            if (w < W) {
-                ri.hrem = 1; ri.wrem = 1;
-                ri.rowoff = ((long)row * W + w) * d.ldy;
-            }
+            const int row = (int)__umulhi((unsigned)p, d.p3_magic_wp);   // p / Wp = b*H + h: one pad pixel per preceding row
+            if (p - row * Wp < W) dense = p - row;
         }
-        s_row[r] = ri;
+        s_dense[r] = dense;
     }
     __syncthreads();
-    igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, red, m0, n0, z, tid);
+    TRC(5);
+    {
+        const int c4 = tid % TPR, rg = tid / TPR;
+        const int n = n0 + 4 * c4;
+        const bool full = n + 3 < d.N, vec_ok = full && (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) {
+            bias.x = n < d.N ? d.bias[n] : 0.f; bias.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
+            bias.z = n + 2 < d.N ? d.bias[n + 2] : 0.f; bias.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
+        }
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int NPASS = BM / RPP;
+        // all LDS reads first (independent), then the stores: one latency, not NPASS of them
+        int dn[NPASS];
+        float4 tv[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) dn[k] = s_dense[rg + k * RPP];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) tv[k] = *reinterpret_cast<const float4*>(tile + (rg + k * RPP) * BN + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            if (dn[k] < 0) continue;
+            float4 v = tv[k];
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            if (d.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            float* dst = d.y + (long)dn[k] * d.ldy + n;
+            if (vec_ok) *reinterpret_cast<float4*>(dst) = v;
+            else {
+                if (n < d.N) dst[0] = v.x;
+                if (n + 1 < d.N) dst[1] = v.y;
+                if (n + 2 < d.N) dst[2] = v.z;
+                if (n + 3 < d.N) dst[3] = v.w;
+            }
+        }
+        if (d.stats != nullptr) {                 // per-channel (sum, sumsq) of the raw output -> fp64 accumulators [2][N]
+            *reinterpret_cast<float4*>(red + (0 * RPP + rg) * BN + 4 * c4) = cs;
+            *reinterpret_cast<float4*>(red + (1 * RPP + rg) * BN + 4 * c4) = cq;
+            __syncthreads();
+            for (int t = tid; t < 2 * BN; t += 256) {
+                const int which = t / BN, col = t - which * BN;
+                if (n0 + col < d.N) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < RPP; ++g) sum += red[(which * RPP + g) * BN + col];
+                    atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
+                }
+            }
+        }
+    }
+    TRC(6);
+#undef TRC
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES>
@@ -281,9 +390,13 @@ static int launch_conv3p(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-int conv3p_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s) {
+int conv3p_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
+    IgemmDesc d = d_in;
     if (!d.xp3 || d.p3_np <= 0) return fail(SAGEN_ERR_NULL, "conv3p: the P3 activation planes are missing");
     if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: no split-K");
+    if ((long)(d.p3_np + 512) * (d.Win + 1) >= (1L << 32)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: too many pixels for 32-bit index arithmetic");
+    d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)(d.Win + 1)) + 1u;
+    d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hin) + 1u;
     switch (tile) {
         case TILE_P3_128x64: return launch_conv3p<128, 64, 64, 32, 2>(d, s);
         case TILE_P3_128x128: return launch_conv3p<128, 128, 64, 64, 2>(d, s);

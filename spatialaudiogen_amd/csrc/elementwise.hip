@@ -267,6 +267,54 @@ __global__ __launch_bounds__(256) void power_map_kernel(const double* __restrict
     rms[p] = (float)sqrt(fmax(e, 0.0) * inv_T);
 }
 
+// One map per chunk of T samples, `nchunks` chunks back to back (SphericalAmbisonicsVisualizer.loop_frames,
+// distance.py:41-59: one RMS map per 0.1 s window): block b reduces the second moments of chunk b (no atomics).
+__global__ __launch_bounds__(256) void power_moments_batched_kernel(const float4* __restrict__ ambi, long T, double* __restrict__ S) {
+    const float4* a4 = ambi + (long)blockIdx.x * T;
+    float m[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m[k] = 0.f;
+    for (long t = threadIdx.x; t < T; t += 256) {
+        const float4 a = a4[t];
+        m[0] += a.x * a.x; m[1] += a.x * a.y; m[2] += a.x * a.z; m[3] += a.x * a.w;
+        m[4] += a.y * a.y; m[5] += a.y * a.z; m[6] += a.y * a.w;
+        m[7] += a.z * a.z; m[8] += a.z * a.w; m[9] += a.w * a.w;
+    }
+    __shared__ float red[4][10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        float v = m[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10)
+        S[(long)blockIdx.x * 10 + threadIdx.x] = (double)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void power_map_batched_kernel(const double* __restrict__ Sall, double inv_T, const float4* __restrict__ sh,
+                                                                int P, float* __restrict__ rms) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const double* S = Sall + (long)blockIdx.y * 10;
+    const float4 y = sh[p];
+    const double v[4] = {y.x, y.y, y.z, y.w};
+    const double s[4][4] = {{S[0], S[1], S[2], S[3]}, {S[1], S[4], S[5], S[6]}, {S[2], S[5], S[7], S[8]}, {S[3], S[6], S[8], S[9]}};
+    double e = 0.0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) e += v[i] * s[i][j] * v[j];
+    rms[(long)blockIdx.y * P + p] = (float)sqrt(fmax(e, 0.0) * inv_T);
+}
+
+int power_map_batched_launch(const float* ambi, int nchunks, long T, const float* sh, int P, float* rms, double* moments, hipStream_t s) {
+    hipLaunchKernelGGL(power_moments_batched_kernel, dim3(nchunks), dim3(256), 0, s, (const float4*)ambi, T, moments);
+    SAGEN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(power_map_batched_kernel, dim3(cdiv(P, 256), nchunks), dim3(256), 0, s, moments, 1.0 / (double)T, (const float4*)sh, P, rms);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 // scratch for the moments lives at the head of rms' caller-provided buffer? No: keep it explicit.
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s) {
     // 10 doubles of scratch are taken from a static per-device buffer allocated lazily would break

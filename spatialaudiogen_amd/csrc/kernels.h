@@ -61,6 +61,7 @@ struct IgemmDesc {
     const void* xp3 = nullptr;
     unsigned xp3_bytes = 0, xp3_cstride = 0;
     int p3_np = 0;
+    unsigned p3_magic_wp = 0, p3_magic_h = 0;   // filled by conv3p_dispatch: floor(2^32 / d) + 1 for d = Win + 1, Hin (exact quotients by mul-hi)
     // debug builds (-DSAGEN_TRACE): phase timeline of workgroup `trace_block`
     void* trace = nullptr;
     int trace_block = 0;
@@ -142,6 +143,8 @@ int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, i
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);
+// one map per chunk of T samples: ambi [nchunks][T][4] -> rms [nchunks][P]; moments = scratch of nchunks*10 doubles
+int power_map_batched_launch(const float* ambi, int nchunks, long T, const float* sh, int P, float* rms, double* moments, hipStream_t s);
 // NO_SEPARATION decoder (model.py:274-280, 430): out[b,n,o] = w[b,step,o,0]*mono + bias
 int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B, int snd_size,
                      int snd_contx, int snd_dur, int num_out, hipStream_t s);

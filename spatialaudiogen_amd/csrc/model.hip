@@ -60,6 +60,7 @@ struct sagen_ctx {
     std::map<std::string, bool> materialize;     // conv_2 layers: apply the producer's BN+ReLU in a separate pass?
     bool tuning = false;
     bool fp32_only = false;                      // SAGEN_FP32_ONLY=1: never use the bf16x3 tiles
+    bool use_p3 = true;                          // 3x3 stride-1 trunk convs read pre-split bf16 planes (conv3p.hip); SAGEN_NO_P3=1 disables
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
     hipStream_t aux = nullptr;
@@ -183,6 +184,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     sagen_ctx* c = new sagen_ctx();
 
     c->fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
+    c->use_p3 = !c->fp32_only && getenv("SAGEN_NO_P3") == nullptr;
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
@@ -289,8 +291,12 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         c->alloc("y0" + x, (size_t)B * 112 * 224 * 64);
         const size_t stage = (size_t)B * 56 * 112 * 64;
         for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc", "ry1n"}) c->alloc(nm + x, stage);
+        c->alloc("p3" + x, (p3_bytes(B, 56, 112, 64) + 3) / 4 + 64);   // bf16 planes of the current 3x3 conv input (largest: stage 2)
         c->alloc("bnacc" + x, (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer
         c->alloc("fcred" + x, (size_t)B * 98 * 128);
+        // trunk output (block conv5_2) for parity tests: the ping-pong lands in rx0 after the 8 blocks
+        const std::string enc = (set == 1 || !c->has_video) ? "flow_encoder" : "video_encoder";
+        c->expose(enc + "/conv5_2", "rx0" + x, 0, {B, 7, 14, 512}, 512);
     }
     // intermediates for parity tests
     c->expose("mag", "mag", 0, {B, 127, 1024, 1}, 1);
@@ -478,7 +484,7 @@ struct Fwd {
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;
             for (int sk : SKS) {
-                if (sk > 1 && (!allow_split || !dense)) break;
+                if (sk > 1 && (!allow_split || !dense || igemm_tile_p3(tile))) break;
                 if (sk > 1 && (nk / sk < 4 || (size_t)sk * d.M * d.N > ws_capacity())) break;
                 if (sk == 1 && rep > 1 && (size_t)d.M * d.N > ws_capacity()) continue;
                 const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn) * sk;
@@ -526,7 +532,7 @@ struct Fwd {
         } else if (it != c->plan.end()) {
             ch = it->second;
             if (!igemm_tile_ok(d, (IgemmTile)ch.tile)) ch = heuristic(d, rep, allow_split);
-            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || d.Kpad / igemm_tile_bk((IgemmTile)ch.tile) / ch.splitk < 1)) ch.splitk = 1;
+            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || igemm_tile_p3((IgemmTile)ch.tile) || d.Kpad / igemm_tile_bk((IgemmTile)ch.tile) / ch.splitk < 1)) ch.splitk = 1;
         } else {
             ch = heuristic(d, rep, allow_split);
         }
@@ -613,10 +619,17 @@ struct Fwd {
     // conv of the ResNet trunk: raw output + batch statistics into accumulator `bn_index`; `bn_in` = the producer's
     // batch-norm + ReLU applied to the input on the fly
     void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
-                 const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index, const std::string& plan_key = "") {
+                 const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index, const std::string& plan_key = "",
+                 const void* planes = nullptr) {
         if (rc) return;
         IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
                                 Cout, Hout, Wout);
+        if (planes) {                       // the input as pre-split bf16 planes (p3.hip); x may be null then
+            d.xp3 = planes;
+            d.p3_np = c->B * Hin * (Win + 1);
+            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
+            d.xp3_bytes = (unsigned)p3_bytes(c->B, Hin, Win, Cin);
+        }
         d.bn_in = bn_in;
         d.stats = bn_acc(bn_index);
         layer = plan_key.empty() ? name : plan_key;
@@ -645,7 +658,10 @@ struct Fwd {
             layer = name;
             contract(d);
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
-            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
+            if (c->use_p3)       // pooled block input as fp32 (residual) AND as planes (operand of conv2_1/conv_1)
+                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s); });
+            else
+                timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
         }
@@ -668,10 +684,27 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li);
+                void* planes = c->use_p3 ? (void*)c->p("p3" + sfx) : nullptr;
+                // stride-1 conv_1: its input planes were written by the pool / the previous block's merge
+                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "",
+                        stride == 1 ? planes : nullptr);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
+                if (c->use_p3) {
+                    // relu(bn1(y1)) -> planes (one elementwise pass), conv_2 on the planes, then the residual merge, which also
+                    // writes the planes of the block output when the next conv_1 is a stride-1 3x3 (unit 1 of a stage)
+                    layer = pfx + "/bn1-relu";
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, 1, nullptr, planes, B, Ho, Wo, cout, s); });
+                    conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes);
+                    const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
+                    layer = pfx + "/merge";
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, xout, unit == 1 ? planes : nullptr, B, Ho, Wo, cout, s); });
+                    ++li;
+                    std::swap(xin, xout);
+                    H = Ho; W = Wo; cin = cout;
+                    continue;
+                }
                 // conv_2 input = relu(bn1(y1)): on the fly in the conv's fragment path, or materialised once
                 // (cheaper for the small late-stage tensors, where every wave would redo the transform)
                 const std::string l2 = pfx + "/conv_2";

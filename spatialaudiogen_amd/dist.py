@@ -24,8 +24,8 @@ def init_process_group(backend=None):
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world == 1:
         return 0, 1
-    if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend is None:          # RCCL ('nccl') on GPUs; SAGEN_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests)
+        backend = os.environ.get('SAGEN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group(backend, rank=int(os.environ['RANK']), world_size=world)
@@ -33,23 +33,34 @@ def init_process_group(backend=None):
 
 
 class MetricReducer(object):
-    """Per-rank float64 sums + sample count -> global means with ONE all-reduce (232 bytes for the 28
-    metric sums of eval.py:125-133)."""
+    """Per-rank float64 (sum, count) per metric + sample count -> global means with ONE all-reduce (2*18+1 doubles for the
+    on-graph metrics of eval.py:125-133).  Non-finite per-sample values (the SNR of a masked channel is 0/0) are left
+    out of that metric's mean and count."""
 
     def __init__(self, names, device=None):
         import torch
         self.names = list(names)
-        self.buf = torch.zeros(len(self.names) + 1, dtype=torch.float64, device=device)
+        self.k = len(self.names)
+        self.buf = torch.zeros(2 * self.k + 1, dtype=torch.float64, device=device)
+
+    def add_rows(self, rows):
+        """rows [n, k]: one row of metric values per sample."""
+        import numpy as np
+        import torch
+        rows = np.asarray(rows, np.float64).reshape(-1, self.k)
+        ok = np.isfinite(rows)
+        upd = np.concatenate([np.where(ok, rows, 0.0).sum(0), ok.sum(0).astype(np.float64), [float(rows.shape[0])]])
+        self.buf += torch.as_tensor(upd, dtype=torch.float64, device=self.buf.device)
 
     def add(self, values, count):
-        import torch
-        self.buf[:-1] += torch.as_tensor(values, dtype=torch.float64, device=self.buf.device) * count
-        self.buf[-1] += count
+        """`count` samples that all have the metric values `values`."""
+        import numpy as np
+        self.add_rows(np.tile(np.asarray(values, np.float64).reshape(1, -1), (int(count), 1)))
 
     def reduce(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.buf)
-        total = float(self.buf[-1].item())
-        vals = (self.buf[:-1] / max(total, 1.0)).tolist()
-        return dict(zip(self.names, vals)), int(total)
+        sums, cnts = self.buf[:self.k], self.buf[self.k:2 * self.k]
+        vals = (sums / cnts.clamp(min=1.0)).tolist()
+        return dict(zip(self.names, vals)), int(self.buf[-1].item())

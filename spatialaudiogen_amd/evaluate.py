@@ -6,7 +6,8 @@ GPUs.
 Per clip: every 10th 0.1 s window (`skip_rate=10`, feeder.py:379), batches of 16 (eval.py:44), input = W channel with
 1 s of context, target = Y,Z,X of the centre 0.1 s (eval.py:68-72), channel masks per clip (feeder.py:312-314,
 `meta/audio_layouts.txt`).  Each rank owns a contiguous block of clips (whole batches stay on one GPU because
-batch-norm runs on batch statistics); per-sample metric rows are written by rank 0 to `eval-detailed.txt` in the
+batch-norm runs on batch statistics; batches are cut from ONE global window order, so results do not depend on the number
+of ranks); per-sample metric rows are written by rank 0 to `eval-detailed.txt` in the
 reference's format, and the global means come from ONE all-reduce of float64 sums + count (RCCL).
 
 Host-only metrics of eval.py (mel-LSD via librosa, envelope distance via scipy.hilbert, EMD via pyemd) are outside
@@ -21,6 +22,7 @@ from .definitions import VIDEO, FLOW, NO_SEPARATION
 from .dist import init_process_group, shard_range, MetricReducer
 
 BATCH_SIZE = 16            # eval.py:44
+SKIP_RATE = 10             # feeder.py:379 (for_eval)
 METRIC_KEYS = ['amplitude/predicted', 'amplitude/gt',
                'mse/avg', 'mse/X', 'mse/Y', 'mse/Z', 'stft/avg', 'stft/X', 'stft/Y', 'stft/Z',
                'lsd/avg', 'lsd/X', 'lsd/Y', 'lsd/Z', 'snr/avg', 'snr/X', 'snr/Y', 'snr/Z']    # eval.py:125-133 (on-graph subset)
@@ -37,29 +39,43 @@ def read_layouts(fn):
     return out
 
 
-def clip_windows(reader):
-    """All samples of one clip as stacked arrays."""
-    chunks = list(reader.loop_chunks())
-    if not chunks:
-        return None
-    out = {'id': [c['id'] for c in chunks], 'ambix': np.stack([c['ambix'] for c in chunks], 0).astype(np.float32)}
-    for k in ('video', 'flow'):
-        if k in chunks[0]:
-            out[k] = np.stack([c[k] for c in chunks], 0).astype(np.float32)
-    return out
+def window_plan(db_dir, clip_ids):
+    """The GLOBAL evaluation order: clips in list order, within a clip every SKIP_RATE-th window of audio_pow.lst in time
+    order.  Only the (small) lists are read.  Returns [(clip_id, t)].
+
+    The reference fills one TF queue from 4 racing reader threads (feeder.py:372-410) and dequeues 16 at a time, so its
+    batch composition is not reproducible; because batch-norm runs on batch statistics the composition is part of the
+    result, and this driver therefore fixes it: batch b = windows [16 b, 16 b + 16) of this order - for ANY number of ranks."""
+    from .feeder import read_pow_list, select_times
+    plan = []
+    for yid in clip_ids:
+        times, powers = read_pow_list(os.path.join(db_dir, yid, 'audio_pow.lst'))
+        plan.extend((yid, t) for t in select_times(times, powers, skip_rate=SKIP_RATE))
+    return plan
+
+
+def batch_shard(n_windows, rank, world, partial_batch='drop'):
+    """Whole batches per rank: (first_batch, end_batch, n_batches).  The trailing partial batch is dropped like the
+    reference's queue drops it (dequeue_many blocks, eval.py:140-143 / feeder.py:412-419 stop with up to 31 samples
+    queued) or, with partial_batch='pad', evaluated zero-padded as the LAST batch."""
+    n_batches = n_windows // BATCH_SIZE + (1 if partial_batch == 'pad' and n_windows % BATCH_SIZE else 0)
+    lo, hi = shard_range(n_batches, rank, world)
+    return lo, hi, n_batches
 
 
 class Evaluator(object):
-    def __init__(self, net, params):
+    def __init__(self, net, params, power_maps=False):
         self.net, self.params = net, params
         self.ss = int(params.audio_rate * params.context) // 2
         self.t = int(params.audio_rate * 0.1)
         self.rows, self.ids = [], []
+        self.power_maps = power_maps
+        self.maps = []                    # per sample (pred map, gt map) [7,12] each (eval.py:190: ang_res=30)
+        self._sh = None
 
     def run_batch(self, ids, ambix, video, flow, masks):
-        """ambix [n<=16, 52799, 4]; masks [n, 4].  Short batches are zero-padded to 16 like the TF queue would never
-        do (it blocks) — the padded windows are dropped from the metrics but do enter batch-norm statistics, so a
-        clip list whose window count is not a multiple of 16 ends with one such batch per rank."""
+        """ambix [n<=16, 52799, 4]; masks [n, 4].  n < 16 only for the optional zero-padded final batch: its padded
+        windows are dropped from the metrics but do enter the batch-norm statistics."""
         import torch
         n = ambix.shape[0]
         pad = lambda x: x if x is None or n == BATCH_SIZE else np.concatenate([x, np.zeros((BATCH_SIZE - n,) + x.shape[1:], x.dtype)], 0)
@@ -72,65 +88,84 @@ class Evaluator(object):
         amp_p = pred.abs().amax(dim=(1, 2)); amp_g = target.abs().amax(dim=(1, 2))
         per = torch.stack([amp_p, amp_g], 1).cpu().numpy()
         S = [x.cpu().numpy() for x in (mse_ps, stft_ps, lsd_ps, snr_ps)]
+        if self.power_maps:
+            self._power_maps(a, pred, target, m, n)
         for i in range(n):
             row = [per[i, 0], per[i, 1]]
-            for arr in S:                       # eval.py:155-171 appends the RAW per-sample values (no x5e3 / x100)
+            for k, arr in enumerate(S):         # eval.py:155-171 appends the RAW per-sample values (no x5e3 / x100)
                 v = arr[i]
-                row += [float(np.mean(v)), float(v[2]), float(v[0]), float(v[1])]   # avg, X, Y, Z  (channels are Y,Z,X)
+                avg = float(np.nanmean(v)) if k == 3 and np.isfinite(v).any() else float(np.mean(v))   # snr/avg is a nanmean (eval.py:168)
+                row += [avg, float(v[2]), float(v[0]), float(v[1])]   # avg, X, Y, Z  (channels are Y,Z,X)
             self.rows.append(row)
             self.ids.append(ids[i])
 
+    def _power_maps(self, a, pred, target, m, n):
+        """Directional RMS maps of the masked WYZX prediction / ground truth of every sample - the inputs of the
+        reference's EMD metric (eval.py:147-149,188-191 -> distance.py:41-59,133-143; one 0.1 s frame per sample, 30 degree
+        mesh), computed on the device by sagen_power_map_batched.  The EMD itself (pyemd) is host code outside the path."""
+        import torch
+        from . import ops
+        from .ambisonics import sh_matrix
+        if self._sh is None:
+            self._sh = torch.as_tensor(sh_matrix(30.0), dtype=torch.float32, device=pred.device)
+        mono = a[:, self.ss:self.ss + self.t, :1]
+        for x in (pred, target):
+            wyzx = (torch.cat([mono, x], 2) * m[:, None, :]).contiguous()
+            self.maps.append(ops.power_map_batched(wyzx, self._sh)[:n].reshape(n, 7, 12).flip(1).cpu().numpy())
 
-def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None, params=None, overwrite=True):
+
+class _ReaderCache(object):
+    """SampleReaders of the most recently used clips (consecutive windows usually come from the same clip)."""
+
+    def __init__(self, make, keep=2):
+        self.make, self.keep, self.items = make, keep, OrderedDict()
+
+    def get(self, yid):
+        if yid in self.items:
+            self.items.move_to_end(yid)
+        else:
+            self.items[yid] = self.make(yid)
+            while len(self.items) > self.keep:
+                self.items.popitem(last=False)
+        return self.items[yid]
+
+
+def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None, params=None, overwrite=True,
+             partial_batch='drop', power_maps=False):
     import torch
     from .deploy import load_params, W2XYZ
     from .feeder import SampleReader, img_prep_fcn
     rank, world = init_process_group()
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     params = params or load_params(model_dir)
     w2 = W2XYZ(model_dir, params=params, variables=variables)
     net = w2.model
     ids = [l.strip() for l in open(subset_fn)] if subset_fn else sorted(os.listdir(db_dir))
     ids = [i for i in ids if i and os.path.isdir(os.path.join(db_dir, i))]
     layouts = read_layouts(layouts_fn)
-    lo, hi = shard_range(len(ids), rank, world)
-    ev = Evaluator(net, params)
-    pend = {'id': [], 'ambix': [], 'video': [], 'flow': [], 'mask': []}
+    plan = window_plan(db_dir, ids)
+    lo, hi, n_batches = batch_shard(len(plan), rank, world, partial_batch)
+    readers = _ReaderCache(lambda yid: SampleReader(
+        os.path.join(db_dir, yid), ambi_order=params.ambi_order, audio_rate=params.audio_rate, video_rate=params.video_rate,
+        context=params.context, duration=0.1, return_video=VIDEO in params.encoders, img_prep=img_prep_fcn(),
+        return_flow=FLOW in params.encoders, skip_silence_thr=None, shuffle=False, random_rotations=False,
+        skip_rate=SKIP_RATE))                                              # feeder.py:373-396 (for_eval)
+    ev = Evaluator(net, params, power_maps=power_maps)
+    for b in range(lo, hi):
+        wins = plan[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
+        samples = [readers.get(yid).sample_at(t) for yid, t in wins]
+        stack = lambda k: np.stack([smp[k] for smp in samples], 0).astype(np.float32) if k in samples[0] else None
+        ev.run_batch([smp['id'] for smp in samples], stack('ambix'), stack('video'), stack('flow'),
+                     np.stack([layouts.get(yid, np.ones(4)) for yid, _ in wins], 0))
 
-    def flush(force=False):
-        while len(pend['id']) >= BATCH_SIZE or (force and pend['id']):
-            take = min(BATCH_SIZE, len(pend['id']))
-            cut = {k: v[:take] for k, v in pend.items()}
-            for k in pend:
-                pend[k] = pend[k][take:]
-            stack = lambda k: np.stack(cut[k], 0) if cut[k] else None
-            ev.run_batch(cut['id'], stack('ambix'), stack('video'), stack('flow'), stack('mask'))
-
-    for yid in ids[lo:hi]:
-        rd = SampleReader(os.path.join(db_dir, yid), ambi_order=params.ambi_order, audio_rate=params.audio_rate,
-                          video_rate=params.video_rate, context=params.context, duration=0.1,
-                          return_video=VIDEO in params.encoders, img_prep=img_prep_fcn(),
-                          return_flow=FLOW in params.encoders, skip_silence_thr=None, shuffle=False,
-                          random_rotations=False, skip_rate=10)                    # feeder.py:373-396 (for_eval)
-        win = clip_windows(rd)
-        if win is None:
-            continue
-        mask = layouts.get(yid, np.ones(4))
-        for i in range(len(win['id'])):
-            pend['id'].append(win['id'][i]); pend['ambix'].append(win['ambix'][i]); pend['mask'].append(mask)
-            for k in ('video', 'flow'):
-                if k in win:
-                    pend[k].append(win[k][i])
-        flush()
-    flush(force=True)
-
-    red = MetricReducer(METRIC_KEYS, device=net.device if world > 1 and torch.cuda.is_available() else None)
+    # global means: ONE all-reduce of per-key (sum over finite values, finite count) + sample count
+    red = MetricReducer(METRIC_KEYS, device=net.device if world > 1 and torch.cuda.is_available() and
+                        torch.distributed.get_backend() != 'gloo' else None)
     rows = np.asarray(ev.rows, np.float64).reshape(-1, len(METRIC_KEYS))
-    for r in rows:
-        red.add(np.nan_to_num(r), 1)
+    red.add_rows(rows)
     means, count = red.reduce()
-    # per-sample rows to rank 0 (eval.py:210-215 file format)
+    # per-sample rows to rank 0 (eval.py:210-215 file format); ranks hold consecutive batch ranges, so rank order = global order
     all_ids, all_rows = [ev.ids], [rows]
     if world > 1:
         import torch.distributed as dist
@@ -145,6 +180,10 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
             for ids_r, rows_r in zip(all_ids, all_rows):
                 for sid, row in zip(ids_r, rows_r):
                     f.write('{} | {}\n'.format(sid, ' '.join(str(v) for v in row)))
+        dropped = len(plan) - count
+        if dropped:
+            print('EVAL | %d trailing windows (a partial batch of %d) were not evaluated' % (dropped, BATCH_SIZE))
+    evaluate.last_maps = ev.maps
     return OrderedDict((k, means[k]) for k in METRIC_KEYS), count
 
 
@@ -156,8 +195,11 @@ def main(argv=None):
     ap.add_argument('--subset_fn', default=None)
     ap.add_argument('--layouts_fn', default='meta/audio_layouts.txt')
     ap.add_argument('--overwrite', action='store_true')
+    ap.add_argument('--partial_batch', choices=['drop', 'pad'], default='drop',
+                    help="trailing windows that do not fill a batch of 16: 'drop' (the reference's queue never dequeues them) or 'pad' with zero windows")
     args = ap.parse_args(argv)
-    means, count = evaluate(args.model_dir, args.db_dir, args.subset_fn, args.layouts_fn, overwrite=args.overwrite)
+    means, count = evaluate(args.model_dir, args.db_dir, args.subset_fn, args.layouts_fn, overwrite=args.overwrite,
+                            partial_batch=args.partial_batch)
     if int(os.environ.get('RANK', 0)) == 0:
         print('EVAL | %d samples' % count)
         for k, v in means.items():

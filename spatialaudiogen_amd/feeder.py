@@ -324,12 +324,8 @@ class SampleReader(object):
         return window_table(self.chunks_t, self.context, self.audio_size, self.audio_rate, self.audio_reader.num_frames,
                             self.video_rate)
 
-    def get(self):
-        self.head += 1
-        if self.head >= len(self.chunks_t):
-            return None
-        t = self.cur_t = self.chunks_t[self.head]
-        rotation = random.random() * 2 * np.pi - np.pi if self.random_rotations else None
+    def sample_at(self, t, rotation=None):
+        """The sample of window time `t` (any time, not only the listed ones)."""
         tab = window_table([t], self.context, self.audio_size, self.audio_rate, self.audio_reader.num_frames, self.video_rate)
         sample = {'id': '%s %s' % (self.video_id, t),
                   'ambix': self.audio_reader.assemble(tab, 0, self.audio_size, rotation)}
@@ -338,6 +334,13 @@ class SampleReader(object):
         if self.return_flow:
             sample['flow'] = self.flow_reader.frames(int(tab.frame[0]), self.video_size, rotation)
         return sample
+
+    def get(self):
+        self.head += 1
+        if self.head >= len(self.chunks_t):
+            return None
+        self.cur_t = self.chunks_t[self.head]
+        return self.sample_at(self.cur_t, random.random() * 2 * np.pi - np.pi if self.random_rotations else None)
 
     def loop_chunks(self, n=np.inf):
         served = 0

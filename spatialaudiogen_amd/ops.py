@@ -142,6 +142,16 @@ def power_map(ambi_wyzx, sh_matrix):
     return rms[:P]
 
 
+def power_map_batched(ambi_wyzx, sh_matrix):
+    """One RMS map per chunk (SphericalAmbisonicsVisualizer.loop_frames, distance.py:41-59): ambi [n_chunks, T, 4] -> [n_chunks, P]."""
+    a, sh = _f32(ambi_wyzx, 'ambi'), _f32(sh_matrix, 'sh')
+    n, T, P = a.shape[0], a.shape[1], sh.shape[0]
+    rms = torch.empty(n, P, dtype=torch.float32, device=a.device)
+    moments = torch.empty(n * 10, dtype=torch.float64, device=a.device)
+    check(_lib.lib().sagen_power_map_batched(_ptr(a), n, T, _ptr(sh), P, _ptr(rms), _ptr(moments), _stream()))
+    return rms
+
+
 def assemble_wyzx(audio, ambi_yzx, snd_contx=48000):
     """deploy.py:143-152: prepend W = mono[snd_contx/2 : snd_contx/2 + snd_dur]."""
     audio, ambi_yzx = _f32(audio, 'audio'), _f32(ambi_yzx, 'ambi')

@@ -10,21 +10,23 @@ from spatialaudiogen_amd.deploy import ClipArrays, audio_window, frame_index
 from util import rng
 
 
-def make_clip(root, secs=3, flow=False, seed=0):
+def make_clip(root, secs=3, flow=False, seed=0, video=True):
     from PIL import Image
     r = rng(seed)
     os.makedirs(os.path.join(root, 'ambix')); os.makedirs(os.path.join(root, 'video'))
     audio = np.clip(0.3 * r.normal(size=(secs * 48000, 4)), -1, 1)
     for i in range(secs):
         F.save_wav(os.path.join(root, 'ambix', '%06d.wav' % i), audio[i * 48000:(i + 1) * 48000], 48000)
-    frames = r.integers(0, 256, size=(secs * 10, 224, 448, 3)).astype(np.uint8)
-    frames = (frames // 32) * 32                                  # coarse levels survive JPEG poorly anyway: decode is the truth
-    for i, fr in enumerate(frames):
-        Image.fromarray(fr).save(os.path.join(root, 'video', '%06d.jpg' % i), quality=95)
     with open(os.path.join(root, 'audio_pow.lst'), 'w') as f:
         for i in range((secs - 1) * 10):
             t = i / 10. + 0.5
             f.write('{} {}\n'.format(t, 0.1 + 0.01 * i))
+    if not video:                                                  # audio-only clip (no frames to decode)
+        return audio
+    frames = r.integers(0, 256, size=(secs * 10, 224, 448, 3)).astype(np.uint8)
+    frames = (frames // 32) * 32                                  # coarse levels survive JPEG poorly anyway: decode is the truth
+    for i, fr in enumerate(frames):
+        Image.fromarray(fr).save(os.path.join(root, 'video', '%06d.jpg' % i), quality=95)
     if flow:
         os.makedirs(os.path.join(root, 'flow'))
         for i in range(secs * 10):

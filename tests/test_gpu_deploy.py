@@ -19,7 +19,8 @@ class Params(object):
         self.encoders = encoders
 
 
-@pytest.mark.parametrize('encoders,secs,duration', [(['audio'], 4, 10.), (['audio', 'video'], 3, 1.25)])
+# (['audio'], 12, 10.) = BASELINE configs[0] / SURVEY 8(d)-1: a 12 s clip deployed for 10 s = 95 windows, 10 groups, the last 5 real + 5 zero
+@pytest.mark.parametrize('encoders,secs,duration', [(['audio'], 4, 10.), (['audio', 'video'], 3, 1.25), (['audio'], 12, 10.)])
 def test_deploy_matches_oracle(encoders, secs, duration):
     import torch
     assert torch.cuda.is_available()
@@ -35,6 +36,8 @@ def test_deploy_matches_oracle(encoders, secs, duration):
 
     rows = O.deploy_window_table(O.audio_pow_times(secs), 0., duration)
     assert got.shape == (len(rows) * 4800, 4)
+    if secs == 12:
+        assert len(rows) == 95 and got.shape == (456000, 4)
     orc = O.SptAudioGenOracle(encoders=encoders)
     ref = []
     for g in range(0, len(rows), 10):
@@ -103,7 +106,8 @@ def test_evaluate_driver_matches_oracle(tmp_path):
         make_clip(str(db / name), secs=3, seed=20 + i)
         clips[name] = np.concatenate([F.load_wav(os.path.join(str(db / name), 'ambix', '%06d.wav' % k))[0] for k in range(3)], 0)
     (tmp_path / 'layouts.txt').write_text('clipA WXYZ\nclipB WXY\n')
-    means, count = evaluate(str(model_dir), str(db), None, str(tmp_path / 'layouts.txt'), variables=P, params=Params(enc))
+    means, count = evaluate(str(model_dir), str(db), None, str(tmp_path / 'layouts.txt'), variables=P, params=Params(enc),
+                            partial_batch='pad')
     assert count == 4                                                # 20 windows per clip, every 10th -> 2 per clip
     lines = open(str(model_dir / 'eval-detailed.txt')).read().splitlines()
     assert lines[0] == 'SampleID | ' + ' '.join(METRIC_KEYS) and len(lines) == 5 and lines[1].startswith('clipA 0.5 |')
@@ -125,3 +129,53 @@ def test_evaluate_driver_matches_oracle(tmp_path):
            'snr/avg': np.mean(snr_ps[:4]), 'stft/Z': np.mean(stft_ps[:4, 1]), 'amplitude/gt': np.mean(np.abs(target[:4]).max(axis=(1, 2)))}
     for key, v in ref.items():
         assert abs(means[key] - v) <= 2e-3 * max(1e-3, abs(v)) + 1e-6, (key, means[key], v)
+
+
+def _write_model_dir(model_dir, P, encoders):
+    import os
+    np.savez(os.path.join(model_dir, 'variables.npz'), **P)
+    with open(os.path.join(model_dir, 'train-params.txt'), 'w') as f:
+        f.write("encoders: [%s]\nseparation: unet_mask\nambi_order: 1\naudio_rate: 48000\nvideo_rate: 10\ncontext: 1.0\n"
+                "num_sep_tracks: 32\nloc_units: [512, 512]\n" % ', '.join("'%s'" % e for e in encoders))
+
+
+def _run_eval_cli(root, model_dir, db, world, port, extra=()):
+    """python -m spatialaudiogen_amd.evaluate under `world` ranks that share this one GPU (gloo for the collective)."""
+    import os, subprocess, sys
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   SAGEN_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, '-m', 'spatialaudiogen_amd.evaluate', model_dir, db, '--overwrite'] + list(extra),
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return outs[0], open(os.path.join(model_dir, 'eval-detailed.txt')).read()
+
+
+def test_evaluate_is_identical_for_one_and_two_ranks(tmp_path):
+    """The real evaluate() (clips -> global window order -> whole batches of 16 dealt to ranks -> metrics -> ONE all-reduce +
+    row gather) run as 1 rank and as 2 ranks on this GPU: every eval-detailed.txt row and every global mean must be
+    bit-identical, because batch composition (hence batch-norm statistics) does not depend on the world size."""
+    import os, socket
+    ensure_lib()
+    from test_feeder import make_clip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    enc = ['audio']
+    P = init_weights(variable_specs(enc), seed=9, mode='test')
+    db = tmp_path / 'db'; db.mkdir()
+    for i in range(19):                                  # 19 clips x 3 windows (every 10th of 30) = 57 = 3 batches + 9 dropped
+        make_clip(str(db / ('clip%02d' % i)), secs=4, seed=100 + i, video=False)
+    outs = {}
+    for world in (1, 2):
+        model_dir = tmp_path / ('model%d' % world); model_dir.mkdir()
+        _write_model_dir(str(model_dir), P, enc)
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        outs[world] = _run_eval_cli(root, str(model_dir), str(db), world, port)
+    log1, rows1 = outs[1]
+    log2, rows2 = outs[2]
+    assert rows1 == rows2 and len(rows1.splitlines()) == 1 + 48
+    means = lambda log: [l for l in log.splitlines() if l.startswith('EVAL | \t')]
+    assert means(log1) == means(log2) and len(means(log1)) == 18
+    assert 'EVAL | 48 samples' in log1 and 'EVAL | 48 samples' in log2

@@ -62,12 +62,29 @@ def test_audio_video(T):
     net, orc, got, ref = run_pair(T, ['audio', 'video'])
     g = net.intermediate(2, 'bottleneck').cpu().numpy()
     assert rel_rms_err(g, orc.ends['bottleneck']) < 2e-4
+    # ResNet trunk output (block conv5_2, resnet.py:184-190) compared directly, not only through the bottleneck
+    t = net.intermediate(2, 'video_encoder/conv5_2').cpu().numpy()
+    assert t.shape == (2, 7, 14, 512) and rel_rms_err(t, orc.ends['video_encoder/conv5_2']) < 1e-4
     check_out(got, ref)
 
 
 def test_audio_video_flow(T):
-    _, _, got, ref = run_pair(T, ['audio', 'video', 'flow'], seed=1)
+    net, orc, got, ref = run_pair(T, ['audio', 'video', 'flow'], seed=1)
+    for enc in ('video', 'flow'):
+        t = net.intermediate(2, enc + '_encoder/conv5_2').cpu().numpy()
+        assert rel_rms_err(t, orc.ends[enc + '_encoder/conv5_2']) < 1e-4, enc
     check_out(got, ref)
+
+
+def test_trunk_without_presplit_planes(T):
+    """SAGEN_NO_P3=1 keeps the fp32-activation kernels (igemm3dw) on the 3x3 trunk convs: same bar (one subprocess, the
+    switch is read when a context is created)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env['SAGEN_NO_P3'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_model.py'), '-m', 'gpu', '-q', '-x',
+                        '-k', 'test_audio_video and not flow'], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
 
 
 def test_no_separation_mode(T):

@@ -220,6 +220,23 @@ def test_power_map(T, res):
     assert rel_rms_err(np.flipud(rms), ref) < 1e-5
 
 
+def test_power_map_per_frame_batched(T):
+    """One RMS map per 0.1 s frame (SphericalAmbisonicsVisualizer.loop_frames, distance.py:41-59): the batched kernel
+    against the oracle frame by frame, with the product-side mesh / harmonics."""
+    from spatialaudiogen_amd import ops
+    from spatialaudiogen_amd.ambisonics import sh_matrix, mesh_shape
+    r = rng(19)
+    nfr = 13
+    ambi = r.normal(size=(nfr, 4800, 4)) * np.array([1.0, 0.3, 0.1, 0.6]) * r.uniform(0.1, 2.0, size=(nfr, 1, 1))
+    ambi[5] = 0.0                                                        # a silent frame
+    for res in (30.0, 5.0):
+        rms = ops.power_map_batched(dev(T, ambi), dev(T, sh_matrix(res))).cpu().numpy()
+        for f in range(nfr):
+            ref = O.power_map(ambi[f], res)
+            got = np.flipud(rms[f].reshape(mesh_shape(res)))
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (res, f)
+
+
 def test_assemble_wyzx_is_bit_exact(T):
     from spatialaudiogen_amd import ops
     r = rng(4)

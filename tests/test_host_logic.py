@@ -60,3 +60,46 @@ def test_shard_range_partitions_in_order():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_ambisonics_host_module_matches_the_oracle_mesh():
+    """Product-side mesh / order-1 harmonics (spatialaudiogen_amd/ambisonics.py) vs the oracle's restatement of
+    distance.py:9-13 and common.py:151-157, and the analytic known answers of SURVEY.md 8c."""
+    import numpy as np
+    from spatialaudiogen_amd import ambisonics as A
+    from oracle import np_oracle as O
+    for res in (30.0, 20.0, 5.0):
+        phi, nu = A.spherical_mesh(res)
+        ophi, onu = O.spherical_mesh(res)
+        assert np.array_equal(phi, ophi) and np.array_equal(nu, onu)
+        assert np.allclose(A.sh_matrix(res), O.sh_matrix_order1(ophi, onu), atol=0, rtol=0)
+    assert A.mesh_shape(30.0) == (7, 12) and A.mesh_shape(5.0) == (37, 72)
+    assert np.allclose(A.sh_order1(np.pi / 2, 0.0), [1, 1, 0, 0]) and np.allclose(A.sh_order1(0.0, 0.0), [1, 0, 0, 1])
+    assert np.allclose(A.sh_order1(0.3, np.pi / 2), [1, 0, 1, 0])
+
+
+def test_eval_batches_do_not_depend_on_the_world_size():
+    """evaluate.batch_shard: batches are cut from one global window order and whole batches are dealt to ranks, so the set of
+    (batch -> windows) is identical for every world size; the trailing partial batch is dropped (or padded, last)."""
+    from spatialaudiogen_amd.evaluate import batch_shard, BATCH_SIZE
+    for n_windows in (0, 5, 16, 100, 1024 * 9, 1000):
+        for mode in ('drop', 'pad'):
+            ref = None
+            for world in (1, 2, 3, 8):
+                got = []
+                for rank in range(world):
+                    lo, hi, nb = batch_shard(n_windows, rank, world, mode)
+                    got += list(range(lo, hi))
+                assert got == list(range(nb))
+                assert nb == n_windows // BATCH_SIZE + (1 if mode == 'pad' and n_windows % BATCH_SIZE else 0)
+                ref = ref or got
+                assert got == ref
+
+
+def test_metric_reducer_skips_non_finite_values():
+    import numpy as np
+    from spatialaudiogen_amd.dist import MetricReducer
+    red = MetricReducer(['a', 'b'])
+    red.add_rows(np.array([[1.0, np.nan], [3.0, 4.0], [5.0, np.inf]]))
+    vals, n = red.reduce()
+    assert n == 3 and vals['a'] == 3.0 and vals['b'] == 4.0
