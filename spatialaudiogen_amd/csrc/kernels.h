@@ -88,7 +88,7 @@ enum IgemmTile {
     // bf16x3 for the 7x7 stride-2 stem over the padded 4-channel image, K ordered (dh, dw padded to 8, c) (igemm3s2_kernel)
     TILE_B3S2_256x64, TILE_B3S2_128x64,
     // bf16x3 for dense 3x3 stride-1 SAME convs over pre-split activation planes (conv3p_kernel; needs IgemmDesc::xp3)
-    TILE_P3_128x64, TILE_P3_128x128, TILE_P3_128x128_S3, TILE_P3_256x64_S3, TILE_P3_64x64, TILE_P3_64x128,
+    TILE_P3_128x64, TILE_P3_128x128, TILE_P3_256x64, TILE_P3_64x64, TILE_P3_64x128,
     TILE_AUTO
 };
 

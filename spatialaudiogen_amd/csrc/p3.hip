@@ -15,29 +15,29 @@ namespace sagen {
 
 size_t p3_bytes(int B, int H, int W, int C) { return (size_t)(C / 16) * B * H * (W + 1) * 96; }
 
-// scale / shift of 4 consecutive channels (same derivation as elementwise.hip)
-__device__ __forceinline__ void p3_bn4(const float* scale, const float* shift, const BnRef& bn, int C, int c0, float4& sc, float4& sh) {
-    if (bn.acc != nullptr) {
-        float s4[4], h4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c0 + k;
+// Per-block table of the batch-norm coefficients: scale = gamma / sqrt(var + eps), shift = beta - mean * scale from the
+// producer's fp64 (sum, sumsq) accumulators (contrib batch_norm, training mode, core.py:6,209-210; biased variance).
+// One fp64 sqrt + divide per CHANNEL and block instead of eight per thread (which made the small late-stage tensors
+// latency-bound: 16 MB in 11-14 us).
+constexpr int P3_MAX_C = 512;
+__device__ __forceinline__ void p3_bn_table(const float* scale, const float* shift, const BnRef& bn, int C, float (*tab)[P3_MAX_C]) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sc = 1.f, sh = 0.f;
+        if (bn.acc != nullptr) {
             const double mean = bn.acc[c] * bn.inv_count;
             double var = bn.acc[C + c] * bn.inv_count - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             const double a = (double)bn.gamma[c] / sqrt(var + (double)bn.eps);
-            s4[k] = (float)a;
-            h4[k] = (float)((double)bn.beta[c] - mean * a);
+            sc = (float)a;
+            sh = (float)((double)bn.beta[c] - mean * a);
+        } else if (scale != nullptr) {
+            sc = scale[c];
+            sh = shift[c];
         }
-        sc = make_float4(s4[0], s4[1], s4[2], s4[3]);
-        sh = make_float4(h4[0], h4[1], h4[2], h4[3]);
-    } else if (scale != nullptr) {
-        sc = *reinterpret_cast<const float4*>(scale + c0);
-        sh = *reinterpret_cast<const float4*>(shift + c0);
-    } else {
-        sc = make_float4(1.f, 1.f, 1.f, 1.f);
-        sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        tab[0][c] = sc;
+        tab[1][c] = sh;
     }
+    __syncthreads();
 }
 
 // 8 fp32 values -> the three bf16 planes (8 bf16 = 16 bytes each)
@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
     const long cstride = nrows * (W + 1) * 96;
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
-    float4 sc0, sh0, sc1, sh1;
-    p3_bn4(scale, shift, bn, C, 8 * c8, sc0, sh0);
-    p3_bn4(scale, shift, bn, C, 8 * c8 + 4, sc1, sh1);
+    __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
+    p3_bn_table(scale, shift, bn, C, tab);
+    const float4 sc0 = *reinterpret_cast<const float4*>(&tab[0][8 * c8]), sc1 = *reinterpret_cast<const float4*>(&tab[0][8 * c8 + 4]);
+    const float4 sh0 = *reinterpret_cast<const float4*>(&tab[1][8 * c8]), sh1 = *reinterpret_cast<const float4*>(&tab[1][8 * c8 + 4]);
     for (long i = t0; i < total; i += (long)gridDim.x * 256) {
         const long pp = i / C8;
         const long row = pp / (W + 1);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
 
 // grid whose stride (grid*256 threads) is a multiple of `unit_threads`, so per-thread channel groups are loop-invariant
 static int aligned_grid(long total, int unit_threads) {
-    long g = std::min<long>(cdiv(total, 256), 256L * 16);
+    long g = std::min<long>(cdiv(total, 256), 256L * 8);      // <= 8 blocks per CU: the coefficient table is amortised over several elements per thread
     long a = 256, b = unit_threads;
     while (b) { const long t = a % b; a = b; b = t; }
     const long unit = unit_threads / a;                  // smallest g with (g*256) % unit_threads == 0
@@ -115,7 +116,7 @@ static int aligned_grid(long total, int unit_threads) {
 
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
                    float* y, void* p3, int B, int H, int W, int C, hipStream_t s) {
-    if (C % 16) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: C=%d must be a multiple of 16", C);
+    if (C % 16 || C > P3_MAX_C) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: C=%d must be a multiple of 16, at most %d", C, P3_MAX_C);
     if (!y && !p3) return fail(SAGEN_ERR_NULL, "p3_pack: no output");
     const long nrows = (long)B * H;
     if (p3_bytes(B, H, W, C) >= (1UL << 31)) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: tensor exceeds 2 GiB buffer addressing");
@@ -137,9 +138,10 @@ __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict
     const long cstride = nrows * (Wo + 1) * 96;
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
-    float4 sc0, sh0, sc1, sh1;
-    p3_bn4(scale, shift, bn, C, 8 * c8, sc0, sh0);
-    p3_bn4(scale, shift, bn, C, 8 * c8 + 4, sc1, sh1);
+    __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
+    p3_bn_table(scale, shift, bn, C, tab);
+    const float4 sc0 = *reinterpret_cast<const float4*>(&tab[0][8 * c8]), sc1 = *reinterpret_cast<const float4*>(&tab[0][8 * c8 + 4]);
+    const float4 sh0 = *reinterpret_cast<const float4*>(&tab[1][8 * c8]), sh1 = *reinterpret_cast<const float4*>(&tab[1][8 * c8 + 4]);
     const bool has_bn = scale != nullptr || bn.acc != nullptr;
     for (long i = t0; i < total; i += (long)gridDim.x * 256) {
         const long pp = i / C8;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict
 
 int p3_maxpool_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, void* p3, int B, int H,
                       int W, int C, hipStream_t s) {
-    if (C % 16) return fail(SAGEN_ERR_UNSUPPORTED, "p3_maxpool: C=%d must be a multiple of 16", C);
+    if (C % 16 || C > P3_MAX_C) return fail(SAGEN_ERR_UNSUPPORTED, "p3_maxpool: C=%d must be a multiple of 16, at most %d", C, P3_MAX_C);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
     const long total = (long)B * Ho * (Wo + 1) * (C / 8);

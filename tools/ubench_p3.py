@@ -60,7 +60,7 @@ for (B, H, W, Cin, N) in shapes:
     p3 = torch.zeros((Cin // 16) * np3 * 96 // 4 + 64, device='cuda')
     assert lib.p3dbg_pack(p(x), p(p3), B, H, W, Cin, None) == 0
     y = torch.empty(B, H, W, N, device='cuda'); stats = None if nostats else torch.zeros(2 * N, dtype=torch.float64, device='cuda')
-    nblk = -(-np3 // (bm - 2))
+    nblk = 8192
     trc = torch.zeros(nblk * 16, dtype=torch.int64, device='cuda') if trace else None
     for _ in range(3):
         assert lib.p3dbg_conv(p(p3), p(wbuf), p(y), p(stats), p(trc), B, H, W, Cin, N, tile, None) == 0
@@ -76,9 +76,14 @@ for (B, H, W, Cin, N) in shapes:
     us = float(np.median(ts))
     print('%s %s flags=%s: %.1f us  %.1f TF (fp32-equiv)  rel err vs torch fp32 conv %.2e  blocks %d' % (tile_name, (B, H, W, Cin, N), ' '.join(flags), us, fl / us / 1e6, err, nblk * -(-N // 64)), flush=True)
     if trace:
+        trc.zero_(); lib.p3dbg_conv(p(p3), p(wbuf), p(y), p(stats), p(trc), B, H, W, Cin, N, tile, None); torch.cuda.synchronize()
         t = trc.cpu().numpy().reshape(nblk, 16).astype(np.int64)
         ok = t[:, 6] > 0
         t = t[ok]
+        print('   workgroups %d: tiles/WG min %d median %d max %d; per WG (median ticks): entry->first issue %d | K loops %d | epilogues %d | life %d; per tile: K %d, epilogue %d'
+              % (len(t), t[:, 4].min(), np.median(t[:, 4]), t[:, 4].max(), np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2]), np.median(t[:, 3]),
+                 np.median(t[:, 6] - t[:, 0]), np.median(t[:, 2] / np.maximum(t[:, 4], 1)), np.median(t[:, 3] / np.maximum(t[:, 4], 1))))
+        continue
         t0 = t[:, 0].min()
         # occupancy over time: how many workgroups are between their first and last stamp
         ev = np.concatenate([np.stack([t[:, 0], np.ones(len(t))], 1), np.stack([t[:, 6], -np.ones(len(t))], 1)])
