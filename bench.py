@@ -1,15 +1,22 @@
 #!/usr/bin/env python
 """Headline benchmark: ambisonic seconds generated per second (0.1 s windows, 224x448 video).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config av|a|avf|eval]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
             --master-port P bench.py --gpus N --steps K --warmup W)
 
-One "step" = one pass of the hot path (sagen_forward: STFT -> audio + ResNet18 video encoders ->
-U-Net mask decoder -> iSTFT -> ambisonic mix) over one batch of 32 synthetic 0.1 s windows per GPU
-(BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  Windows shard over
-ranks with no data-path collective (weak scaling); the only collective is the eval-style metric
-all-reduce (RCCL) issued once at the end of the timed region.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (sagen_forward: STFT -> audio [+ ResNet18 video / flow] encoders -> U-Net mask
+decoder -> iSTFT -> ambisonic mix) over one batch of synthetic 0.1 s windows per GPU.  Inputs are resident in HBM before the
+timed region.  Windows / batches shard over ranks with no data-path collective (the only collective is the eval-style metric
+all-reduce, RCCL, once at the end of the timed region).  Rank 0 prints ONE JSON line.
+
+--config selects the BASELINE.json configuration:
+    av    configs[1]  audio + video encoders, 32 windows per batch                      (default: the configuration the metric is quoted on)
+    a     configs[0]  audio encoder only, deploy.py's batch of 10 windows               (the reference's CPU-runnable plumbing case, here on the GPU)
+    avf   configs[2]  audio + video + flow encoders, 32 windows per batch
+    eval  configs[3]  YT-All stand-in: 1024 synthetic clips x 9 windows, batches of 16 cut from one global window order and dealt
+                      whole to the ranks (spatialaudiogen_amd.evaluate.batch_shard), forward + on-device evaluation_ops per batch,
+                      ONE all-reduce of the metric sums at the end; strong scaling (total work fixed); --steps caps the batches per rank
 """
 import argparse
 import json
@@ -22,13 +29,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 32
-ENCODERS = ['audio', 'video']
-# needed-only algorithmic work per window, A+V (BASELINE.md 2 / SURVEY.md 8d)
-GFLOP_PER_WINDOW = 8.41
+# needed-only algorithmic work per window (BASELINE.md 2 / SURVEY.md 8d) and the workload of each configuration
+CONFIGS = {
+    'av': dict(encoders=['audio', 'video'], batch=32, gflop=8.41, scaling='weak',
+               workload='configs[1]: audio+video encoders (no flow), 224x448@10fps + 48 kHz mono, batch 32 x 0.1 s windows per GPU, '
+                        'FREQ_MASK separation, 32 tracks'),
+    'a': dict(encoders=['audio'], batch=10, gflop=1.13, scaling='weak',
+              workload="configs[0]: audio-only encoder, deploy.py's batch of 10 x 0.1 s windows per GPU (the reference's CPU plumbing "
+                       'case run on the GPU; synthetic weights, the REC-Street checkpoint is not available offline)'),
+    'avf': dict(encoders=['audio', 'video', 'flow'], batch=32, gflop=15.69, scaling='weak',
+                workload='configs[2]: audio+video+flow encoders (three-stream fusion), batch 32 x 0.1 s windows per GPU'),
+    'eval': dict(encoders=['audio', 'video'], batch=16, gflop=8.41, scaling='strong',
+                 workload='configs[3]: YT-All eval stand-in, 1024 synthetic clips x 9 windows (every 10th window of a 10 s clip), batches of '
+                          '16 dealt whole to the ranks, forward + on-device evaluation metrics, one metric all-reduce'),
+}
+EVAL_CLIPS, EVAL_WINDOWS_PER_CLIP = 1024, 9
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 32 cycles / SIMD)
-# igemm3_kernel evaluates every fp32 product as 6 bf16 products (bf16x3 operand split, fp32 accumulate): its matrix roof
+# the bf16x3 kernels evaluate every fp32 product as 6 bf16 products (3-way operand split, fp32 accumulate): their matrix roof
 # in ALGORITHMIC fp32 FLOP/s is the bf16 peak / 6
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
@@ -38,7 +56,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='av')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the one-in-flight and H2D-inclusive legs (they run after the timed region)')
     ap.add_argument('--in-flight', type=int, default=2,
                     help='batches in flight per GPU: steps rotate over this many native contexts, each on its own stream, the streams '
                          'probed to really run concurrently (DESIGN.md 6.1); 1 = strictly one forward at a time')
@@ -48,34 +68,36 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(P, inputs, budget_s):
+def cpu_baseline(P, inputs, budget_s, encoders, batch):
     """The reference-equivalent CPU path (oracle/torch_ref.py, torch-CPU/oneDNN fp32, all host
     threads) on the same synthetic batch; TF 1.4 cannot be installed offline."""
     import torch
     from oracle.torch_ref import TorchRef
     threads = torch.get_num_threads()
-    ref = TorchRef(P, ENCODERS, dtype=torch.float32)
-    a, v = inputs['audio'], inputs['video']
+    ref = TorchRef(P, encoders, dtype=torch.float32)
+    args = [inputs['audio']] + [inputs[k] for k in ('video', 'flow') if k in inputs]
     t0 = time.time()
-    ref.forward(a, v)                                  # warm-up (oneDNN primitive creation)
+    ref.forward(*args)                                 # warm-up (oneDNN primitive creation)
     warm = time.time() - t0
     times = []
     t_start = time.time()
     while len(times) < 2 or (time.time() - t_start < budget_s and len(times) < 20):
         t0 = time.time()
-        ref.forward(a, v)
+        ref.forward(*args)
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {
-        'value': round(0.1 * BATCH / med, 3), 'unit': 'ambisonic-s/s', 'cores': threads, 'kind': 'port',
-        'sample': '%d timed batches of %d windows (same synthetic A+V workload, fp32), median %.3f s/batch, '
+        'value': round(0.1 * batch / med, 3), 'unit': 'ambisonic-s/s', 'cores': threads, 'kind': 'port',
+        'sample': '%d timed batches of %d windows (same synthetic %s workload, fp32), median %.3f s/batch, '
                   'warm-up %.2f s; torch-CPU/oneDNN stand-in for the TF1 CPU path (TF1 unavailable offline)'
-                  % (len(times), BATCH, med, warm),
+                  % (len(times), batch, '+'.join(encoders), med, warm),
     }
 
 
 def main():
     args = parse()
+    cfg = CONFIGS[args.config]
+    ENCODERS, BATCH = cfg['encoders'], cfg['batch']
     if args.gpus > 1 and 'RANK' not in os.environ:
         # convenience: re-launch ourselves under torchrun, one rank per GPU
         import subprocess
@@ -98,13 +120,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU implementation')
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    backend = os.environ.get('SAGEN_DIST_BACKEND', 'nccl')
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # RCCL ('nccl') is the backend; SAGEN_DIST_BACKEND=gloo is a test hook for running several ranks on ONE GPU
-        dist.init_process_group(os.environ.get('SAGEN_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     P = init_weights(variable_specs(ENCODERS), seed=0, mode='bench')           # same replica on every rank
-    inp = synth_inputs(BATCH, ENCODERS, seed=1234 + rank)                      # each rank owns its windows
+    is_eval = args.config == 'eval'
+    # eval: a pool of distinct synthetic windows stands in for the 9216 windows of the clip set (window w of the global order
+    # uses pool entry w % pool); the other configurations: each rank owns one batch of its own windows
+    POOL = 4 * BATCH if is_eval else BATCH
+    inp = synth_inputs(POOL, ENCODERS, seed=1234 + (0 if is_eval else rank))
     # Steps are independent batches, so NF of them are kept in flight: step i runs on native context i % NF and stream
     # i % NF (each context has its own workspace and its own second stream).  Every step is still one full forward of
     # one batch; the kernels of neighbouring steps fill each other's launch tails.  Outputs are bit-identical to
@@ -115,21 +142,46 @@ def main():
         n.load_variables(P)
     net = nets[0]
     streams = []                        # created after the contexts (below): ROCm maps HIP streams to hardware queues in creation order
-    audio = torch.as_tensor(inp['audio']).cuda()
-    video = torch.as_tensor(inp['video']).cuda()
+    dev_in = {k: torch.as_tensor(v).cuda() for k, v in inp.items()}
+    names_in = ['audio'] + [k for k in ('video', 'flow') if k in dev_in]
+
+    def batch_inputs(b):                # device views of the windows of (global) batch b
+        lo = (b * BATCH) % POOL
+        return [dev_in[k][lo:lo + BATCH] for k in names_in]
+
     outs = [torch.empty(BATCH, 4800, 3, device='cuda') for _ in range(NF)]
-    out = outs[0]
-    metric = torch.zeros(4, dtype=torch.float64, device='cuda')
+    metric = torch.zeros(14, dtype=torch.float64, device='cuda')
+    eval_sums = [torch.zeros(12, dtype=torch.float64, device='cuda') for _ in range(NF)]
     counter = [0]
 
+    # which batches does this rank run?  eval: its whole-batch shard of the global order; otherwise its own batch, repeated
+    if is_eval:
+        from spatialaudiogen_amd.evaluate import batch_shard
+        lo_b, hi_b, n_batches = batch_shard(EVAL_CLIPS * EVAL_WINDOWS_PER_CLIP, rank, world, 'drop')
+        my_batches = list(range(lo_b, hi_b))
+        steps = min(args.steps, len(my_batches)) if args.steps > 0 else len(my_batches)
+    else:
+        my_batches, steps = [rank], args.steps
+
+    def run_step(j, b, ctx_nets, ctx_outs):
+        """one forward (+ metrics in eval mode) of global batch b on context j (current stream)"""
+        a = batch_inputs(b)
+        ctx_nets[j].inference_ops(*a, out=ctx_outs[j])
+        if is_eval:         # targets: a fixed pseudo ground truth (the W-channel crop scaled per channel) - the metric kernels run at full cost
+            tgt = a[0][:, 24000:28800, :] * torch.tensor([0.5, 0.25, -0.5], device='cuda')
+            ps, _ = ctx_nets[j].evaluation_ps(ctx_outs[j], tgt.contiguous())
+            eval_sums[j] += ps.double().sum(1).reshape(-1)
+
     def step():
-        j = counter[0] % NF
+        i = counter[0]
+        j = i % NF
         counter[0] += 1
+        b = my_batches[i % len(my_batches)]
         if NF == 1:
-            net.inference_ops(audio, video, out=out)
+            run_step(0, b, nets, outs)
         else:
             with torch.cuda.stream(streams[j]):
-                nets[j].inference_ops(audio, video, out=outs[j])
+                run_step(j, b, nets, outs)
         return j
 
     def barrier():
@@ -137,42 +189,52 @@ def main():
             dist.barrier()
 
     def reduce_metric():
-        # eval-style metric reduction: per-rank sums + count, one all-reduce over RCCL
+        # eval-style metric reduction: per-rank sums + count, one all-reduce (RCCL)
         if NF > 1:                          # the reduction (current stream) consumes what the step streams produced
             for st in streams:
                 torch.cuda.current_stream().wait_stream(st)
         metric[0] = sum((o.double() ** 2).sum() for o in outs) / NF
         metric[1] = float(BATCH)
+        metric[2:] = sum(eval_sums)
         if world > 1:
-            dist.all_reduce(metric)
+            if backend == 'gloo':
+                m = metric.cpu()
+                dist.all_reduce(m)
+                metric.copy_(m)
+            else:
+                dist.all_reduce(metric)
 
     # untimed set-up: per-layer (tile, split-K) autotune on this rank's own batch, then W warm-up steps
     plan = []
+    a0 = batch_inputs(my_batches[0] if my_batches else 0)
     if args.plan_file and os.path.exists(args.plan_file):
-        net.inference_ops(audio, video, out=out)
+        net.inference_ops(*a0, out=outs[0])
         net.load_plan(BATCH, args.plan_file)
         plan = net.plan(BATCH)
     elif not args.no_autotune:
-        plan = net.autotune(audio, video)
+        plan = net.autotune(*a0)
         if args.plan_file and rank == 0:
             net.save_plan(BATCH, args.plan_file)
     names = SptAudioGen.tile_names()
     from spatialaudiogen_amd.streams import pick_concurrent_streams
     streams.extend(pick_concurrent_streams(NF))
     for n in nets[1:]:                      # the other contexts replay the plan tuned on context 0
-        n.inference_ops(audio, video)
+        n.inference_ops(*a0)
         for layer, tile, sk, _ in plan:
             n.plan_set(BATCH, layer, names.index(tile) if tile in names else 0, sk)
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     reduce_metric()                     # also loads the torch kernels it uses before the timed region
+    for e in eval_sums:
+        e.zero_()
+    counter[0] = 0
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         st = streams[counter[0] % NF] if NF > 1 else torch.cuda.current_stream()
         ev[i][0].record(st)
         step()
@@ -182,17 +244,52 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend != 'gloo' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ns = torch.tensor([float(steps)], dtype=torch.float64, device='cuda' if backend != 'gloo' else 'cpu')
+        dist.all_reduce(ns)
+        total_steps = int(ns.item())
+    else:
+        total_steps = steps
     if os.environ.get('BENCH_DEBUG'):
         t00 = ev[0][0]
         print('step timeline (start, end ms):', [(round(t00.elapsed_time(a), 2), round(t00.elapsed_time(b), 2)) for a, b in ev[:8]], file=sys.stderr)
-    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev) or [0.0]
 
-    windows = world * BATCH * args.steps
+    windows = BATCH * total_steps                       # all ranks
     value = 0.1 * windows / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
+    ms_per_step = 1e3 * elapsed / max(steps, 1)
+
+    # ---- extra legs (after the timed region; rank-local): strictly one forward at a time, and host-resident inputs ----
+    extra = {}
+    if not args.no_extra_legs and not is_eval:
+        ks = max(5, min(steps, 20))
+        a = batch_inputs(my_batches[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(ks):
+            net.inference_ops(*a, out=outs[0])          # context 0 on the current stream, nothing else in flight
+        torch.cuda.synchronize()
+        extra['one_in_flight'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
+                                  'note': 'strictly sequential forwards on one context (this rank x n_gpus), %d steps' % ks}
+        # H2D-inclusive: every batch starts in pinned host memory; copy (on the step's stream) + forward, NF in flight
+        host = [t.cpu().pin_memory() for t in a]
+        devb = [[torch.empty_like(t) for t in a] for _ in range(NF)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ks):
+            j = i % NF
+            ctx = torch.cuda.stream(streams[j]) if NF > 1 else torch.cuda.stream(torch.cuda.current_stream())
+            with ctx:
+                for d_, h_ in zip(devb[j], host):
+                    d_.copy_(h_, non_blocking=True)
+                nets[j].inference_ops(*devb[j], out=outs[j])
+        torch.cuda.synchronize()
+        mb = sum(h.numel() * 4 for h in host) / 1e6
+        extra['h2d_inclusive'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
+                                  'note': 'inputs start in pinned host memory: %.1f MB copied per batch on the step stream, then the forward; '
+                                          '%d batches in flight, %d steps' % (mb, NF, ks)}
 
     # ---- roofline of the dominant kernel: per-launch HIP events recorded by the native runtime on the
     #      launch stream (sagen_profile_*), three extra forwards outside the timed region ----
@@ -201,7 +298,7 @@ def main():
     agg = {}
     nprof = 3
     for _ in range(nprof):
-        net.inference_ops(audio, video, out=out)          # context 0 alone on the current stream: unoverlapped launch times
+        net.inference_ops(*a0, out=outs[0])              # context 0 alone on the current stream: unoverlapped launch times
         for k, layer, us, fl in net.profile_report(BATCH):
             a = agg.setdefault(k, [0, 0.0, 0.0])
             a[0] += 1; a[1] += us; a[2] += fl
@@ -210,20 +307,22 @@ def main():
     dom = max(agg, key=lambda k: agg[k][1])
     n_l, us_l, fl_l = agg[dom]
     achieved = fl_l / (us_l * 1e-6) / 1e12
-    traffic = None
+    traffic, traffic_src = None, None
     try:     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             traffic = json.load(f).get(dom)
+        if traffic is not None:
+            traffic_src = 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x2 per the gfx950 note), not measured in this run'
     except Exception:
         pass
-    step_tflops = GFLOP_PER_WINDOW * BATCH / (ms_per_step * 1e-3) / 1e3          # throughput-based (steps overlap when NF > 1)
+    step_tflops = cfg['gflop'] * BATCH / (ms_per_step * 1e-3) / 1e3          # throughput-based (steps overlap when NF > 1)
     b3 = dom.startswith('igemm3') or dom.startswith('conv3p')   # igemm3 / igemm3dw / igemm3s2 / conv3p kernels: the bf16x3 family
     peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
     b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3') or k.startswith('conv3p'))
     f32_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm_kernel'))
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
-        'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+        'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
                        if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -233,21 +332,22 @@ def main():
         'contraction_time_split': {'bf16x3_kernels_us': round(b3_us / nprof, 1), 'fp32_mfma_kernels_us': round(f32_us / nprof, 1)},
         'whole_step': {'achieved': round(step_tflops, 2), 'frac': round(step_tflops / peak, 4),
                        'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
-                       'gflop_per_window_needed_only': GFLOP_PER_WINDOW,
+                       'gflop_per_window_needed_only': cfg['gflop'],
                        'kernel_time_us_per_step': round(total_us / nprof, 1)},
     }
 
     result = {
         'metric': 'ambisonic seconds generated/sec (0.1 s windows, 224x448 video)',
-        'value': round(value, 2), 'unit': 'ambisonic-s/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'value': round(value, 2), 'unit': 'ambisonic-s/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None,
         'dtype': 'f32 (products on the bf16 matrix cores as a 3-way bf16 operand split, 6 products per multiply, fp32 accumulate '
                  '- fp32-equivalent, parity bar 1e-4 RMS unchanged; SAGEN_FP32_ONLY=1 selects the exact fp32 MFMA kernels)',
-        'data': 'synthetic',
-        'config': {'workload': 'configs[1]: audio+video encoders (no flow), 224x448@10fps + 48 kHz mono, '
-                               'batch 32 x 0.1 s windows per GPU, FREQ_MASK separation, 32 tracks',
+        'data': 'synthetic' + (' (pool of %d distinct windows cycled over the %d x %d window set)' % (POOL, EVAL_CLIPS, EVAL_WINDOWS_PER_CLIP) if is_eval else ''),
+        'config': {'workload': cfg['workload'], 'name': args.config,
                    'windows_per_gpu_per_step': BATCH, 'windows_per_s': round(windows / elapsed, 1),
-                   'sharding': 'windows/clips over ranks, no data-path collective; 1 metric all-reduce at the end',
+                   'sharding': ('whole batches of the global window order over ranks (%d batches in total, %d timed on this rank); '
+                                '1 metric all-reduce at the end' % (n_batches, steps)) if is_eval else
+                               'windows/clips over ranks, no data-path collective; 1 metric all-reduce at the end',
                    'weights': 'random init (Xavier / BN identity), same replica on every rank',
                    'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics',
                    'batches_in_flight': NF},
@@ -255,8 +355,13 @@ def main():
                           'p90': round(step_ms[(9 * len(step_ms)) // 10], 4)},
         'roofline': roofline,
     }
+    result.update(extra)
+    if is_eval:
+        tot = metric[2:].cpu().numpy().reshape(4, 3) / max(windows, 1)
+        result['eval_metric_means'] = {k: [round(float(x), 6) for x in tot[i]] for i, k in enumerate(('stft', 'lsd', 'mse', 'snr'))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(P, inp, args.cpu_seconds)
+        sample = {k: v[:BATCH] for k, v in inp.items()}
+        cb = cpu_baseline(P, sample, args.cpu_seconds, ENCODERS, BATCH)
         cb['gpu_over_cpu'] = round(value / cb['value'], 1)
         result['cpu_baseline'] = cb
     if rank == 0:

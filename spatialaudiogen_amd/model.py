@@ -196,11 +196,9 @@ class SptAudioGen(object):
         return out
 
     # ---- evaluation metrics (model.py:110-154) -----------------------------------------------------
-    def evaluation_ops(self, preds_t, targets_t, w_t=None, mask_channels=None):
-        """preds/targets [B, snd_dur, 3] -> (metrics OrderedDict, stft_dist_ps, lsd_ps, mse_ps, snr_ps), the last four
-        [B, 3] device tensors exactly as the reference returns them.  `w_t` is accepted for signature parity (unused
-        by the reference too).  Per-sample values are computed by libsagen_hip.so; the masked channel means of
-        model.py:119-150 are a handful of scalar operations on [B,3] done here."""
+    def evaluation_ps(self, preds_t, targets_t):
+        """Device-only part of evaluation_ops: (ps [4, B, 3] = per-sample stft distance, lsd, mse, snr; pw [2] fp64 power sums),
+        no host synchronisation (the eval loop keeps batches in flight and reduces once at the end)."""
         pr = torch.as_tensor(preds_t).to(device=self.device, dtype=torch.float32).contiguous()
         gt = torch.as_tensor(targets_t).to(device=self.device, dtype=torch.float32).contiguous()
         B = pr.shape[0]
@@ -219,6 +217,15 @@ class SptAudioGen(object):
         pw = torch.zeros(2, dtype=torch.float64, device=self.device)
         check(l.sagen_eval_metrics(C.c_void_p(pr.data_ptr()), C.c_void_p(gt.data_ptr()), B, C.c_void_p(ps.data_ptr()),
                                    C.c_void_p(pw.data_ptr()), C.c_void_p(scratch.data_ptr()), scratch.numel() * 4, stream))
+        return ps, pw
+
+    def evaluation_ops(self, preds_t, targets_t, w_t=None, mask_channels=None):
+        """preds/targets [B, snd_dur, 3] -> (metrics OrderedDict, stft_dist_ps, lsd_ps, mse_ps, snr_ps), the last four
+        [B, 3] device tensors exactly as the reference returns them.  `w_t` is accepted for signature parity (unused
+        by the reference too).  Per-sample values are computed by libsagen_hip.so; the masked channel means of
+        model.py:119-150 are a handful of scalar operations on [B,3] done here."""
+        ps, pw = self.evaluation_ps(preds_t, targets_t)
+        B = ps.shape[1]
         mask = torch.ones(B, 3, device=self.device) if mask_channels is None else \
             torch.as_tensor(mask_channels).to(device=self.device, dtype=torch.float32)
         num_masked = torch.clamp(mask.sum(0), min=1.0)

@@ -1,0 +1,64 @@
+"""bench.py as the driver runs it: every --config produces one JSON line with the contract's fields, and the N > 1 path
+(one process per rank, here two ranks sharing the one GPU with gloo standing in for RCCL) gives the 1-rank eval result."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from util import ensure_lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ['--warmup', '1', '--no-autotune', '--no-cpu-baseline']
+
+
+def _run(args, world=1):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        if world > 1:
+            env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                       SAGEN_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world)] + args, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    lines = [l for o, _ in outs for l in o.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('config,batch', [('a', 10), ('av', 32), ('avf', 32)])
+def test_bench_configs_emit_the_contract_line(config, batch):
+    ensure_lib()
+    r = _run(['--config', config, '--steps', '4'] + FAST)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'one_in_flight', 'h2d_inclusive'):
+        assert k in r, k
+    assert r['n_gpus'] == 1 and r['steps'] == 4 and r['value'] > 0 and r['config']['windows_per_gpu_per_step'] == batch
+    assert r['config']['name'] == config and r['config']['workload'].startswith('configs[')
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(r['roofline'])
+    assert 0 < r['h2d_inclusive']['value'] and 0 < r['one_in_flight']['value']
+
+
+def test_bench_eval_config_two_ranks_match_one_rank():
+    """configs[3]: whole batches of ONE global window order dealt to the ranks; 2 ranks on this GPU must report the same
+    metric means as 1 rank (the batches, hence the batch-norm statistics, are identical), from one JSON line."""
+    ensure_lib()
+    one = _run(['--config', 'eval', '--steps', '12', '--in-flight', '1'] + FAST)
+    two = _run(['--config', 'eval', '--steps', '6', '--in-flight', '1'] + FAST, world=2)
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['scaling'] == 'strong'
+    # 1 rank timed batches 0..11 of its shard; with 2 ranks, rank 0 timed 0..5 and rank 1 timed 288..293: different windows of the
+    # pool, so compare only the bookkeeping here and the values through equal window sets below
+    assert two['config']['windows_per_s'] > 0 and two['steps'] == 6
+    full1 = _run(['--config', 'eval', '--steps', '0', '--in-flight', '1'] + FAST)
+    full2 = _run(['--config', 'eval', '--steps', '0', '--in-flight', '1'] + FAST, world=2)
+    assert full1['steps'] == 576 and full2['steps'] == 288
+    for k in ('stft', 'lsd', 'mse', 'snr'):
+        for a, b in zip(full1['eval_metric_means'][k], full2['eval_metric_means'][k]):
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (k, a, b)
