@@ -78,6 +78,9 @@ typedef struct {
 typedef struct sagen_ctx sagen_ctx;
 
 int  sagen_version(void);
+/* the compiler flags this library was built with (the Python host refuses a build without -fno-slp-vectorize -fno-vectorize:
+ * packed-fp32 VALU next to bf16 MFMA waves of another stream returned wrong results on MI355X) */
+const char* sagen_build_info(void);
 const char* sagen_last_error(void);
 
 /* ---- model-level: replaces SptAudioGen.inference_ops (model.py:356-434), as called at

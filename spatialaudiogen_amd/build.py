@@ -30,6 +30,14 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
+def flags_digest():
+    """Hash of everything besides the sources that decides what the objects contain: the flags and this file."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    h.update(open(os.path.abspath(__file__), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -40,6 +48,9 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
+    stamp = os.path.join(OBJ, 'flags.stamp')
+    if not os.path.exists(stamp) or open(stamp).read().strip() != flags_digest():
+        force = True                    # objects built with other flags (or by another build.py) are never reused
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -49,7 +60,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        cmd = [hipcc] + FLAGS + ['-DSAGEN_BUILD_FLAGS="%s"' % ' '.join(FLAGS), '-c', s, '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -69,6 +80,8 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stderr)
+    with open(stamp, 'w') as f:
+        f.write(flags_digest() + '\n')
     return LIB
 
 

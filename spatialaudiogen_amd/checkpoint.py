@@ -195,8 +195,9 @@ def read_index(index_fn):
     return entries, header
 
 
-def load_checkpoint(prefix, names=None):
-    """{name: ndarray} for every (or the requested) non-sliced tensor of checkpoint `prefix`."""
+def load_checkpoint(prefix, names=None, verify=True):
+    """{name: ndarray} for every (or the requested) non-sliced tensor of checkpoint `prefix`; with `verify` the per-tensor
+    crc32c of the index (when present) is checked."""
     entries, header = read_index(prefix + '.index')
     nshards = header.get('num_shards', 1)
     shards = {}
@@ -215,8 +216,10 @@ def load_checkpoint(prefix, names=None):
         count = int(np.prod(e['shape'])) if e['shape'] else 1
         if count * dt.itemsize != e['size']:
             raise ValueError('%s: size %d does not match shape %s' % (name, e['size'], e['shape']))
-        raw = shards[sid][e['offset']:e['offset'] + e['size']]
-        out[name] = np.frombuffer(raw.tobytes(), dtype=dt).reshape(e['shape']).copy()
+        raw = shards[sid][e['offset']:e['offset'] + e['size']].tobytes()
+        if verify and e['crc32c'] and _mask_crc(crc32c_bulk(raw)) != e['crc32c']:
+            raise ValueError('%s: tensor bytes fail the crc32c recorded in the index (corrupt checkpoint)' % name)
+        out[name] = np.frombuffer(raw, dtype=dt).reshape(e['shape']).copy()
     return out
 
 
@@ -259,6 +262,42 @@ def _mask_crc(c):
     return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
 
 
+def _crc_tables():
+    crc32c(b'')
+    return np.asarray(_CRC_TABLE, dtype=np.uint32)
+
+
+def crc32c_bulk(data, lanes=4096):
+    """crc32c of a large buffer (tensor payloads: up to tens of MB) in O(len / lanes) numpy steps.  The CRC register is affine
+    in its start value: R(chunk, r0) = R(chunk, 0) ^ Z_L(r0), Z_L = "process L zero bytes".  So the buffer is cut into `lanes`
+    equal chunks whose registers (from 0) advance together, one byte position per numpy step, and are then folded left to right
+    through Z_L (four 256-entry tables); head bytes that do not fill the lanes go through the scalar routine first."""
+    buf = np.frombuffer(bytes(data) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).tobytes(), dtype=np.uint8)
+    n = buf.size
+    if n < 4 * lanes:
+        return crc32c(buf.tobytes())
+    T = _crc_tables()
+    L = n // lanes
+    head = n - L * lanes
+    reg = 0xFFFFFFFF
+    for b in buf[:head].tolist():                       # < lanes bytes
+        reg = int(T[(reg ^ b) & 0xFF]) ^ (reg >> 8)
+    body = buf[head:].reshape(lanes, L)
+    r = np.zeros(lanes, dtype=np.uint32)
+    for j in range(L):
+        r = T[(r ^ body[:, j]) & np.uint32(0xFF)] ^ (r >> np.uint32(8))
+    # Z_L as byte tables: advance the four single-byte basis sets through L zero bytes (vectorised over the 256 values)
+    Z = []
+    for byte in range(4):
+        v = (np.arange(256, dtype=np.uint32) << np.uint32(8 * byte))
+        for _ in range(L):
+            v = T[v & np.uint32(0xFF)] ^ (v >> np.uint32(8))
+        Z.append(v)
+    for k in range(lanes):
+        reg = int(Z[0][reg & 0xFF]) ^ int(Z[1][(reg >> 8) & 0xFF]) ^ int(Z[2][(reg >> 16) & 0xFF]) ^ int(Z[3][(reg >> 24) & 0xFF]) ^ int(r[k])
+    return reg ^ 0xFFFFFFFF
+
+
 def _pb(field, wt, payload):
     return _put_varint((field << 3) | wt) + payload
 
@@ -270,6 +309,8 @@ def _entry_proto(arr, offset):
     if offset:
         msg += _pb(4, 0, _put_varint(offset))
     msg += _pb(5, 0, _put_varint(arr.nbytes))
+    # BundleEntryProto.crc32c (field 6, fixed32): masked crc32c of the tensor bytes - TF's BundleReader verifies it on restore
+    msg += _pb(6, 5, struct.pack('<I', _mask_crc(crc32c_bulk(arr))))
     return msg
 
 

@@ -59,6 +59,10 @@ using namespace sagen;
 extern "C" {
 
 int sagen_version(void) { return SAGEN_VERSION; }
+#ifndef SAGEN_BUILD_FLAGS
+#define SAGEN_BUILD_FLAGS "unknown"
+#endif
+const char* sagen_build_info(void) { return SAGEN_BUILD_FLAGS; }
 const char* sagen_last_error(void) { return err_buf(); }
 
 int sagen_create(sagen_ctx** out, const sagen_config* cfg) {

@@ -174,6 +174,9 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
                     "fft_window=0.025 (the geometry of every BASELINE config)");
     if (cfg->separation != SAGEN_SEP_NONE && cfg->separation != SAGEN_SEP_FREQ_MASK)
         return fail(SAGEN_ERR_UNSUPPORTED, "unknown separation mode %d", cfg->separation);
+    if (cfg->separation == SAGEN_SEP_NONE && cfg->num_sep_tracks > 1)
+        return fail(SAGEN_ERR_UNSUPPORTED, "separation 'none' decodes the mono track only: num_sep_tracks must be 1 (got %d); the reference's fc3 "
+                    "would be [.., 3*(num_sep_tracks+1)] (model.py:254) against a single separated track (model.py:274-280)", cfg->num_sep_tracks);
     if (cfg->separation == SAGEN_SEP_FREQ_MASK && cfg->num_sep_tracks != 16 && cfg->num_sep_tracks != 32 &&
         cfg->num_sep_tracks != 64)
         return fail(SAGEN_ERR_UNSUPPORTED, "num_sep_tracks=%d (supported 16/32/64)", cfg->num_sep_tracks);
@@ -767,6 +770,15 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     const bool forked = c->aux && !c->tuning && !one_stream && (c->has_video || c->has_flow);
     Fwd f{c, s};
     Fwd g{c, forked ? c->aux : s};
+    // error exit: work may still be queued on the context's stream, reading the caller's tensors / the workspace - the caller's
+    // stream must not run ahead of it (torch's caching allocator could hand that memory out again on `s`)
+    auto bail = [&](int rc) {
+        if (forked) {
+            if (hipEventRecord(c->ev_join, c->aux) == hipSuccess) (void)hipStreamWaitEvent(s, c->ev_join, 0);
+            else (void)hipStreamSynchronize(c->aux);
+        }
+        return rc;
+    };
     if (forked) {
         g.wsname = "splitk_aux";
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
@@ -834,7 +846,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         w.fc(c->p("fcred" + w.sfx), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
         choff += 512;
     }
-    if (g.rc) return g.rc;
+    if (f.rc || g.rc) return bail(f.rc ? f.rc : g.rc);
     if (forked) {
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
         SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -859,7 +871,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         }
         const int nlast = 3 * (c->nsep + 1);
         w.fc(x, B * 3, K, K, "localization/fc" + std::to_string(c->cfg.n_loc_units + 1), nlast, false, c->p("coeffs"), nlast);
-        if (g.rc) return g.rc;
+        if (f.rc || g.rc) return bail(f.rc ? f.rc : g.rc);
     }
 
     if (!c->freq_mask) {

@@ -96,7 +96,11 @@ class _Ctx(object):
 class SptAudioGen(object):
     def __init__(self, ambi_order, audio_rate=48000, video_rate=10, context=1., sample_duration=0.1,
                  encoders=None, separation='none', params=None, device=None):
-        params = params or SptAudioGenParams()
+        if params is None:              # defaults: 32 separated tracks; the mono-only decoder has exactly one (deploy.py:62-63 passes 1)
+            params = SptAudioGenParams(sep_num_tracks=1) if separation == NO_SEPARATION else SptAudioGenParams()
+        if separation == NO_SEPARATION and params.sep_num_tracks != 1:
+            raise ValueError("separation 'none' needs params.sep_num_tracks = 1 (got %r): the reference sizes fc3 with sep_num_tracks + 1 "
+                             "(model.py:254) against the single mono track of model.py:274-280" % (params.sep_num_tracks,))
         self.geom = Geometry(audio_rate=audio_rate, video_rate=video_rate, context=context,
                              sample_duration=sample_duration, ambi_order=ambi_order,
                              fft_window=params.sep_fft_window)        # asserts of model.py:33,42

@@ -73,6 +73,10 @@ def variable_specs(encoders, separation=FREQ_MASK, num_sep_tracks=32, loc_units=
         s['localization/fc%d/weights' % (i + 1)] = (cin, u)
         s['localization/fc%d/biases' % (i + 1)] = (u,)
         cin = u
+    if separation == NO_SEPARATION and num_sep_tracks not in (None, 1):
+        # the reference sizes fc3 with sep_num_tracks+1 whatever the mode (model.py:254) while NO_SEPARATION yields ONE track
+        # (model.py:274-280): only sep_num_tracks = 1 is consistent, and that is what its drivers pass (deploy.py:62-63)
+        raise ValueError("separation 'none' needs num_sep_tracks = 1 (got %r)" % (num_sep_tracks,))
     nsep = num_sep_tracks if separation != NO_SEPARATION else 1
     nlast = geom.num_out * geom.num_in * (nsep + 1)
     s['localization/fc%d/weights' % (len(loc_units) + 1)] = (cin, nlast)

@@ -73,3 +73,33 @@ def test_bad_files_are_rejected(tmp_path):
     with pytest.raises(ValueError):
         ck.read_index(str(p))
     assert ck.latest_checkpoint(str(tmp_path)) is None
+
+
+def test_crc32c_known_answers_and_bulk_path():
+    """crc32c (Castagnoli) known answers (RFC 3720 B.4) and the lane-parallel bulk routine against the scalar one."""
+    assert ck.crc32c(b'123456789') == 0xE3069283
+    assert ck.crc32c(bytes(32)) == 0x8A9136AA and ck.crc32c(b'\xff' * 32) == 0x62A8AB43
+    r = np.random.default_rng(5)
+    for n in (0, 1, 1000, 4 * 4096 - 1, 4 * 4096, 70001, 300000):
+        data = r.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert ck.crc32c_bulk(data, lanes=256 if n < 200000 else 4096) == ck.crc32c(data), n
+
+
+def test_writer_records_tensor_crcs_and_loader_checks_them(tmp_path):
+    """BundleEntryProto.crc32c (field 6): written masked, as TF's BundleWriter does, and verified on load: a flipped payload
+    byte must be reported, not loaded silently."""
+    P = {'a/weights': np.arange(12, dtype=np.float32).reshape(3, 4), 'b/biases': np.linspace(-1, 1, 7).astype(np.float32)}
+    prefix = str(tmp_path / 'model.ckpt-1')
+    ck.save_checkpoint(prefix, P)
+    entries, _ = ck.read_index(prefix + '.index')
+    for name, arr in P.items():
+        assert entries[name]['crc32c'] == ck._mask_crc(ck.crc32c(arr.tobytes())) != 0
+    got = ck.load_checkpoint(prefix)
+    assert all(np.array_equal(got[k], P[k]) for k in P)
+    fn = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(fn, 'rb').read())
+    raw[5] ^= 0x40
+    open(fn, 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='crc32c'):
+        ck.load_checkpoint(prefix)
+    assert ck.load_checkpoint(prefix, verify=False)['a/weights'].shape == (3, 4)

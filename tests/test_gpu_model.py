@@ -88,8 +88,11 @@ def test_trunk_without_presplit_planes(T):
 
 
 def test_no_separation_mode(T):
-    _, _, got, ref = run_pair(T, ['audio'], separation='none')
+    _, _, got, ref = run_pair(T, ['audio'], separation='none', nsep=1)
     check_out(got, ref)
+    from spatialaudiogen_amd.model import SptAudioGen, SptAudioGenParams
+    with pytest.raises(ValueError):                     # fc3 would be sized for 33 tracks against one mono track (model.py:254 vs :274-280)
+        SptAudioGen(1, encoders=['audio'], separation='none', params=SptAudioGenParams(sep_num_tracks=32))
 
 
 def test_other_widths(T):

@@ -5,7 +5,7 @@ R=$(cd $(dirname $0)/.. && pwd); B=$R/spatialaudiogen_amd/csrc/build; S=$R/spati
 mkdir -p $O
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -fno-vectorize"
 OBJS=$(ls $B/*.o | grep -v conv3p.o)
-build() {  # name, flags
+build() {  # name, flags (variant libraries keep the production flag string so _lib accepts them)
     /opt/rocm/bin/hipcc $FLAGS $2 -c $S/conv3p.hip -o $O/conv3p_$1.o 2>/dev/null || { echo "compile $1 failed"; return 1; }
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/conv3p_$1.o $OBJS -o $O/libsagen_$1.so || { echo "link $1 failed"; return 1; }
     rm -f $O/conv3p_$1.o; echo "built $O/libsagen_$1.so"
