@@ -216,6 +216,17 @@ int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, f
 int sagen_power_map_batched(const float* ambi_wyzx, int nchunks, int64_t t, const float* sh, int p, float* rms, double* moments,
                             void* stream);
 
+/* ---- training-step pieces (reference train.py:137-236; the network backward is not built yet) ----
+ * Loss of the reference: losses['stft/mse'] = metrics['stft/avg'] (model.py:156-159, 122-127; stft_for_loss myutils.py:151-178).
+ * pred / target [B,4800,3]; mask [B,3] channel mask or NULL; grad [B,4800,3] = dL/dpred (or NULL); loss = one fp64 (or NULL). */
+int sagen_stft_loss_grad(const float* pred_yzx, const float* target_yzx, const float* mask, int batch, float* grad, double* loss,
+                         void* stream);
+/* tf.train.AdamOptimizer (myutils.py:214-222) on one flat fp32 bucket of n floats (n % 4 == 0, 16-byte aligned):
+ * m,v slots updated in place, params -= lr_t * m / (sqrt(v) + epsilon); lr_t = lr * sqrt(1-beta2^t) / (1-beta1^t) from the host;
+ * grads are multiplied by grad_scale first (1 / world_size after a sum all-reduce). */
+int sagen_adam_update(float* params, const float* grads, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                      float epsilon, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

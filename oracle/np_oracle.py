@@ -490,3 +490,36 @@ def evaluation_ops(preds, targets, mask_channels=None, snd_rate=48000, fft_windo
     metrics['pow/pred'] = (preds ** 2).mean(axis=2).mean(axis=0).sum()
     metrics['pow/gt'] = (targets ** 2).mean(axis=2).mean(axis=0).sum()
     return metrics, stft_ps, lsd_ps, mse_ps, snr_ps
+
+
+# ----------------------------------------------------------------------------------------
+# training loss and optimiser (model.py:156-159, myutils.py:214-222) - checker for spatialaudiogen_amd/train.py
+# ----------------------------------------------------------------------------------------
+def stft_loss(pred, gt, mask_channels=None):
+    """losses['stft/mse'] = metrics['stft/avg'] (model.py:156-159): the FFT form of model.py:62-76,122-127."""
+    return evaluation_ops(pred, gt, mask_channels)[0]['stft/avg']
+
+
+def stft_loss_grad_fd(pred, gt, mask_channels, probes, h=1e-3):
+    """Central finite differences of stft_loss at the (b, n, c) index triples `probes` (fp64)."""
+    out = []
+    for (b, n, c) in probes:
+        p1, p2 = pred.copy(), pred.copy()
+        p1[b, n, c] += h
+        p2[b, n, c] -= h
+        out.append((stft_loss(p1, gt, mask_channels) - stft_loss(p2, gt, mask_channels)) / (2 * h))
+    return np.array(out)
+
+
+def adam_tf(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer, dense update, as TF 1.4 documents it (the 'epsilon hat' form):
+    lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);  m, v moments;  p -= lr_t m / (sqrt(v) + eps).  Returns (p, m, v)."""
+    lr_t = lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    return p - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+def exponential_decay_staircase(lr, step, decay_steps, decay_rate):
+    """tf.train.exponential_decay(..., staircase=True) (myutils.py:215-218)."""
+    return lr * decay_rate ** (step // decay_steps)

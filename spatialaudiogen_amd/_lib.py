@@ -67,6 +67,8 @@ SIGNATURES = {
     'sagen_eval_init': (C.c_int, [_P, _SZ, _I, _P]),
     'sagen_eval_metrics': (C.c_int, [_P, _P, _I, _P, _P, _P, _SZ, _P]),
     'sagen_power_map': (C.c_int, [_P, _I64, _P, _I, _P, _P]),
+    'sagen_stft_loss_grad': (C.c_int, [_P, _P, _P, _I, _P, _P, _P]),
+    'sagen_adam_update': (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),
     'sagen_power_map_batched': (C.c_int, [_P, _I, _I64, _P, _I, _P, _P, _P]),
 }
 

@@ -352,4 +352,21 @@ int sagen_power_map_batched(const float* ambi_wyzx, int nchunks, int64_t t, cons
     return power_map_batched_launch(ambi_wyzx, nchunks, t, sh, p, rms, moments, (hipStream_t)stream);
 }
 
+int sagen_stft_loss_grad(const float* pred_yzx, const float* target_yzx, const float* mask, int batch, float* grad, double* loss,
+                         void* stream) {
+    if (!pred_yzx || !target_yzx || (!grad && !loss)) return fail(SAGEN_ERR_NULL, "sagen_stft_loss_grad: null argument");
+    if (batch <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_stft_loss_grad: batch=%d", batch);
+    if (loss && ((uintptr_t)loss) % 8) return fail(SAGEN_ERR_SHAPE, "sagen_stft_loss_grad: loss must be 8-byte aligned");
+    return stft_loss_grad_launch(pred_yzx, target_yzx, mask, batch, grad, loss, (hipStream_t)stream);
+}
+
+int sagen_adam_update(float* params, const float* grads, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                      float epsilon, float grad_scale, void* stream) {
+    if (!params || !grads || !m || !v) return fail(SAGEN_ERR_NULL, "sagen_adam_update: null argument");
+    if (n <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_adam_update: n=%ld", (long)n);
+    if ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) % 16)
+        return fail(SAGEN_ERR_SHAPE, "sagen_adam_update: buckets must be 16-byte aligned");
+    return adam_update_launch(params, grads, m, v, n, lr_t, beta1, beta2, epsilon, grad_scale, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -29,7 +29,9 @@
 // other is typically in its prologue / epilogue.  A PERSISTENT variant (workgroups pulling tiles from per-XCD ticket
 // counters, the next tile's first group issued under the current tile's last group, epilogue through the freed ring stage)
 // was built and measured (tools/ubench_p3.py): two workgroups that are BOTH permanently in their K loops take
-// 3.4k cycles per group instead of 2.1k, and the layer 116 us instead of 88 - not kept.
+// 3.4k cycles per group instead of 2.1k, and the layer 116 us instead of 88 - not kept.  Tiles 256x64 and 64x128 (one
+// workgroup per CU) were also built: never faster than 128x64 / 64x64 inside the forward (the tuner's isolated timing liked
+// 64x128 for the 512-channel layers, 85 us, where it then ran 114 us) - removed.
 #include "igemm3_common.h"
 #include <cstdlib>
 
@@ -396,9 +398,7 @@ int conv3p_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     switch (tile) {
         case TILE_P3_128x64: return launch_conv3p<128, 64, 64, 32>(d, s);
         case TILE_P3_128x128: return launch_conv3p<128, 128, 64, 64>(d, s);
-        case TILE_P3_256x64: return launch_conv3p<256, 64, 64, 64>(d, s);
         case TILE_P3_64x64: return launch_conv3p<64, 64, 32, 32>(d, s);
-        case TILE_P3_64x128: return launch_conv3p<64, 128, 32, 64>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: bad tile id %d", (int)tile);
     }
 }

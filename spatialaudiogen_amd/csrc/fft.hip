@@ -150,7 +150,9 @@ template <int NTR>
 __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ dmask, long dmask_bstride, int dmask_f0,
                                                          const float2* __restrict__ spec, const float* __restrict__ coeffs,
                                                          float* __restrict__ frames) {
-    __shared__ float2 bufA[1024], bufB[1024];
+    __shared__ __attribute__((aligned(16))) float2 fftbuf[2048];      // FFT ping-pong; before that: staging of the mask rows
+    float2* const bufA = fftbuf;
+    float2* const bufB = fftbuf + 1024;
     __shared__ float E[6][1024];
     __shared__ float2 X[513];
     __shared__ float wl[2][3][NTR];
@@ -166,33 +168,55 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
         wl[si][o][j] = coeffs[(((long)b * 3 + st) * 3 + o) * (NTR + 1) + j];
     }
     for (int k = tid; k < 513; k += 256) X[k] = spec[((long)b * 28 + f) * 513 + k];
-    __syncthreads();
 
-    const float* drow = dmask + (long)b * dmask_bstride + (long)(f - dmask_f0) * 1024 * NTR;
+    // ---- E[c][k] = sum_j w_c[j] * sigmoid(mask[k][j]): the 128 KiB of mask rows of this frame are the kernel's HBM traffic.
+    // They are read as ONE contiguous stream (16 bytes per lane, 1 KiB per wave-instruction), parked in LDS (16-byte chunks
+    // XOR-swizzled by the row so the row-wise reads below spread over the banks) and consumed by NTR/16 lanes per bin; the next
+    // pass's loads are in flight while the current one is reduced.  (The first version let every lane walk its own 128-byte row:
+    // 64 cache lines per load instruction, 1.07 TB/s.)
+    constexpr int NC = NTR / 4;                  // 16-byte chunks per mask row
+    constexpr int RPP = 4096 / NTR;              // rows per pass (16 KiB of staging)
+    constexpr int TPRW = 256 / RPP;              // lanes per row: each takes 16 tracks
+    constexpr int NPASS = 1024 / RPP;
+    float4* const stage = reinterpret_cast<float4*>(fftbuf);
+    const float4* src = reinterpret_cast<const float4*>(dmask + (long)b * dmask_bstride + (long)(f - dmask_f0) * 1024 * NTR);
+    float4 nx0 = src[tid], nx1 = src[tid + 256], nx2 = src[tid + 512], nx3 = src[tid + 768];      // (named: an array here ended up in scratch)
+    __syncthreads();                             // wl / X visible
+    const int row = tid / TPRW, part = tid % TPRW;
+    auto park = [&](int i, const float4& v) {
+        const int idx = tid + 256 * i, r = idx / NC, ch = idx % NC;
+        stage[r * NC + (ch ^ (r & (NC - 1)))] = v;
+    };
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-        const int k = tid + 256 * t;
-        const float4* p = reinterpret_cast<const float4*>(drow + (long)k * NTR);
+    for (int ps = 0; ps < NPASS; ++ps) {
+        park(0, nx0); park(1, nx1); park(2, nx2); park(3, nx3);
+        __syncthreads();
+        const int pn = ps + 1 < NPASS ? ps + 1 : ps;         // (the last pass re-reads its own rows: keeps the loop body branch-free)
+        nx0 = src[pn * 1024 + tid]; nx1 = src[pn * 1024 + tid + 256]; nx2 = src[pn * 1024 + tid + 512]; nx3 = src[pn * 1024 + tid + 768];
         float e[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j4 = 0; j4 < NTR / 4; ++j4) {
-            const float4 v = p[j4];
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = stage[row * NC + ((part * 4 + q) ^ (row & (NC - 1)))];
             const float sg[4] = {1.f / (1.f + expf(-v.x)), 1.f / (1.f + expf(-v.y)), 1.f / (1.f + expf(-v.z)),
                                  1.f / (1.f + expf(-v.w))};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j4 * 4 + q;
+            for (int u = 0; u < 4; ++u) {
+                const int j = (part * 4 + q) * 4 + u;
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    e[o] = fmaf(wl[0][o][j], sg[q], e[o]);
-                    if (two) e[3 + o] = fmaf(wl[1][o][j], sg[q], e[3 + o]);
+                    e[o] = fmaf(wl[0][o][j], sg[u], e[o]);
+                    if (two) e[3 + o] = fmaf(wl[1][o][j], sg[u], e[3 + o]);
                 }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) E[c][k] = e[c];
+        for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int m = 1; m < TPRW; m <<= 1) e[c] += __shfl_xor(e[c], m);
+            if (part == 0) E[c][ps * RPP + row] = e[c];
+        }
+        __syncthreads();                         // the staging area is rewritten by the next pass (and then by the FFT)
     }
-    __syncthreads();
 
     float* fout = frames + ((long)b * MASK_NF + fi) * 3 * 1024;
     const int npack = two ? 3 : 2;

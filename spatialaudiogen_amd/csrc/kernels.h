@@ -88,7 +88,7 @@ enum IgemmTile {
     // bf16x3 for the 7x7 stride-2 stem over the padded 4-channel image, K ordered (dh, dw padded to 8, c) (igemm3s2_kernel)
     TILE_B3S2_256x64, TILE_B3S2_128x64,
     // bf16x3 for dense 3x3 stride-1 SAME convs over pre-split activation planes (conv3p_kernel; needs IgemmDesc::xp3)
-    TILE_P3_128x64, TILE_P3_128x128, TILE_P3_256x64, TILE_P3_64x64, TILE_P3_64x128,
+    TILE_P3_128x64, TILE_P3_128x128, TILE_P3_64x64,
     TILE_AUTO
 };
 
@@ -180,5 +180,12 @@ size_t eval_scratch_floats(int B);
 int eval_init_launch(float* scratch, hipStream_t s);                  // fills the DFT matrix once
 // ps [4][B][3] = per-sample stft distance, lsd, temporal mse, snr;  pw[2] = sum pred^2, sum gt^2 (fp64)
 int eval_metrics_launch(const float* pred, const float* gt, int B, float* ps, double* pw, float* scratch, hipStream_t s);
+
+// -----------------------------------------------------------------------------------------
+// training-step pieces (train.hip): stft loss + gradient w.r.t. the prediction, fused Adam over a flat bucket
+// -----------------------------------------------------------------------------------------
+int stft_loss_grad_launch(const float* pred, const float* gt, const float* mask, int B, float* grad, double* loss, hipStream_t s);
+int adam_update_launch(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
+                       float gscale, hipStream_t s);
 
 }  // namespace sagen

@@ -301,6 +301,9 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         const std::string enc = (set == 1 || !c->has_video) ? "flow_encoder" : "video_encoder";
         c->expose(enc + "/conv5_2", "rx0" + x, 0, {B, 7, 14, 512}, 512);
     }
+    // scratch the tuner overwrites between candidate timings to cool the L2 (any buffer that is dead while a contraction runs
+    // and is rewritten before its next use: the mask buffer, else the second stream's split-K scratch)
+    c->bufs["dmask_or_scratch_flush"] = c->freq_mask ? c->bufs.at("dmask") : c->bufs.at("splitk_aux");
     // intermediates for parity tests
     c->expose("mag", "mag", 0, {B, 127, 1024, 1}, 1);
     c->expose("stft", "spec", 0, {B, 28, 513, 2}, 2);
@@ -462,6 +465,10 @@ struct Fwd {
 
     // one timed launch (group) of a candidate, in microseconds
     float time_once(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
+        // cold L2: in the forward a layer's filters and activations are not L2-resident from a previous run of the SAME layer;
+        // back-to-back timing made the tuner prefer tiles that only win on warm caches (conv5 planes: 14 MB)
+        const Buf& fl = c->bufs.at("dmask_or_scratch_flush");
+        (void)hipMemsetAsync(c->ws + fl.off, 0, std::min<size_t>(fl.n * sizeof(float), (size_t)48 << 20), s);
         (void)hipEventRecord(c->tune_e0, s);
         run_choice(d, rep, tile, sk);
         (void)hipEventRecord(c->tune_e1, s);

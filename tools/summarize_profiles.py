@@ -19,7 +19,7 @@ with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns'])
     rows = [r for r in rows if not r['Name'].startswith('Cijk_')]      # the host's stream-concurrency probe (torch.mm), not the path
-    for r in rows[:24]:
+    for r in rows[:30]:
         w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], '%.1f' % float(r['AverageNs']), r['Percentage'], r['MinNs'], r['MaxNs']])
 
 # 2. PMC passes: per-kernel mean of each counter
@@ -35,7 +35,7 @@ for sub in ('fetch', 'write', 'sq', 'sq2'):
         for c, v in d.items():
             pmc[k][c] = sum(v) / len(v)
             pmc[k]['launches_' + sub] = len(v)
-keep = {k: v for k, v in pmc.items() if 'igemm' in k or 'kernel' in k and not k.startswith('at::')}
+keep = {k: v for k, v in pmc.items() if 'igemm' in k or 'conv3p' in k or 'kernel' in k and not k.startswith('at::')}
 json.dump(keep, open(os.path.join(dst, tag + '_pmc_per_launch.json'), 'w'), indent=1, sort_keys=True)
 
 # 3. HBM traffic per launch for bench.py's roofline.traffic: FETCH_SIZE/WRITE_SIZE are in KiB-ish units of
@@ -52,7 +52,7 @@ json.dump(traffic, open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1
 label = {}
 wsum = collections.defaultdict(lambda: [0.0, 0.0])
 for k, v in traffic.items():
-    if k.startswith('igemm_kernel<') or k.startswith('igemm3s2_kernel<'):
+    if k.startswith('igemm_kernel<') or k.startswith('igemm3s2_kernel<') or k.startswith('conv3p_kernel<'):
         label[k.replace(' ', '')] = round(v['hbm_bytes_fetch_x2'])
     elif k.startswith('igemm3_kernel<') or k.startswith('igemm3dw_kernel<'):
         # the runtime labels the bf16x3 kernels without their last template argument (batch-norm prologue flag):
@@ -69,5 +69,5 @@ if os.path.exists(b):
     open(os.path.join(dst, tag + '_bench_under_rocprof.json'), 'w').write(open(b).read())
 print(open(os.path.join(dst, tag + '_kernel_stats.csv')).read())
 for k, v in sorted(keep.items()):
-    if 'igemm' in k:
+    if 'igemm' in k or 'conv3p' in k or 'p3_' in k:
         print(k, {c: ('%.4g' % x) for c, x in v.items() if not c.startswith('launches')})
