@@ -515,8 +515,13 @@ def adam_tf(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     """tf.train.AdamOptimizer, dense update, as TF 1.4 documents it (the 'epsilon hat' form):
     lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);  m, v moments;  p -= lr_t m / (sqrt(v) + eps).  Returns (p, m, v)."""
     lr_t = lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
-    m = beta1 * m + (1 - beta1) * g
-    v = beta2 * v + (1 - beta2) * g * g
+    # the variables are float32, so TF casts beta1 / beta2 to float32 and forms (1 - beta) in float32 (training_ops:
+    # ApplyAdam on float): 1 - 0.999f = 9.9998713e-4, 1.3e-5 off the real 1e-3.  The coefficients are restated with that
+    # rounding; the accumulation itself is done in float64 here.
+    b1, b2 = np.float32(beta1), np.float32(beta2)
+    omb1, omb2 = float(np.float32(1) - b1), float(np.float32(1) - b2)
+    m = float(b1) * m + omb1 * g
+    v = float(b2) * v + omb2 * g * g
     return p - lr_t * m / (np.sqrt(v) + eps), m, v
 
 

@@ -61,6 +61,7 @@ struct sagen_ctx {
     bool tuning = false;
     bool fp32_only = false;                      // SAGEN_FP32_ONLY=1: never use the bf16x3 tiles
     bool use_p3 = true;                          // 3x3 stride-1 trunk convs read pre-split bf16 planes (conv3p.hip); SAGEN_NO_P3=1 disables
+    int p3_from_stage = 3;                       // ... from this ResNet stage on (2..5; SAGEN_P3_FROM_STAGE): see resnet()
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
     hipStream_t aux = nullptr;
@@ -188,6 +189,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
 
     c->fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
     c->use_p3 = !c->fp32_only && getenv("SAGEN_NO_P3") == nullptr;
+    if (const char* e = getenv("SAGEN_P3_FROM_STAGE")) c->p3_from_stage = atoi(e);
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
@@ -668,7 +670,7 @@ struct Fwd {
             layer = name;
             contract(d);
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
-            if (c->use_p3)       // pooled block input as fp32 (residual) AND as planes (operand of conv2_1/conv_1)
+            if (c->use_p3 && c->p3_from_stage <= 2)       // pooled block input as fp32 (residual) AND as planes (operand of conv2_1/conv_1)
                 timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s); });
             else
                 timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
@@ -694,14 +696,18 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                void* planes = c->use_p3 ? (void*)c->p("p3" + sfx) : nullptr;
+                // Pre-split planes pay where the tensors are small next to the contraction: per residual block the plane-writing
+                // passes cost 77 / 38 / 27 / 22 us (stage 2..5, batch 32) against ~30 / 15 / 8 / 5 us for the fp32 BN passes they
+                // replace, while conv3p saves ~19 us per conv at every stage (profiles/r02_*): stage 2 stays on igemm3dw.
+                const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage;
+                void* planes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;
                 // stride-1 conv_1: its input planes were written by the pool / the previous block's merge
                 conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "",
                         stride == 1 ? planes : nullptr);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
-                if (c->use_p3) {
+                if (p3_here) {
                     // relu(bn1(y1)) -> planes (one elementwise pass), conv_2 on the planes, then the residual merge, which also
                     // writes the planes of the block output when the next conv_1 is a stride-1 3x3 (unit 1 of a stage)
                     layer = pfx + "/bn1-relu";
@@ -709,7 +715,8 @@ struct Fwd {
                     conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes);
                     const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                     layer = pfx + "/merge";
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, xout, unit == 1 ? planes : nullptr, B, Ho, Wo, cout, s); });
+                    const bool next_p3 = unit == 1;      // the next conv_1 is a stride-1 3x3 of this stage
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s); });
                     ++li;
                     std::swap(xin, xout);
                     H = Ho; W = Wo; cin = cout;
