@@ -197,9 +197,16 @@ def main(argv=None):
     ap.add_argument('--overwrite', action='store_true')
     ap.add_argument('--partial_batch', choices=['drop', 'pad'], default='drop',
                     help="trailing windows that do not fill a batch of 16: 'drop' (the reference's queue never dequeues them) or 'pad' with zero windows")
+    ap.add_argument('--power_maps', action='store_true',
+                    help='also compute the per-sample directional RMS maps of prediction and ground truth on the device (the inputs of the '
+                         "reference's EMD metric, eval.py:188-191) and save this rank's maps to <model_dir>/eval-powermaps-rank<r>.npz")
     args = ap.parse_args(argv)
     means, count = evaluate(args.model_dir, args.db_dir, args.subset_fn, args.layouts_fn, overwrite=args.overwrite,
-                            partial_batch=args.partial_batch)
+                            partial_batch=args.partial_batch, power_maps=args.power_maps)
+    if args.power_maps and evaluate.last_maps:
+        maps = evaluate.last_maps                      # [pred, gt, pred, gt, ...] per batch, each [n, 7, 12]
+        np.savez(os.path.join(args.model_dir, 'eval-powermaps-rank%d.npz' % int(os.environ.get('RANK', 0))),
+                 pred=np.concatenate(maps[0::2], 0), gt=np.concatenate(maps[1::2], 0))
     if int(os.environ.get('RANK', 0)) == 0:
         print('EVAL | %d samples' % count)
         for k, v in means.items():

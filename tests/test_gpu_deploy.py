@@ -107,7 +107,7 @@ def test_evaluate_driver_matches_oracle(tmp_path):
         clips[name] = np.concatenate([F.load_wav(os.path.join(str(db / name), 'ambix', '%06d.wav' % k))[0] for k in range(3)], 0)
     (tmp_path / 'layouts.txt').write_text('clipA WXYZ\nclipB WXY\n')
     means, count = evaluate(str(model_dir), str(db), None, str(tmp_path / 'layouts.txt'), variables=P, params=Params(enc),
-                            partial_batch='pad')
+                            partial_batch='pad', power_maps=True)
     assert count == 4                                                # 20 windows per clip, every 10th -> 2 per clip
     lines = open(str(model_dir / 'eval-detailed.txt')).read().splitlines()
     assert lines[0] == 'SampleID | ' + ' '.join(METRIC_KEYS) and len(lines) == 5 and lines[1].startswith('clipA 0.5 |')
@@ -129,6 +129,14 @@ def test_evaluate_driver_matches_oracle(tmp_path):
            'snr/avg': np.mean(snr_ps[:4]), 'stft/Z': np.mean(stft_ps[:4, 1]), 'amplitude/gt': np.mean(np.abs(target[:4]).max(axis=(1, 2)))}
     for key, v in ref.items():
         assert abs(means[key] - v) <= 2e-3 * max(1e-3, abs(v)) + 1e-6, (key, means[key], v)
+    # per-sample directional RMS maps of the masked WYZX prediction / ground truth (inputs of eval.py:188-191's EMD), 30 degree mesh
+    maps = evaluate.last_maps
+    assert len(maps) == 2 and maps[0].shape == (4, 7, 12) and maps[1].shape == (4, 7, 12)
+    for k in range(4):
+        mono = amb[k, 24000:28800, :1]
+        for got, x in ((maps[0][k], pred[k]), (maps[1][k], target[k])):
+            wyzx = np.concatenate([mono, x], 1) * masks[k][None, :]
+            assert np.abs(got - O.power_map(wyzx, 30.0)).max() <= 1e-4 * max(1.0, np.abs(got).max())
 
 
 def _write_model_dir(model_dir, P, encoders):
