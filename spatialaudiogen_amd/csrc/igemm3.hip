@@ -327,7 +327,8 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
         if (t + 1 < nsteps) step(std::integral_constant<int, 1>{}, t + 1);
     }
 
-    igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
+    if (!igemm_epilogue_rows<BM, BN, WM, WN, 2 * STAGE_F>(d, acc, s_row, smem, n0, tid))
+        igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, bool PRO>

@@ -232,7 +232,8 @@ __device__ __forceinline__ void igemm3s2_body(const IgemmDesc& d) {
         if (g + 1 < ngroups) gstep(std::integral_constant<int, 1>{});
     }
 
-    igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
+    if (!igemm_epilogue_rows<BM, BN, WM, WN, 2 * A_ST + 2 * B_ST>(d, acc, s_row, smem, n0, tid))
+        igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
 }
 
 template <int BM, int BN, int WM, int WN>
