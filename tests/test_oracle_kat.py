@@ -149,3 +149,25 @@ def test_decoder_selects_track_and_step():
     assert rms(y[:, :, 0] - tr[:, 4]) < 1e-12 and np.abs(y[:, :, 1] - 0.25).max() < 1e-12 and rms(y[:, :, 2] + tr[:, 9]) < 1e-12
     assert orc.ends['separation/deconv1'].shape == (1, 127, 1024, 32)
     assert orc.ends['separation/mask'].shape == (1, 1, 32, 28, 1024)
+
+
+def test_stft_loss_is_a_weighted_time_domain_energy():
+    """Parseval form used by csrc/train.hip and csrc/eval.hip: the stft distance of stft_for_loss (three Hann frames of 2048,
+    myutils.py:151-178; model.py:62-76) equals (1/3) sum_n W2[n] (gt - pred)[n]^2, W2 = sum of hann^2 over the covering frames;
+    the training loss (model.py:122-127,156-159) is its masked channel mean x100, and its gradient follows in closed form."""
+    r = rng(77)
+    B = 3
+    gt = 0.3 * r.normal(size=(B, 4800, 3))
+    pred = gt + 0.1 * r.normal(size=gt.shape)
+    mask = np.ones((B, 3)); mask[2, 1] = 0.0
+    n = np.arange(4800)
+    h = lambda m: 0.5 - 0.5 * np.cos(2 * np.pi * m / 2048.0)
+    w2 = np.where(n < 4096, h(n % 2048) ** 2, 0.0) + np.where((n >= 1024) & (n < 3072), h(n - 1024) ** 2, 0.0)
+    dist = (w2[None, :, None] * (gt - pred) ** 2).sum(1) / 3.0                     # [B, 3]
+    nm = np.maximum(mask.sum(0), 1)
+    closed = np.mean(100.0 * (dist * mask).sum(0) / nm)
+    assert abs(O.stft_loss(pred, gt, mask) - closed) <= 1e-7 * closed        # (the oracle's window is rounded to float32 like TF's)
+    grad = (100.0 / 3.0) / nm[None, None, :] * mask[:, None, :] * (2.0 / 3.0) * w2[None, :, None] * (pred - gt)
+    probes = [(0, 100, 0), (1, 2047, 2), (2, 3000, 1), (2, 3000, 0), (0, 4500, 1)]
+    fd = O.stft_loss_grad_fd(pred, gt, mask, probes)
+    assert np.abs(fd - np.array([grad[p] for p in probes])).max() <= 1e-6 * np.abs(grad).max()
