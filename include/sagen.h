@@ -216,9 +216,10 @@ int sagen_power_map(const float* ambi_wyzx, int64_t t, const float* sh, int p, f
 int sagen_power_map_batched(const float* ambi_wyzx, int nchunks, int64_t t, const float* sh, int p, float* rms, double* moments,
                             void* stream);
 
-/* ---- training-step pieces (reference train.py:137-236; the network backward is not built yet) ----
+/* ---- training step (reference train.py:137-236) -------------------------------------------------------
  * Loss of the reference: losses['stft/mse'] = metrics['stft/avg'] (model.py:156-159, 122-127; stft_for_loss myutils.py:151-178).
- * pred / target [B,4800,3]; mask [B,3] channel mask or NULL; grad [B,4800,3] = dL/dpred (or NULL); loss = one fp64 (or NULL). */
+ * pred / target [B,4800,3]; mask [B,3] channel mask (the Y,Z,X columns of the feeder's [B,4] W,Y,Z,X mask, train.py:127) or NULL;
+ * grad [B,4800,3] = dL/dpred (or NULL); loss = one fp64 (or NULL). */
 int sagen_stft_loss_grad(const float* pred_yzx, const float* target_yzx, const float* mask, int batch, float* grad, double* loss,
                          void* stream);
 /* tf.train.AdamOptimizer (myutils.py:214-222) on one flat fp32 bucket of n floats (n % 4 == 0, 16-byte aligned):
@@ -226,6 +227,55 @@ int sagen_stft_loss_grad(const float* pred_yzx, const float* target_yzx, const f
  * grads are multiplied by grad_scale first (1 / world_size after a sum all-reduce). */
 int sagen_adam_update(float* params, const float* grads, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                       float epsilon, float grad_scale, void* stream);
+
+/* One sess.run(train_op) without the optimiser (train.py:208; opt.minimize = compute_gradients + apply_gradients,
+ * myutils.py:220-221): forward with retained activations, loss, backward.  Replaces tf.gradients over the graph of
+ * model.py:356-434 for separation 'unet_mask'.
+ *  - the ctx must be bound (sagen_bind_weights) to the LIVE parameter tensors: every sagen_train_step re-packs the filters from
+ *    them first, so the optimiser may update them in place between steps;
+ *  - sagen_train_bind: `grads` names, for every trainable variable, where its gradient is written (same name / shape / layout
+ *    as the variable; e.g. views into flat gradient buckets); `moving` (optional) names writable bn/moving_mean and
+ *    bn/moving_variance tensors, updated like the contrib batch_norm update ops (decay 0.99) when update_moving_averages != 0;
+ *    train_workspace: >= sagen_train_workspace_bytes(ctx) bytes, 256-byte aligned, owned by the caller, used only by this ctx;
+ *  - sagen_train_step: target_yzx [B,4800,3], mask [B,3] or NULL, pred_yzx [B,4800,3] or NULL (the prediction of this step),
+ *    loss: device pointer to one fp64 or NULL.  Asynchronous on `stream`; gradients are complete when the stream reaches the end
+ *    of the call's work.  Weight gradients are reduced in a fixed order (bit-reproducible). */
+size_t sagen_train_workspace_bytes(sagen_ctx* ctx);
+int sagen_train_bind(sagen_ctx* ctx, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving,
+                     void* train_workspace, size_t train_workspace_bytes, void* stream);
+int sagen_train_step(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
+                     const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream);
+/* named buffer of the train workspace (parity tests): e.g. "t:dcoeffs" [B*3][100], "t:ddmask" [B,31,1024,ntracks] (deconv1 output
+ * rows 40..70), "t:dpred", "t:g:feat" (dL/d conv5_2) */
+int sagen_train_get_buffer(const sagen_ctx* ctx, const char* name, const float** data, size_t* n_floats);
+
+/* ---- backward, op level (unit-testable) ------------------------------------------------------------------------------
+ * Filter gradient of tf.nn.convolution / tf.nn.conv2d_transpose / tf.matmul (core.py:206,140,79) in one form:
+ *   dw[th,tw,g,d] = sum_{b,i,j} G[b, i*sh + th + h0, j*sw + tw + w0, g] * D[b,i,j,d]      (G zero outside [hg) x [wg))
+ * conv (HWIO): G = x [B,hg,wg,cg=cin], D = dy [B,hd,wd,cd=cout], h0/w0 = -pad_before; conv2d_transpose ([kh,kw,Cout,Cin]):
+ * G = dy, D = x, h0 = w0 = 0; FC: hg = wg = hd = wd = kh = kw = 1, batch = rows.  cg, cd multiples of 4.  scratch (optional,
+ * sagen_wgrad_scratch_bytes) enables pixel-range splitting. */
+size_t sagen_wgrad_scratch_bytes(int kh, int kw, int cg, int cd);
+int sagen_wgrad(const float* g, int batch, int hg, int wg, int cg, const float* d, int hd, int wd, int cd, int kh, int kw, int sh, int sw,
+                int h0, int w0, float* dw, void* scratch, size_t scratch_bytes, void* stream);
+/* Input gradient of tfw.conv_2d (core.py:206): dy [B,hout,wout,cout], w HWIO -> dx [B,h,w,cin].  Stride 1: any padding; strided:
+ * VALID, or SAME with no padding before (every strided conv of the path).  cout a power of two >= 4. */
+size_t sagen_conv2d_bwd_data_scratch_bytes(int kh, int kw, int cin, int cout, int sh, int sw);
+int sagen_conv2d_bwd_data(const float* dy, int batch, int hout, int wout, int cout, const float* w_hwio, int kh, int kw, int cin,
+                          int sh, int sw, int padding, int h, int w, float* dx, void* scratch, size_t scratch_bytes, void* stream);
+/* contrib batch_norm (training mode) backward: dz = (ga + gb) * (act > 0) (gb, act nullable) is the gradient at the BN output;
+ * bn_stats = the accumulators sagen_conv2d filled for the raw conv output y.  dy = gradient at y; dz (nullable) = the masked
+ * gradient itself; dgamma / dbeta [C].  scratch: 2*C doubles, 8-byte aligned. */
+int sagen_bn_bwd(const float* ga, const float* gb, const float* act, const float* y, const float* bn_stats, const float* gamma,
+                 const float* beta, float eps, int64_t n_pixels, int c, float* dy, float* dz, float* dgamma, float* dbeta,
+                 void* scratch, size_t scratch_bytes, void* stream);
+/* backward of sagen_maxpool3x3s2(relu(bn(y0))): pooled = its output, ga (+ gb) = gradient at the pooled tensor -> dz at bn(y0) */
+int sagen_maxpool3x3s2_bwd(const float* y0, const float* bn_stats, const float* gamma, const float* beta, float eps, const float* pooled,
+                           const float* ga, const float* gb, float* dz, int batch, int h, int w, int c, void* stream);
+/* adjoint of sagen_mask_istft_mix: dpred [B,4800,3] -> d_dmask [B,28,1024,ntracks], d_coeffs [B,3,3,ntracks+1] */
+size_t sagen_mask_istft_mix_bwd_scratch_bytes(int batch, int ntracks);
+int sagen_mask_istft_mix_bwd(const float* dmask, const float* spec, const float* coeffs, const float* dpred, int batch, int ntracks,
+                             float* d_dmask, float* d_coeffs, void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,9 @@ class TorchRef(object):
 
     @torch.no_grad()
     def forward(self, audio, video=None, flow=None):
+        return self._forward(audio, video, flow)
+
+    def _forward(self, audio, video=None, flow=None):
         P, dt = self.P, self.dt
         audio = torch.as_tensor(np.asarray(audio)).to(dt)[:, :, 0]           # [B, 52799]
         B = audio.shape[0]
@@ -122,6 +125,7 @@ class TorchRef(object):
         for i in range(self.n_loc):
             x = self.fc(x, 'localization/fc%d' % (i + 1))
         x = self.fc(x, 'localization/fc%d' % (self.n_loc + 1), act=False).reshape(B, 3, 3, self.nsep + 1)
+        self.ends['localization/coeffs'] = x
         w_loc, b_loc = x[..., :-1], x[..., -1]                             # [B,step,o,k], [B,step,o]
         # separation (model.py:282-348)
         f = self.fc(feats, 'separation/fc-feats')                          # [B,3,512]
@@ -133,6 +137,7 @@ class TorchRef(object):
             if l == 0:
                 break
             x = torch.cat([F.relu(x), enc[l]], 1)
+        self.ends['separation/deconv1'] = x
         m = torch.sigmoid(x[:, :, 43:71, :])                               # [B,32,28,1024]
         sep = S[:, None, 89:117, :] * m                                    # complex
         y = torch.fft.ifft(sep, dim=-1).real.to(dt)                        # [B,32,28,1024]
@@ -145,3 +150,53 @@ class TorchRef(object):
         w_t = w_loc[:, step]                                               # [B,4800,o,k]
         out = torch.einsum('bnok,bkn->bno', w_t, xs) + b_loc[:, step]
         return out
+
+
+    # ---- training step checker (train.py:137-236): loss `stft/avg` (model.py:122-127, 156-159) and its gradient with
+    #      respect to every trainable variable by autograd over the restated graph -------------------------------------
+    def loss_and_grads(self, audio, video, flow, target, mask=None, keep=()):
+        """fp64 recommended (dtype=torch.float64).  Returns (loss float, {variable name: gradient ndarray},
+        prediction ndarray, {intermediate name: gradient ndarray for names in `keep`})."""
+        names = [k for k in self.P if '/moving_' not in k]
+        for k in names:
+            self.P[k] = self.P[k].detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            pred = self._forward(audio, video, flow)
+            kept = {}
+            for k in keep:
+                self.ends[k].retain_grad()
+                kept[k] = self.ends[k]
+            loss = stft_loss_torch(pred, torch.as_tensor(np.asarray(target)).to(self.dt),
+                                   None if mask is None else torch.as_tensor(np.asarray(mask)).to(self.dt))
+            loss.backward()
+        grads = {k: self.P[k].grad.detach().numpy().copy() for k in names}
+        igr = {k: v.grad.detach().numpy().copy() for k, v in kept.items()}
+        for k in names:
+            self.P[k] = self.P[k].detach()
+        return float(loss.detach()), grads, pred.detach().numpy(), igr
+
+
+def stft_for_loss_torch(x, window=2048, n_overlap=2):
+    """myutils.stft_for_loss (myutils.py:151-178) for window = 2^ceil(log2(0.025*48000)) = 2048, 2 overlaps:
+    x [B, N, C] -> complex [B, C, nW, window]."""
+    B, N, C = x.shape
+    n = torch.arange(window, dtype=torch.float64)
+    hann = (0.5 - 0.5 * torch.cos(2 * math.pi / window * n)).to(torch.float32).to(x.dtype)
+    wins = []
+    stride = window // n_overlap
+    for i in range(n_overlap):
+        nW = int(float(N - i * stride - 1) / window)
+        wins.append(x[:, i * stride:i * stride + window * nW, :].reshape(B, nW, window, C))
+    w = torch.cat(wins, 1).permute(0, 3, 1, 2) * hann
+    return torch.fft.fft(w, dim=-1)
+
+
+def stft_loss_torch(pred, gt, mask=None):
+    """losses['stft/mse'] = metrics['stft/avg'] (model.py:62-76, 122-127, 156-159)."""
+    B, _, C = pred.shape
+    if mask is None:
+        mask = torch.ones(B, C, dtype=pred.dtype)
+    nm = torch.clamp(mask.sum(0), min=1.0)
+    d = (stft_for_loss_torch(gt) - stft_for_loss_torch(pred)).abs() ** 2
+    ps = d.mean(3).mean(2)                                   # [B, C]
+    return ((ps * mask).sum(0) / nm * 100.).mean()

@@ -70,6 +70,18 @@ SIGNATURES = {
     'sagen_stft_loss_grad': (C.c_int, [_P, _P, _P, _I, _P, _P, _P]),
     'sagen_adam_update': (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _P]),
     'sagen_power_map_batched': (C.c_int, [_P, _I, _I64, _P, _I, _P, _P, _P]),
+    'sagen_train_workspace_bytes': (_SZ, [_P]),
+    'sagen_train_bind': (C.c_int, [_P, C.POINTER(SagenTensor), _I, C.POINTER(SagenTensor), _I, _P, _SZ, _P]),
+    'sagen_train_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'sagen_train_get_buffer': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_SZ)]),
+    'sagen_wgrad_scratch_bytes': (_SZ, [_I] * 4),
+    'sagen_wgrad': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    'sagen_conv2d_bwd_data_scratch_bytes': (_SZ, [_I] * 6),
+    'sagen_conv2d_bwd_data': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    'sagen_bn_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I64, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    'sagen_maxpool3x3s2_bwd': (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'sagen_mask_istft_mix_bwd_scratch_bytes': (_SZ, [_I, _I]),
+    'sagen_mask_istft_mix_bwd': (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _SZ, _P]),
 }
 
 _lib = None

@@ -20,6 +20,12 @@ int sagen_plan_set_impl(sagen_ctx* c, const char* layer, int tile, int splitk);
 int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen);
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride);
+size_t sagen_train_workspace_bytes_impl(sagen_ctx* c);
+int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving, void* tws,
+                          size_t tws_bytes, hipStream_t s);
+int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
+                          const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s);
+int sagen_train_get_buffer_impl(const sagen_ctx* c, const char* name, const float** data, size_t* n);
 
 namespace sagen {
 
@@ -367,6 +373,128 @@ int sagen_adam_update(float* params, const float* grads, float* m, float* v, int
     if ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) % 16)
         return fail(SAGEN_ERR_SHAPE, "sagen_adam_update: buckets must be 16-byte aligned");
     return adam_update_launch(params, grads, m, v, n, lr_t, beta1, beta2, epsilon, grad_scale, (hipStream_t)stream);
+}
+
+
+/* ---- training step (train_model.hip) ---- */
+size_t sagen_train_workspace_bytes(sagen_ctx* ctx) { return ctx ? sagen_train_workspace_bytes_impl(ctx) : 0; }
+int sagen_train_bind(sagen_ctx* ctx, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving,
+                     void* train_workspace, size_t train_workspace_bytes, void* stream) {
+    return guarded([&] { return sagen_train_bind_impl(ctx, grads, n_grads, moving, n_moving, train_workspace, train_workspace_bytes, (hipStream_t)stream); });
+}
+int sagen_train_step(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
+                     const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream) {
+    if (loss && ((uintptr_t)loss) % 8) return fail(SAGEN_ERR_SHAPE, "sagen_train_step: loss must be 8-byte aligned");
+    return guarded([&] { return sagen_train_step_impl(ctx, audio, video, flow, target_yzx, mask, pred_yzx, loss, update_moving_averages, (hipStream_t)stream); });
+}
+int sagen_train_get_buffer(const sagen_ctx* ctx, const char* name, const float** data, size_t* n_floats) {
+    if (!ctx || !name || !data || !n_floats) return fail(SAGEN_ERR_NULL, "sagen_train_get_buffer: null argument");
+    return guarded([&] { return sagen_train_get_buffer_impl(ctx, name, data, n_floats); });
+}
+
+/* ---- backward, op level ---- */
+size_t sagen_wgrad_scratch_bytes(int kh, int kw, int cg, int cd) { return align_up((size_t)64 * kh * kw * cg * cd * sizeof(float), 256); }
+
+int sagen_wgrad(const float* g, int batch, int hg, int wg, int cg, const float* d, int hd, int wd, int cd, int kh, int kw, int sh, int sw,
+                int h0, int w0, float* dw, void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        if (!g || !d || !dw) return fail(SAGEN_ERR_NULL, "sagen_wgrad: null argument");
+        if (cd % 4) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_wgrad: cd=%d must be a multiple of 4 at the op level (dense rows)", cd);
+        WgradDesc w;
+        w.g = g; w.d = d; w.out = dw; w.B = batch; w.Hd = hd; w.Wd = wd; w.HG = hg; w.WG = wg; w.ldg = cg; w.Cg = cg; w.ldd = cd; w.Cd = cd;
+        w.g_rstride = (unsigned)((long)wg * cg); w.g_bstride = (unsigned)((long)hg * wg * cg);
+        w.d_rstride = (unsigned)((long)wd * cd); w.d_bstride = (unsigned)((long)hd * wd * cd);
+        w.sh = sh; w.sw = sw; w.TH = kh; w.TW = kw; w.h0 = h0; w.w0 = w0;
+        w.ws = (float*)scratch;
+        w.splitk = scratch ? wgrad_pick_splitk(w, scratch_bytes / sizeof(float)) : 1;
+        return wgrad_launch(w, (hipStream_t)stream);
+    });
+}
+
+size_t sagen_conv2d_bwd_data_scratch_bytes(int kh, int kw, int cin, int cout, int sh, int sw) {
+    const long n = (sh == 1 && sw == 1) ? cin : (long)sh * sw * cin;
+    const long k = (sh == 1 && sw == 1) ? (long)kh * kw * cout : (long)cdiv(kh, sh) * cdiv(kw, sw) * cout;
+    return pk_bytes(n, k);
+}
+
+int sagen_conv2d_bwd_data(const float* dy, int batch, int hout, int wout, int cout, const float* w_hwio, int kh, int kw, int cin,
+                          int sh, int sw, int padding, int h, int w, float* dx, void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream;
+        if (!dy || !w_hwio || !dx || !scratch) return fail(SAGEN_ERR_NULL, "sagen_conv2d_bwd_data: null argument");
+        if (ilog2_exact(cout) < 2 || cin % 4) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_conv2d_bwd_data: cout must be a power of two >= 4, cin a multiple of 4");
+        if (scratch_bytes < sagen_conv2d_bwd_data_scratch_bytes(kh, kw, cin, cout, sh, sw)) return fail(SAGEN_ERR_WORKSPACE, "sagen_conv2d_bwd_data: scratch too small");
+        int pt = 0, pl = 0;
+        if (padding == 1) {
+            pt = std::max((cdiv(h, sh) - 1) * sh + kh - h, 0) / 2;
+            pl = std::max((cdiv(w, sw) - 1) * sw + kw - w, 0) / 2;
+            if (hout != cdiv(h, sh) || wout != cdiv(w, sw)) return fail(SAGEN_ERR_SHAPE, "sagen_conv2d_bwd_data: output size does not match SAME padding");
+        } else if (hout != (h - kh) / sh + 1 || wout != (w - kw) / sw + 1) {
+            return fail(SAGEN_ERR_SHAPE, "sagen_conv2d_bwd_data: output size does not match VALID padding");
+        }
+        float* wp = (float*)scratch;
+        IgemmDesc d;
+        d.x = dy; d.w = wp; d.y = dx; d.w_split = 1;
+        d.Hin = hout; d.Win = wout; d.Cin = cout; d.ldx = cout; d.x_bstride = (long)hout * wout * cout; d.log2Cin = ilog2_exact(cout);
+        d.Cout = cin; d.ldy = cin; d.y_rstride = (long)w * cin; d.y_bstride = (long)h * w * cin; d.Hlim = h; d.Wlim = w;
+        int rc;
+        if (sh == 1 && sw == 1) {
+            // dx = correlation of dy with the tap-reversed, channel-transposed filter, padded (kh-1-pt, kw-1-pl) before
+            d.M = batch * h * w; d.N = cin; d.K = kh * kw * cout; d.Kpad = (d.K + 15) / 16 * 16;
+            d.Hg = h; d.Wg = w; d.ntaps = kh * kw; d.TW = kw; d.tap_h0 = -(kh - 1 - pt); d.tap_w0 = -(kw - 1 - pl);
+            rc = pack_conv_flipT_launch(w_hwio, kh * kw, cin, cout, wp, d.Kpad, s);
+        } else {
+            if (pt || pl) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_conv2d_bwd_data: strided conv with padding before (%d,%d)", pt, pl);
+            const int nth = cdiv(kh, sh), ntw = cdiv(kw, sw);
+            d.Hg = cdiv(h, sh); d.Wg = cdiv(w, sw);
+            d.M = batch * d.Hg * d.Wg; d.N = sh * sw * cin; d.K = nth * ntw * cout; d.Kpad = (d.K + 15) / 16 * 16;
+            d.ntaps = nth * ntw; d.TW = ntw; d.tap_sh = -1; d.tap_sw = -1; d.dsh = sh; d.dsw = sw;
+            rc = pack_deconv_launch(w_hwio, kh, kw, cin, cout, sh, sw, wp, d.N, d.Kpad, s);
+        }
+        if (!rc) rc = pack_split_launch(wp, d.N, d.Kpad, s);
+        if (rc) return rc;
+        return igemm_launch(d, TILE_AUTO, s);
+    });
+}
+
+/* bn_stats = the fp64 (sum, sumsq) accumulators sagen_conv2d filled for the raw conv output y */
+int sagen_bn_bwd(const float* ga, const float* gb, const float* act, const float* y, const float* bn_stats, const float* gamma,
+                 const float* beta, float eps, int64_t n_pixels, int c, float* dy, float* dz, float* dgamma, float* dbeta,
+                 void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream;
+        if (!ga || !y || !bn_stats || !gamma || !beta || !dy || !scratch) return fail(SAGEN_ERR_NULL, "sagen_bn_bwd: null argument");
+        if (scratch_bytes < (size_t)2 * c * sizeof(double) || ((uintptr_t)scratch) % 8) return fail(SAGEN_ERR_WORKSPACE, "sagen_bn_bwd: scratch too small / unaligned");
+        BnRef bn;
+        bn.acc = (const double*)bn_stats; bn.gamma = gamma; bn.beta = beta; bn.inv_count = 1.0 / (double)n_pixels; bn.eps = eps;
+        SAGEN_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)2 * c * sizeof(double), s));
+        int rc = bn_bwd_reduce_launch(ga, gb, act, y, bn, n_pixels, c, (double*)scratch, s);
+        if (rc) return rc;
+        return bn_bwd_apply_launch(ga, gb, act, y, bn, (const double*)scratch, n_pixels, c, dy, dz, dgamma, dbeta, s);
+    });
+}
+
+int sagen_maxpool3x3s2_bwd(const float* y0, const float* bn_stats, const float* gamma, const float* beta, float eps, const float* pooled,
+                           const float* ga, const float* gb, float* dz, int batch, int h, int w, int c, void* stream) {
+    if (!y0 || !bn_stats || !gamma || !beta || !pooled || !ga || !dz) return fail(SAGEN_ERR_NULL, "sagen_maxpool3x3s2_bwd: null argument");
+    BnRef bn;
+    bn.acc = (const double*)bn_stats; bn.gamma = gamma; bn.beta = beta; bn.inv_count = 1.0 / ((double)batch * h * w); bn.eps = eps;
+    return maxpool_bwd_launch(y0, bn, pooled, ga, gb, dz, batch, h, w, c, (hipStream_t)stream);
+}
+
+size_t sagen_mask_istft_mix_bwd_scratch_bytes(int batch, int ntracks) { return mask_istft_bwd_scratch_floats(batch, ntracks) * sizeof(float); }
+
+int sagen_mask_istft_mix_bwd(const float* dmask, const float* spec, const float* coeffs, const float* dpred, int batch, int ntracks,
+                             float* d_dmask, float* d_coeffs, void* scratch, size_t scratch_bytes, void* stream) {
+    return guarded([&]() -> int {
+        hipStream_t s = (hipStream_t)stream;
+        if (!dmask || !spec || !coeffs || !dpred || !d_dmask || !d_coeffs || !scratch) return fail(SAGEN_ERR_NULL, "sagen_mask_istft_mix_bwd: null argument");
+        if (batch <= 0 || scratch_bytes < sagen_mask_istft_mix_bwd_scratch_bytes(batch, ntracks)) return fail(SAGEN_ERR_WORKSPACE, "sagen_mask_istft_mix_bwd: scratch too small");
+        // frames 0 and 24..27 never reach the cropped window: zero gradient
+        SAGEN_HIP_CHECK(hipMemsetAsync(d_dmask, 0, (size_t)batch * 28 * 1024 * ntracks * sizeof(float), s));
+        return mask_istft_mix_bwd_launch(dmask, 28L * 1024 * ntracks, 0, spec, coeffs, dpred, batch, ntracks, d_dmask, 28L * 1024 * ntracks, 0,
+                                         d_coeffs, 3 * (ntracks + 1), (float*)scratch, s);
+    });
 }
 
 }  // extern "C"

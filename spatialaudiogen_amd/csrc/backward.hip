@@ -1,0 +1,384 @@
+// HBM-bound kernels of the network's backward pass (what tf.gradients / opt.minimize build for train.py:147-149,
+// myutils.py:220-221): ReLU / bias gradients, training-mode batch-norm backward (core.py:6,209-210), max-pool backward
+// (resnet.py:135), fan-in sums of tf.tile / tf.concat (model.py:230-236, 291-297), the BN moving averages (UPDATE_OPS,
+// train.py:147-148) and the filter packs of the data-gradient contractions.  All are 16-byte-per-lane coalesced NHWC streams
+// (channels innermost, C % 4 == 0); per-channel sums are accumulated in registers, reduced through LDS and added to fp64
+// accumulators with one atomic per channel and workgroup (same scheme as the forward BN statistics, igemm_common.h).
+#include "kernels.h"
+#include <algorithm>
+
+namespace sagen {
+
+// grid whose stride (grid*256 threads) is a multiple of C4, so a thread always sees the same 4 channels
+static int aligned_grid(long n4, int C4) {
+    long g = std::min<long>(cdiv(n4, 256), 256L * 16);
+    if ((g * 256) % C4) {
+        long a = 256, b = C4;
+        while (b) { const long t = a % b; a = b; b = t; }
+        const long unit = C4 / a;                    // smallest g with (g*256) % C4 == 0
+        g = std::max<long>(unit, g / unit * unit);
+    }
+    return (int)g;
+}
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// per-channel block reduction of `nv` float4 partials per thread -> fp64 atomics.  Requires every thread of the block to call.
+// fast path: 256 % C4 == 0 (thread t owns channels 4*(t % C4)); otherwise per-thread atomics (tiny tensors only).
+template <int NV>
+__device__ __forceinline__ void channel_reduce(const float4 (&v)[NV], int C4, int c4, double* acc, int C) {
+    __shared__ float4 red[NV][256];
+    const int tid = threadIdx.x;
+    if (256 % C4 == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[k][tid] = v[k];
+        __syncthreads();
+        if (tid < C4) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                float4 s = red[k][tid];
+                for (int t = tid + C4; t < 256; t += C4) s = add4(s, red[k][t]);
+                double* a = acc + (long)k * C + 4 * tid;
+                atomicAdd(a + 0, (double)s.x); atomicAdd(a + 1, (double)s.y); atomicAdd(a + 2, (double)s.z); atomicAdd(a + 3, (double)s.w);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double* a = acc + (long)k * C + 4 * c4;
+            if (4 * c4 + 0 < C) atomicAdd(a + 0, (double)v[k].x);
+            if (4 * c4 + 1 < C) atomicAdd(a + 1, (double)v[k].y);
+            if (4 * c4 + 2 < C) atomicAdd(a + 2, (double)v[k].z);
+            if (4 * c4 + 3 < C) atomicAdd(a + 3, (double)v[k].w);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// dy = (ga + gb) * (act > 0)  [+ per-channel sum of dy = the bias gradient of tf.nn.bias_add, core.py:28]
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ ga, int lda, const float* __restrict__ gb, int ldb,
+                                                       const float* __restrict__ act, int ldact, float* __restrict__ dy, int lddy,
+                                                       long n4, int C4, double* __restrict__ colsum, int C) {
+    const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
+    float4 sum[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long row = i / C4;
+        float4 v = *reinterpret_cast<const float4*>(ga + row * lda + 4 * c4);
+        if (gb) v = add4(v, *reinterpret_cast<const float4*>(gb + row * ldb + 4 * c4));
+        if (act) {
+            const float4 a = *reinterpret_cast<const float4*>(act + row * ldact + 4 * c4);
+            v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+        }
+        if (dy) *reinterpret_cast<float4*>(dy + row * lddy + 4 * c4) = v;
+        sum[0] = add4(sum[0], v);
+    }
+    if (colsum) channel_reduce<1>(sum, C4, c4, colsum, C);
+}
+
+int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
+                    int C, double* colsum, hipStream_t s) {
+    if (!ga || (!dy && !colsum)) return fail(SAGEN_ERR_NULL, "relu_bwd: null argument");
+    const int Cp = (C + 3) / 4 * 4;
+    if (lda % 4 || (gb && ldb % 4) || (act && ldact % 4) || (dy && lddy % 4) || lda < Cp)
+        return fail(SAGEN_ERR_UNSUPPORTED, "relu_bwd: row strides must be multiples of 4 floats covering the padded row (C=%d)", C);
+    if (((uintptr_t)ga | (uintptr_t)gb | (uintptr_t)act | (uintptr_t)dy) % 16) return fail(SAGEN_ERR_UNSUPPORTED, "relu_bwd: operands must be 16-byte aligned");
+    const int C4 = Cp / 4;
+    const long n4 = R * C4;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(aligned_grid(n4, C4)), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, n4, C4, colsum, C);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// training-mode batch-norm backward.  Forward: xhat = (y - mean) * invstd, z = gamma * xhat + beta (contrib batch_norm,
+// is_training=True, biased variance, eps 1e-3).  With dz the gradient at z (after the ReLU mask of the consumer):
+//   dbeta = sum dz,  dgamma = sum dz * xhat,  dy = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N)
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void bn_moments4(const BnRef& bn, int C, int c4, float4& mean, float4& invstd) {
+    float m[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * c4 + k;
+        const double mu = bn.acc[c] * bn.inv_count;
+        double var = bn.acc[C + c] * bn.inv_count - mu * mu;
+        var = var < 0.0 ? 0.0 : var;
+        m[k] = (float)mu;
+        r[k] = (float)(1.0 / sqrt(var + (double)bn.eps));
+    }
+    mean = make_float4(m[0], m[1], m[2], m[3]);
+    invstd = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+__device__ __forceinline__ float4 masked_sum(const float4* ga, const float4* gb, const float4* act, long i) {
+    float4 v = ga[i];
+    if (gb) v = add4(v, gb[i]);
+    if (act) {
+        const float4 a = act[i];
+        v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb,
+                                                            const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
+                                                            long n4, int C4, double* __restrict__ acc) {
+    const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
+    float4 mean, invstd;
+    bn_moments4(bn, 4 * C4, c4, mean, invstd);
+    float4 sum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 dz = masked_sum(ga, gb, act, i);
+        const float4 v = y[i];
+        sum[0] = add4(sum[0], dz);
+        sum[1].x = fmaf(dz.x, (v.x - mean.x) * invstd.x, sum[1].x); sum[1].y = fmaf(dz.y, (v.y - mean.y) * invstd.y, sum[1].y);
+        sum[1].z = fmaf(dz.z, (v.z - mean.z) * invstd.z, sum[1].z); sum[1].w = fmaf(dz.w, (v.w - mean.w) * invstd.w, sum[1].w);
+    }
+    channel_reduce<2>(sum, C4, c4, acc, 4 * C4);
+}
+
+int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
+                         double* acc, hipStream_t s) {
+    if (!ga || !y || !bn.acc || !acc) return fail(SAGEN_ERR_NULL, "bn_bwd_reduce: null argument");
+    if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_reduce: C=%d must be 4 * a divisor of 256", C);
+    const long n4 = n_pixels * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(aligned_grid(n4, C / 4)), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
+                       (const float4*)act, (const float4*)y, bn, n4, C / 4, acc);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb,
+                                                           const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
+                                                           const double* __restrict__ acc, long n4, int C4, float4* __restrict__ dy,
+                                                           float4* __restrict__ dz_out, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    const int C = 4 * C4;
+    const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
+    float4 mean, invstd;
+    bn_moments4(bn, C, c4, mean, invstd);
+    float k0[4], k1[4], gs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * c4 + k;
+        k0[k] = (float)(acc[c] * bn.inv_count);
+        k1[k] = (float)(acc[C + c] * bn.inv_count);
+        gs[k] = bn.gamma[c] * (&invstd.x)[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < C4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * c4 + k;
+            if (dbeta) dbeta[c] = (float)acc[c];
+            if (dgamma) dgamma[c] = (float)acc[C + c];
+        }
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 dz = masked_sum(ga, gb, act, i);
+        const float4 v = y[i];
+        float4 o;
+        o.x = gs[0] * (dz.x - k0[0] - (v.x - mean.x) * invstd.x * k1[0]);
+        o.y = gs[1] * (dz.y - k0[1] - (v.y - mean.y) * invstd.y * k1[1]);
+        o.z = gs[2] * (dz.z - k0[2] - (v.z - mean.z) * invstd.z * k1[2]);
+        o.w = gs[3] * (dz.w - k0[3] - (v.w - mean.w) * invstd.w * k1[3]);
+        dy[i] = o;
+        if (dz_out) dz_out[i] = dz;
+    }
+}
+
+int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
+                        long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s) {
+    if (!ga || !y || !bn.acc || !acc || !dy) return fail(SAGEN_ERR_NULL, "bn_bwd_apply: null argument");
+    if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_apply: C=%d must be 4 * a divisor of 256", C);
+    const long n4 = n_pixels * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(aligned_grid(n4, C / 4)), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
+                       (const float4*)act, (const float4*)y, bn, acc, n4, C / 4, (float4*)dy, (float4*)dz_out, dgamma, dbeta);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// max-pool 3x3/2 SAME backward through relu(bn(y0)).  tf.nn.max_pool's gradient routes each window's gradient to its maximum;
+// here as a gather: input pixel (i, j) collects from the (at most 2x2) windows that contain it and whose pooled value equals
+// its own activation (recomputed with the forward's exact fmaf / fmaxf sequence, so the comparison is exact).  A window whose
+// maximum is 0 (all inputs <= 0) routes nowhere that survives the ReLU mask, in TF as here.  Exact float ties between two
+// positive activations of one window would be credited twice (TF: first in scan order); not observed, measure-zero.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ y0, const BnRef bn, const float4* __restrict__ pooled,
+                                                          const float4* __restrict__ ga, const float4* __restrict__ gb,
+                                                          float4* __restrict__ dz, int B, int H, int W, int C4, int Ho, int Wo, int pt, int pl) {
+    const int C = 4 * C4;
+    const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
+    float4 sc, sh;
+    {
+        float s4[4], h4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {       // identical to bn_coeffs4 of the forward pool (elementwise.hip)
+            const int c = 4 * c4 + k;
+            const double mean = bn.acc[c] * bn.inv_count;
+            double var = bn.acc[C + c] * bn.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double a = (double)bn.gamma[c] / sqrt(var + (double)bn.eps);
+            s4[k] = (float)a;
+            h4[k] = (float)((double)bn.beta[c] - mean * a);
+        }
+        sc = make_float4(s4[0], s4[1], s4[2], s4[3]);
+        sh = make_float4(h4[0], h4[1], h4[2], h4[3]);
+    }
+    const long total = (long)B * H * W * C4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long p = idx / C4;
+        const int j = (int)(p % W); p /= W;
+        const int i = (int)(p % H);
+        const int b = (int)(p / H);
+        float4 a = y0[idx];
+        a.x = fmaxf(fmaf(a.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(a.y, sc.y, sh.y), 0.f);
+        a.z = fmaxf(fmaf(a.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(a.w, sc.w, sh.w), 0.f);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int oi0 = max((i + pt - 1) >> 1, 0), oi1 = min((i + pt) >> 1, Ho - 1);      // windows rows 2*oi - pt .. 2*oi - pt + 2
+        const int oj0 = max((j + pl - 1) >> 1, 0), oj1 = min((j + pl) >> 1, Wo - 1);
+        for (int oi = oi0; oi <= oi1; ++oi)
+            for (int oj = oj0; oj <= oj1; ++oj) {
+                const long q = (((long)b * Ho + oi) * Wo + oj) * C4 + c4;
+                const float4 pv = pooled[q];
+                float4 gv = ga[q];
+                if (gb) gv = add4(gv, gb[q]);
+                g.x += (a.x == pv.x) ? gv.x : 0.f; g.y += (a.y == pv.y) ? gv.y : 0.f;
+                g.z += (a.z == pv.z) ? gv.z : 0.f; g.w += (a.w == pv.w) ? gv.w : 0.f;
+            }
+        g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+        dz[idx] = g;
+    }
+}
+
+int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dz, int B,
+                       int H, int W, int C, hipStream_t s) {
+    if (!y0 || !bn.acc || !pooled || !ga || !dz) return fail(SAGEN_ERR_NULL, "maxpool_bwd: null argument");
+    if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bwd: C=%d must be a multiple of 4", C);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
+    const long total = (long)B * H * W * (C / 4);
+    // (i + pt - 1) >> 1 must be ceil((i + pt - 2) / 2): true for i + pt >= 1; i + pt == 0 gives -1 >> 1 = -1 -> clamped to 0
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(aligned_grid(total, C / 4)), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled,
+                       (const float4*)ga, (const float4*)gb, (float4*)dz, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// out[m][c] = sum_{r<rep} (ina[(m*rep + r)][c] + inb[...][c])
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ ina, int lda, const float* __restrict__ inb, int ldb,
+                                                       int rep, long n4, int C4, float* __restrict__ out, int ldo) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long m = i / C4;
+        const int c4 = (int)(i - m * C4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < rep; ++r) {
+            v = add4(v, *reinterpret_cast<const float4*>(ina + (m * rep + r) * lda + 4 * c4));
+            if (inb) v = add4(v, *reinterpret_cast<const float4*>(inb + (m * rep + r) * ldb + 4 * c4));
+        }
+        *reinterpret_cast<float4*>(out + m * ldo + 4 * c4) = v;
+    }
+}
+
+int sum_rows_launch(const float* ina, int lda, const float* inb, int ldb, int rep, long M, int C, float* out, int ldo, hipStream_t s) {
+    if (!ina || !out) return fail(SAGEN_ERR_NULL, "sum_rows: null argument");
+    if (C % 4 || lda % 4 || (inb && ldb % 4) || ldo % 4 || rep < 1) return fail(SAGEN_ERR_UNSUPPORTED, "sum_rows: C / strides must be multiples of 4");
+    if (((uintptr_t)ina | (uintptr_t)inb | (uintptr_t)out) % 16) return fail(SAGEN_ERR_UNSUPPORTED, "sum_rows: operands must be 16-byte aligned");
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((int)std::min<long>(cdiv(n4, 256), 4096L)), dim3(256), 0, s, ina, lda, inb, ldb, rep, n4, C / 4, out, ldo);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+__global__ __launch_bounds__(256) void acc_to_f32_kernel(const double* __restrict__ acc, float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)acc[i];
+}
+
+int acc_to_f32_launch(const double* acc, float* dst, int n, hipStream_t s) {
+    if (!acc || !dst) return fail(SAGEN_ERR_NULL, "acc_to_f32: null argument");
+    hipLaunchKernelGGL(acc_to_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, acc, dst, n);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// tf.contrib.layers.batch_norm(decay=0.99, is_training=True) update ops (core.py:210; run through UPDATE_OPS, train.py:147-148):
+// moving <- decay * moving + (1 - decay) * batch statistic.  TF 1.4's contrib layer takes the fused path for rank-4 inputs
+// (fused=None), whose running variance is the UNBIASED batch variance (nn.fused_batch_norm); the normalisation itself uses the
+// biased one.  The moving averages are never read by the path (is_training is always True, model.py:197): bookkeeping only.
+__global__ __launch_bounds__(256) void bn_moving_update_kernel(const BnRef bn, float* __restrict__ mm, float* __restrict__ mv, int C, float decay) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = bn.acc[c] * bn.inv_count;
+    double var = bn.acc[C + c] * bn.inv_count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double n = 1.0 / bn.inv_count;
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    mm[c] = decay * mm[c] + (1.f - decay) * (float)mean;
+    mv[c] = decay * mv[c] + (1.f - decay) * (float)unbiased;
+}
+
+int bn_moving_update_launch(const BnRef& bn, float* moving_mean, float* moving_var, int C, float decay, hipStream_t s) {
+    if (!bn.acc || !moving_mean || !moving_var) return fail(SAGEN_ERR_NULL, "bn_moving_update: null argument");
+    hipLaunchKernelGGL(bn_moving_update_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, bn, moving_mean, moving_var, C, decay);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// filter packs of the data-gradient contractions
+// -----------------------------------------------------------------------------------------
+// dx of a stride-1 conv = conv of dy with the tap-reversed, channel-transposed filter
+__global__ __launch_bounds__(256) void pack_conv_flipT_kernel(const float* __restrict__ w, int ntaps, int cin, int cout,
+                                                              float* __restrict__ wp, int Kpad) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)cin * Kpad) return;
+    const int n = (int)(idx / Kpad), k = (int)(idx - (long)n * Kpad);
+    float v = 0.f;
+    if (k < ntaps * cout) {
+        const int tap = k / cout, co = k - tap * cout;
+        v = w[((long)(ntaps - 1 - tap) * cin + n) * cout + co];
+    }
+    wp[idx] = v;
+}
+
+int pack_conv_flipT_launch(const float* w_hwio, int ntaps, int cin, int cout, float* wp, int Kpad, hipStream_t s) {
+    const long total = (long)cin * Kpad;
+    hipLaunchKernelGGL(pack_conv_flipT_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w_hwio, ntaps, cin, cout, wp, Kpad);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wp, int Kpad) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)rows * Kpad) return;
+    const int n = (int)(idx / Kpad), k = (int)(idx - (long)n * Kpad);
+    wp[idx] = k < cols ? w[(long)n * cols + k] : 0.f;
+}
+
+int pack_rows_launch(const float* w, int rows, int cols, float* wp, int Kpad, hipStream_t s) {
+    const long total = (long)rows * Kpad;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, rows, cols, wp, Kpad);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_unpack_kernel(const float* __restrict__ tmp, float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // over [7][7][3][64]
+    if (idx >= 7 * 7 * 3 * 64) return;
+    const int o = idx & 63;
+    int r = idx >> 6;
+    const int c = r % 3; r /= 3;
+    const int tw = r % 7, th = r / 7;
+    dw[idx] = tmp[((th * 32) + tw * 4 + c) * 64 + o];
+}
+
+int stem_wgrad_unpack_launch(const float* tmp, float* dw, hipStream_t s) {
+    hipLaunchKernelGGL(stem_wgrad_unpack_kernel, dim3(cdiv(7 * 7 * 3 * 64, 256)), dim3(256), 0, s, tmp, dw);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+}  // namespace sagen

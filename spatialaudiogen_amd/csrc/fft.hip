@@ -300,4 +300,189 @@ int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, 
     return SAGEN_OK;
 }
 
+// -----------------------------------------------------------------------------------------
+// Adjoint of mask -> iSTFT -> overlap-add -> mix (backward of model.py:326-347, myutils.py:181-211, model.py:421-434).
+// Forward per (window b, frame f):  out[n,o] = 1/4 sum_f y_f^{o,step(n)}[p] + bias,  y^{o,s} = real(ifft((sum_j w[s,o,j] sigma(m_j)) X)),
+// n = 256 f + p - 1216.  With g^{o,s}[p] = 1/4 dL/dout[n,o] [step(n) = s] and G = FFT(g):
+//     Q^{o,s}[k]      = 1/N Re(X[k] conj(G^{o,s}[k]))                       (the gradient at the summed mask of (o, s))
+//     dL/dm_j[k]      = sigma'(m_j[k]) sum_{o,s} w[s,o,j] Q^{o,s}[k]
+//     dL/dw[s,o,j]    = sum_{f,k} sigma(m_j[k]) Q^{o,s}[k]                   (per-frame partials, summed by mask_bwd_finalize)
+//     dL/dbias[s,o]   = sum_{n in step s} dL/dout[n,o]
+// so the adjoint needs <= 3 packed 1024-point FFTs per frame (as the forward) instead of 2 x 32, and one pass over the mask.
+// -----------------------------------------------------------------------------------------
+template <int NTR>
+__global__ __launch_bounds__(256) void mask_istft_bwd_kernel(const float* __restrict__ dmask, long dmask_bstride, int dmask_f0,
+                                                             const float2* __restrict__ spec, const float* __restrict__ coeffs,
+                                                             const float* __restrict__ dpred, float* __restrict__ d_dmask,
+                                                             long dd_bstride, int dd_f0, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float2 fftbuf[2048];
+    float2* const bufA = fftbuf;
+    float2* const bufB = fftbuf + 1024;
+    __shared__ float Q[6][1024];
+    __shared__ float2 X[513];
+    __shared__ float wl[6][NTR];
+    __shared__ float red[4][6][NTR];
+    const int tid = threadIdx.x;
+    const int fi = blockIdx.x, f = MASK_F_LO + fi, b = blockIdx.y;
+    const int n_lo = max(256 * f - OUT_SHIFT, 0), n_hi = min(256 * f - OUT_SHIFT + 1023, 4799);
+    const int s_lo = n_lo / 1600, s_hi = n_hi / 1600;
+    const bool two = s_hi != s_lo;
+
+    for (int i = tid; i < 6 * NTR; i += 256) {
+        const int j = i % NTR, o = (i / NTR) % 3, si = i / (3 * NTR);
+        const int st = si ? s_hi : s_lo;
+        wl[si * 3 + o][j] = coeffs[(((long)b * 3 + st) * 3 + o) * (NTR + 1) + j];
+    }
+    for (int k = tid; k < 513; k += 256) X[k] = spec[((long)b * 28 + f) * 513 + k];
+    for (int i = tid; i < 3 * 1024; i += 256) Q[3 + i / 1024][i % 1024] = 0.f;
+    __syncthreads();
+
+    const int npack = two ? 3 : 2;
+    for (int pk = 0; pk < npack; ++pk) {
+        int ca, cb;                                   // same packing as the forward
+        if (pk == 0) { ca = 0; cb = 1; }
+        else if (pk == 1) { ca = 2; cb = two ? 5 : -1; }
+        else { ca = 3; cb = 4; }
+        const int oa = ca % 3, sa = (ca / 3) ? s_hi : s_lo;
+        const int ob = cb >= 0 ? cb % 3 : 0, sb = (cb >= 0 && cb / 3) ? s_hi : s_lo;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = tid + 256 * t;
+            const int n = 256 * f + p - OUT_SHIFT;
+            float va = 0.f, vb = 0.f;
+            if (n >= 0 && n < 4800) {
+                const int st = n / 1600;
+                const float* g = dpred + ((long)b * 4800 + n) * 3;
+                if (st == sa) va = 0.25f * g[oa];
+                if (cb >= 0 && st == sb) vb = 0.25f * g[ob];
+            }
+            bufA[p] = make_float2(va, vb);
+        }
+        __syncthreads();
+        const float2* Z = fft1024<false>(bufA, bufB, tid);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = tid + 256 * t;
+            const int km = (1024 - k) & 1023;
+            const float2 zk = Z[k];
+            float2 zn = Z[km];
+            zn.y = -zn.y;
+            const float2 Ga = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+            const float ddx = zk.x - zn.x, ddy = zk.y - zn.y;
+            const float2 Gb = make_float2(0.5f * ddy, -0.5f * ddx);
+            float2 xk = (k <= 512) ? X[k] : X[km];
+            if (k > 512) xk.y = -xk.y;
+            Q[ca][k] = (xk.x * Ga.x + xk.y * Ga.y) * (1.f / 1024.f);
+            if (cb >= 0) Q[cb][k] = (xk.x * Gb.x + xk.y * Gb.y) * (1.f / 1024.f);
+        }
+        __syncthreads();
+    }
+
+    // one pass over the mask rows of this frame: thread = (16-byte chunk of 4 tracks, row group)
+    constexpr int NC = NTR / 4, RG = 256 / NC;
+    const int ch = tid % NC, rg = tid / NC;
+    float w[6][4], acc[6][4];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w[c][u] = wl[c][4 * ch + u]; acc[c][u] = 0.f; }
+    const float4* src = reinterpret_cast<const float4*>(dmask + (long)b * dmask_bstride + (long)(f - dmask_f0) * 1024 * NTR);
+    float4* dst = reinterpret_cast<float4*>(d_dmask + (long)b * dd_bstride + (long)(f - dd_f0) * 1024 * NTR);
+#pragma unroll 4
+    for (int k = rg; k < 1024; k += RG) {
+        const float4 v = src[k * NC + ch];
+        float q[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) q[c] = Q[c][k];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sg = 1.f / (1.f + expf(-vv[u]));
+            float dm = 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                dm = fmaf(w[c][u], q[c], dm);
+                acc[c][u] = fmaf(sg, q[c], acc[c][u]);
+            }
+            o[u] = dm * sg * (1.f - sg);
+        }
+        dst[k * NC + ch] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    // dL/dw partials of this frame: reduce over the row groups (lanes sharing a chunk, then the four waves)
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float a = acc[c][u];
+#pragma unroll
+            for (int m = NC; m < 64; m <<= 1) a += __shfl_xor(a, m);
+            acc[c][u] = a;
+        }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < NC) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) red[wave][c][4 * lane + u] = acc[c][u];
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * NTR; i += 256) {
+        const int c = i / NTR, j = i % NTR;
+        partial[(((long)b * MASK_NF + fi) * 6 + c) * NTR + j] = (red[0][c][j] + red[1][c][j]) + (red[2][c][j] + red[3][c][j]);
+    }
+}
+
+// grid (B, 9): (step s, output channel o) of one window: sums the per-frame partials in frame order (deterministic) and the
+// bias gradient; dcoeffs [B*3][ldc], element (b*3 + s)*ldc + o*(ntr+1) + j
+__global__ __launch_bounds__(256) void mask_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ dpred,
+                                                                int ntr, float* __restrict__ dcoeffs, int ldc) {
+    const int b = blockIdx.x, s = blockIdx.y / 3, o = blockIdx.y % 3;
+    const int tid = threadIdx.x;
+    float a = 0.f;
+    for (int n = 1600 * s + tid; n < 1600 * (s + 1); n += 256) a += dpred[((long)b * 4800 + n) * 3 + o];
+    __shared__ float red[4];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float* out = dcoeffs + ((long)b * 3 + s) * ldc + o * (ntr + 1);
+    if (tid == 0) out[ntr] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid < ntr) {
+        float v = 0.f;
+        for (int fi = 0; fi < MASK_NF; ++fi) {
+            const int f = MASK_F_LO + fi;
+            const int n_lo = max(256 * f - OUT_SHIFT, 0), n_hi = min(256 * f - OUT_SHIFT + 1023, 4799);
+            const int s_lo = n_lo / 1600, s_hi = n_hi / 1600;
+            const float* pf = partial + (((long)b * MASK_NF + fi) * 6) * ntr;
+            if (s_lo == s) v += pf[o * ntr + tid];
+            if (s_hi != s_lo && s_hi == s) v += pf[(3 + o) * ntr + tid];
+        }
+        out[tid] = v;
+    }
+}
+
+size_t mask_istft_bwd_scratch_floats(int B, int ntracks) { return (size_t)B * MASK_NF * 6 * ntracks; }
+
+int mask_istft_mix_bwd_launch(const float* dmask, long dmask_bstride, int dmask_f0, const float* spec, const float* coeffs,
+                              const float* dpred, int B, int ntracks, float* d_dmask, long dd_bstride, int dd_f0, float* dcoeffs,
+                              int ldc, float* scratch, hipStream_t s) {
+    int rc = fft_tables_ensure(s);
+    if (rc) return rc;
+    if (dmask_f0 > MASK_F_LO || dd_f0 > MASK_F_LO) return fail(SAGEN_ERR_SHAPE, "mask_istft_bwd: mask buffers must start at frame <= %d", MASK_F_LO);
+    if (ldc < 3 * (ntracks + 1)) return fail(SAGEN_ERR_SHAPE, "mask_istft_bwd: ldc=%d too small", ldc);
+    dim3 grid(MASK_NF, B);
+#define SAGEN_MB(N) hipLaunchKernelGGL(mask_istft_bwd_kernel<N>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, \
+                                       coeffs, dpred, d_dmask, dd_bstride, dd_f0, scratch)
+    if (ntracks == 32) SAGEN_MB(32);
+    else if (ntracks == 64) SAGEN_MB(64);
+    else if (ntracks == 16) SAGEN_MB(16);
+    else return fail(SAGEN_ERR_UNSUPPORTED, "mask_istft_bwd: num_sep_tracks=%d (supported: 16, 32, 64)", ntracks);
+#undef SAGEN_MB
+    SAGEN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mask_bwd_finalize_kernel, dim3(B, 9), dim3(256), 0, s, scratch, dpred, ntracks, dcoeffs, ldc);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 }  // namespace sagen

@@ -188,4 +188,62 @@ int stft_loss_grad_launch(const float* pred, const float* gt, const float* mask,
 int adam_update_launch(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1, float beta2, float eps,
                        float gscale, hipStream_t s);
 
+// -----------------------------------------------------------------------------------------
+// weight gradients (wgrad.hip): dW[t][g][d] = sum_{b,i,j} G[b, i*sh + th + h0, j*sw + tw + w0, g] * D[b, i, j, d]
+// (conv: G = input, D = dL/dy; conv2d_transpose: G = dL/dy, D = input; FC: one tap on a 1x1 grid).  Strides in floats.
+// -----------------------------------------------------------------------------------------
+struct WgradDesc {
+    const float* g = nullptr;         // gathered operand [B][HG][WG][.. Cg ..], pixel stride ldg, row stride g_rstride
+    const float* d = nullptr;         // dense-grid operand [B][Hd][Wd][.. Cd ..], pixel stride ldd, row stride d_rstride
+    float* out = nullptr;             // [TH*TW][Cg][Cd]
+    float* ws = nullptr;              // [splitk][TH*TW][Cg][Cd] partials when splitk > 1
+    int B = 1, Hd = 1, Wd = 1;
+    int HG = 1, WG = 1, ldg = 0, Cg = 0;
+    int ldd = 0, Cd = 0;
+    unsigned g_bstride = 0, g_rstride = 0, d_bstride = 0, d_rstride = 0;
+    int sh = 1, sw = 1, TH = 1, TW = 1, h0 = 0, w0 = 0;
+    int splitk = 1;
+    // filled by wgrad_launch
+    int P = 0;
+    unsigned g_bytes = 0, d_bytes = 0, magic_w = 0, magic_h = 0;
+};
+int wgrad_launch(const WgradDesc& d, hipStream_t s);
+int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats);
+
+// -----------------------------------------------------------------------------------------
+// backward elementwise / reductions (backward.hip).  fp64 accumulators are zeroed by the caller.
+// -----------------------------------------------------------------------------------------
+// dy[r][c] = (ga[r][c] + gb[r][c]) * (act[r][c] > 0); gb / act / dy nullable; colsum (fp64 [C], atomics) nullable: sum_r dy
+int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
+                    int C, double* colsum, hipStream_t s);
+// training-mode batch-norm backward (core.py:6,209-210 under tf.gradients).  dz = (ga + gb) * (act > 0) (act nullable);
+// xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat)
+int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
+                         double* acc, hipStream_t s);
+// dy = gamma*invstd*(dz - acc0/N - xhat*acc1/N) (+ dz to `dz_out`, nullable); writes dgamma = acc1, dbeta = acc0 (nullable)
+int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
+                        long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s);
+// backward of maxpool3x3s2(relu(bn(y0))) (resnet.py:134-135): dz0[b,i,j,c] = (a > 0) * sum over the windows containing (i,j) of
+// [a == pooled] * (ga + gb), a = relu(bn(y0)); pooled = the forward's pool output [B,Ho,Wo,C]
+int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dz,
+                       int B, int H, int W, int C, hipStream_t s);
+// out[m][c] = sum_{r < rep} (ina[(m*rep + r)*lda + c] + inb[(m*rep + r)*ldb + c]); inb nullable (backward of tf.tile / concat fan-in)
+int sum_rows_launch(const float* ina, int lda, const float* inb, int ldb, int rep, long M, int C, float* out, int ldo, hipStream_t s);
+int acc_to_f32_launch(const double* acc, float* dst, int n, hipStream_t s);
+// contrib batch_norm moving averages (UPDATE_OPS, train.py:147-148): m <- decay*m + (1-decay)*batch stat
+int bn_moving_update_launch(const BnRef& bn, float* moving_mean, float* moving_var, int C, float decay, hipStream_t s);
+// filter packs for the data-gradient contractions
+// 3x3 (any kh x kw) stride-1 conv: Wp[n = ci][(tap', co)] = W_hwio[ntaps-1-tap'][ci][co]
+int pack_conv_flipT_launch(const float* w_hwio, int ntaps, int cin, int cout, float* wp, int Kpad, hipStream_t s);
+// row-major matrix [rows][cols] (ld = cols) -> [rows][Kpad] zero padded (FC: dx = dy . W^T)
+int pack_rows_launch(const float* w, int rows, int cols, float* wp, int Kpad, hipStream_t s);
+// stem: [7][8*4][64] (tap row, (tw, c4), o) -> HWIO [7,7,3,64]
+int stem_wgrad_unpack_launch(const float* tmp, float* dw, hipStream_t s);
+
+// adjoint of mask_istft_mix (fft.hip): dpred [B,4800,3] -> dmask (same geometry as dmask, frames MASK_F_LO..), dcoeffs [B*3][ldc]
+size_t mask_istft_bwd_scratch_floats(int B, int ntracks);
+int mask_istft_mix_bwd_launch(const float* dmask, long dmask_bstride, int dmask_f0, const float* spec, const float* coeffs,
+                              const float* dpred, int B, int ntracks, float* d_dmask, long dd_bstride, int dd_f0, float* dcoeffs,
+                              int ldc, float* scratch, hipStream_t s);
+
 }  // namespace sagen

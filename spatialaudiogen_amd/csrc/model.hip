@@ -1,164 +1,7 @@
 // sagen_ctx: the native runtime of the inference path — variable inventory, workspace carving,
 // filter repacking and the launch sequence that replaces one sess.run of
 // SptAudioGen.inference_ops (reference model.py:356-434; called at deploy.py:141, eval.py:145).
-#include "kernels.h"
-#include <algorithm>
-#include <cstdlib>
-#include <map>
-#include <string>
-#include <vector>
-
-namespace sagen {
-
-struct VarSpec {
-    std::string name;
-    int ndim;
-    int64_t shape[4];
-    long numel() const {
-        long n = 1;
-        for (int i = 0; i < ndim; ++i) n *= shape[i];
-        return n;
-    }
-};
-
-struct Buf {            // region of the workspace, in floats
-    size_t off = 0, n = 0;
-};
-
-struct Named {          // intermediate exposed to parity tests
-    Buf buf;
-    size_t extra_off = 0;          // float offset inside buf (channel offset of a concat buffer)
-    int ndim = 0;
-    int64_t shape[4] = {0, 0, 0, 0};
-    int64_t pixel_stride = 0;
-};
-
-static const int AENC_F[5] = {32, 64, 128, 256, 512};
-static const int AENC_K[5][2] = {{7, 16}, {3, 7}, {3, 5}, {3, 5}, {3, 5}};
-static const int AENC_S[5][2] = {{4, 8}, {2, 4}, {2, 2}, {1, 1}, {1, 1}};
-
-}  // namespace sagen
-
-using namespace sagen;
-
-struct ProfRec {
-    std::string kernel, layer;
-    double flops = 0.0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-};
-
-struct Choice {          // how one contraction is launched
-    int tile = -1;       // IgemmTile, -1 = heuristic
-    int splitk = 0;      // 0 = heuristic
-    float us = 0.f;      // measured time of the choice (autotune)
-};
-
-struct sagen_ctx {
-    sagen_config cfg;
-    // per-layer launch plan (filled by sagen_autotune; empty = heuristics)
-    std::map<std::string, Choice> plan;
-    std::map<std::string, bool> materialize;     // conv_2 layers: apply the producer's BN+ReLU in a separate pass?
-    bool tuning = false;
-    bool fp32_only = false;                      // SAGEN_FP32_ONLY=1: never use the bf16x3 tiles
-    bool use_p3 = true;                          // 3x3 stride-1 trunk convs read pre-split bf16 planes (conv3p.hip); SAGEN_NO_P3=1 disables
-    int p3_from_stage = 3;                       // ... from this ResNet stage on (2..5; SAGEN_P3_FROM_STAGE): see resnet()
-    hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
-    // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stft = nullptr;
-    // optional per-launch HIP-event profiler (sagen_profile_enable)
-    bool profiling = false;
-    std::vector<ProfRec> prof;
-    std::vector<hipEvent_t> event_pool;
-    size_t events_used = 0;
-    int B = 0;
-    int snd_size = 52799, snd_contx = 48000, snd_dur = 4800;
-    int enc_h[6], enc_w[6], enc_c[6];   // audio encoder pyramid (index 0 = magnitude)
-    int Cb = 0;                         // bottleneck width
-    int nsep = 32;
-    bool has_video = false, has_flow = false, freq_mask = true;
-
-    std::vector<VarSpec> vars;
-    std::map<std::string, int> var_index;
-    std::vector<const float*> var_ptr;
-    bool bound = false;
-
-    // workspace
-    size_t ws_floats = 0;
-    float* ws = nullptr;
-    std::map<std::string, Buf> bufs;
-    std::map<std::string, Named> named;
-
-    Buf alloc(const std::string& name, size_t n) {
-        Buf b;
-        b.off = ws_floats;
-        b.n = n;
-        ws_floats += (n + 63) / 64 * 64;     // 256-byte granules
-        bufs[name] = b;
-        return b;
-    }
-    float* p(const std::string& name) const { return ws + bufs.at(name).off; }
-    const float* v(const std::string& name) const { return var_ptr[var_index.at(name)]; }
-    void add_var(const std::string& name, std::initializer_list<int64_t> shape) {
-        VarSpec s;
-        s.name = name;
-        s.ndim = (int)shape.size();
-        int i = 0;
-        for (auto d : shape) s.shape[i++] = d;
-        for (; i < 4; ++i) s.shape[i] = 1;
-        var_index[name] = (int)vars.size();
-        vars.push_back(s);
-    }
-    void expose(const std::string& name, const std::string& buf, size_t extra, std::initializer_list<int64_t> shape,
-                int64_t pixel_stride) {
-        Named nm;
-        nm.buf = bufs.at(buf);
-        nm.extra_off = extra;
-        nm.ndim = (int)shape.size();
-        int i = 0;
-        for (auto d : shape) nm.shape[i++] = d;
-        nm.pixel_stride = pixel_stride;
-        named[name] = nm;
-    }
-};
-
-namespace sagen {
-
-static void add_resnet_vars(sagen_ctx* c, const std::string& scope) {
-    auto bn = [&](const std::string& p, int ch) {
-        for (const char* leaf : {"beta", "gamma", "moving_mean", "moving_variance"}) c->add_var(p + "/bn/" + leaf, {ch});
-    };
-    c->add_var(scope + "/conv1/conv/weights", {7, 7, 3, 64});
-    bn(scope + "/conv1/conv", 64);
-    int cin = 64;
-    const int couts[4] = {64, 128, 256, 512};
-    for (int st = 0; st < 4; ++st) {
-        const int cout = couts[st];
-        for (int unit = 1; unit <= 2; ++unit) {
-            const std::string pfx = scope + "/conv" + std::to_string(st + 2) + "_" + std::to_string(unit);
-            if (unit == 1 && cin != cout) c->add_var(pfx + "/shortcut/weights", {1, 1, cin, cout});
-            c->add_var(pfx + "/conv_1/weights", {3, 3, cin, cout});
-            bn(pfx + "/conv_1", cout);
-            c->add_var(pfx + "/conv_2/weights", {3, 3, cout, cout});
-            bn(pfx + "/conv_2", cout);
-            cin = cout;
-        }
-    }
-}
-
-static size_t packed_floats(long N, long K) { return (size_t)N * ((K + 15) / 16 * 16); }
-
-// choose a split-K factor for low-parallelism contractions (>= ~2 workgroups per CU, >= 8 K tiles per split)
-static int auto_splitk(const IgemmDesc& d, IgemmTile tile) {
-    const int bm = (tile == TILE_32x128) ? 32 : 64, bn = (tile == TILE_32x128) ? 128 : 64;
-    const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn);
-    const int nk = d.Kpad / 16;
-    if (blocks >= 384 || nk < 16) return 1;
-    int sk = (int)std::min<long>({(512 + blocks - 1) / blocks, (long)nk / 8, 64L});
-    return std::max(sk, 1);
-}
-
-}  // namespace sagen
+#include "model.h"
 
 // ------------------------------------------------------------------------------------------------
 // create / destroy
@@ -360,7 +203,16 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
     c->var_ptr = ptr;
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
-    // repack filters
+    rc = sagen_repack_impl(c, s);
+    if (rc) return rc;
+    c->bound = true;
+    return SAGEN_OK;
+}
+
+// repack every filter from the bound variables into the kernels' layouts (bind; and once per training step, after the optimiser
+// has updated the variables in place)
+int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
+    int rc = SAGEN_OK;
     for (const auto& vs : c->vars) {
         if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
         const float* src = c->v(vs.name);
@@ -389,383 +241,12 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
         }
         if (rc) return rc;
     }
-    c->bound = true;
     return SAGEN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-namespace sagen {
-
-struct Fwd {
-    sagen_ctx* c;
-    hipStream_t s;
-    int rc = SAGEN_OK;
-    std::string layer;      // label of the layer being launched (profiling only)
-    std::string wsname = "splitk";   // split-K scratch of this launch stream
-    std::string sfx;                 // suffix of the trunk buffers this stream owns ("" or "_b")
-    hipEvent_t wait_before_mfma = nullptr;   // event the first contraction of this stream has to wait for (see forward)
-
-    hipEvent_t next_event() {
-        if (c->events_used == c->event_pool.size()) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            c->event_pool.push_back(e);
-        }
-        return c->event_pool[c->events_used++];
-    }
-    // time one launch (or launch group) with a pair of events on the launch stream
-    template <class F>
-    void timed(const char* kernel, double flops, F&& launch) {
-        if (rc) return;
-        if (!c->profiling) { rc = launch(); return; }
-        ProfRec r;
-        r.kernel = kernel; r.layer = layer; r.flops = flops;
-        r.e0 = next_event(); r.e1 = next_event();
-        if (!r.e0 || !r.e1) { rc = fail(SAGEN_ERR_HIP, "hipEventCreate failed"); return; }
-        hipError_t he = hipEventRecord(r.e0, s);
-        rc = launch();
-        if (he == hipSuccess) he = hipEventRecord(r.e1, s);
-        if (he != hipSuccess && !rc) rc = fail(SAGEN_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(he));
-        c->prof.push_back(r);
-    }
-
-    // ---- one contraction: direct, or split-K partials + reduce (bias / ReLU / row replication / BN statistics) ----
-    bool dense_out(const IgemmDesc& d) const {
-        return d.dsh * d.dsw == 1 && d.g_h0 == 0 && d.g_w0 == 0 && d.y_rstride == (long)d.Wg * d.ldy &&
-               (d.M <= d.Hg * d.Wg || d.y_bstride == (long)d.Hg * d.Wg * d.ldy);
-    }
-    size_t ws_capacity() const { return c->bufs.at(wsname).n; }
-
-    // launches the contraction with an explicit choice; returns the number of BN partial rows written (0 if none)
-    int run_choice(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
-        if (rc) return 0;
-        if (sk > 1 || rep > 1) {
-            IgemmDesc e = d;
-            e.splitk = sk;
-            e.splitk_ws = c->ws + c->bufs.at(wsname).off;
-            e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
-            timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
-            timed("splitk_reduce_kernel", 0.0, [&] {
-                return splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, d.stats, s); });
-            return 0;
-        }
-        timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
-        return 0;
-    }
-
-    Choice heuristic(const IgemmDesc& d, int rep, bool allow_split) const {
-        Choice ch;
-        const IgemmTile tile = igemm_pick_tile(d);
-        ch.tile = (int)tile;
-        const bool can_split = allow_split && dense_out(d) && !d.stats;
-        ch.splitk = can_split ? auto_splitk(d, tile) : 1;
-        while (ch.splitk > 1 && (size_t)ch.splitk * d.M * d.N > ws_capacity()) --ch.splitk;
-        return ch;
-    }
-
-    // one timed launch (group) of a candidate, in microseconds
-    float time_once(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
-        // cold L2: in the forward a layer's filters and activations are not L2-resident from a previous run of the SAME layer;
-        // back-to-back timing made the tuner prefer tiles that only win on warm caches (conv5 planes: 14 MB)
-        const Buf& fl = c->bufs.at("dmask_or_scratch_flush");
-        (void)hipMemsetAsync(c->ws + fl.off, 0, std::min<size_t>(fl.n * sizeof(float), (size_t)48 << 20), s);
-        (void)hipEventRecord(c->tune_e0, s);
-        run_choice(d, rep, tile, sk);
-        (void)hipEventRecord(c->tune_e1, s);
-        if (hipEventSynchronize(c->tune_e1) != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "autotune: event sync failed"); return 1e30f; }
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, c->tune_e0, c->tune_e1);
-        return ms * 1e3f;
-    }
-
-    // time every (tile, split-K) candidate on the real operands (sagen_autotune): a first pass (1 warm + 4 timed, min)
-    // over all candidates, then a playoff of the three fastest (8 interleaved runs each, median) - single timings of
-    // ~10 us launches are too noisy to separate close candidates
-    Choice tune(const IgemmDesc& d, int rep, bool allow_split) {
-        Choice top[3];
-        for (auto& t : top) { t = heuristic(d, rep, allow_split); t.us = 1e30f; }
-        const bool dense = dense_out(d);
-        static const int SKS[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
-        for (int t = 0; t < (int)TILE_AUTO && !rc; ++t) {
-            const IgemmTile tile = (IgemmTile)t;
-            const int bm = igemm_tile_bm(tile), bn = igemm_tile_bn(tile);
-            if (!igemm_tile_ok(d, tile)) continue;
-            const int nk = d.Kpad / igemm_tile_bk(tile);
-            if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
-            if (bm > 32 && bm >= 4 * d.M) continue;
-            for (int sk : SKS) {
-                if (sk > 1 && (!allow_split || !dense || igemm_tile_p3(tile))) break;
-                if (sk > 1 && (nk / sk < 4 || (size_t)sk * d.M * d.N > ws_capacity())) break;
-                if (sk == 1 && rep > 1 && (size_t)d.M * d.N > ws_capacity()) continue;
-                const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn) * sk;
-                if (sk > 1 && blocks > 8192) break;                     // more parallelism than the chip can use
-                float t_best = 1e30f;
-                for (int it = 0; it < 5 && !rc; ++it) {
-                    const float us = time_once(d, rep, tile, sk);
-                    if (it > 0) t_best = std::min(t_best, us);          // first run warms caches / code
-                }
-                Choice ch; ch.tile = t; ch.splitk = sk; ch.us = t_best;
-                for (int k = 0; k < 3; ++k)
-                    if (ch.us < top[k].us) { std::swap(ch, top[k]); }
-            }
-        }
-        if (rc || top[1].us > 1e29f) return top[0];
-        // playoff
-        std::vector<float> runs[3];
-        const int nc = top[2].us > 1e29f ? 2 : 3;
-        for (int it = 0; it < 8 && !rc; ++it)
-            for (int k = 0; k < nc; ++k) runs[k].push_back(time_once(d, rep, (IgemmTile)top[k].tile, top[k].splitk));
-        int best = 0;
-        for (int k = 0; k < nc; ++k) {
-            std::sort(runs[k].begin(), runs[k].end());
-            top[k].us = runs[k][runs[k].size() / 2];
-            if (top[k].us < top[best].us) best = k;
-        }
-        return top[best];
-    }
-
-    int contract(const IgemmDesc& d_in, int rep = 1, bool allow_split = true) {
-        if (rc) return 0;
-        IgemmDesc d = d_in;
-        d.w_split = c->fp32_only ? 0 : 1;          // every bound filter carries its bf16x3 planes
-        if (rep > 1 && !dense_out(d)) { rc = fail(SAGEN_ERR_UNSUPPORTED, "replicated store needs a dense plain epilogue"); return 0; }
-        Choice ch;
-        auto it = c->plan.find(layer);
-        if (c->tuning) {
-            const bool was_prof = c->profiling;
-            c->profiling = false;
-            ch = tune(d, rep, allow_split);
-            c->profiling = was_prof;
-            c->plan[layer] = ch;
-            if (d.stats && !rc && hipMemsetAsync(d.stats, 0, (size_t)2 * d.N * sizeof(double), s) != hipSuccess)
-                rc = fail(SAGEN_ERR_HIP, "autotune: memset failed");         // candidates polluted the accumulators
-        } else if (it != c->plan.end()) {
-            ch = it->second;
-            if (!igemm_tile_ok(d, (IgemmTile)ch.tile)) ch = heuristic(d, rep, allow_split);
-            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || igemm_tile_p3((IgemmTile)ch.tile) || d.Kpad / igemm_tile_bk((IgemmTile)ch.tile) / ch.splitk < 1)) ch.splitk = 1;
-        } else {
-            ch = heuristic(d, rep, allow_split);
-        }
-        if ((ch.splitk > 1 || rep > 1) && (size_t)std::max(ch.splitk, 1) * d.M * d.N > ws_capacity()) {
-            rc = fail(SAGEN_ERR_WORKSPACE, "split-K scratch too small for %s", layer.c_str());
-            return 0;
-        }
-        return run_choice(d, rep, (IgemmTile)ch.tile, std::max(ch.splitk, 1));
-    }
-    void gemm(const IgemmDesc& d, int rep = 1, bool allow_split = true) { contract(d, rep, allow_split); }
-
-    // tfw.conv_2d geometry (core.py:156-220): dense NHWC input/output with pixel strides
-    IgemmDesc conv_desc(const float* x, int Hin, int Win, int Cin, int ldx, const float* wp, int kh, int kw, int sh, int sw,
-                        bool same, int Cout, float* y, int ldy, int& Hout, int& Wout) {
-        IgemmDesc d;
-        int pt = 0, pl = 0;
-        if (same) {
-            Hout = cdiv(Hin, sh); Wout = cdiv(Win, sw);
-            pt = std::max((Hout - 1) * sh + kh - Hin, 0) / 2;
-            pl = std::max((Wout - 1) * sw + kw - Win, 0) / 2;
-        } else {
-            Hout = (Hin - kh) / sh + 1; Wout = (Win - kw) / sw + 1;
-        }
-        d.x = x; d.w = wp; d.y = y;
-        d.M = c->B * Hout * Wout; d.N = Cout; d.K = kh * kw * Cin; d.Kpad = (d.K + 15) / 16 * 16;
-        d.Hg = Hout; d.Wg = Wout;
-        d.Hin = Hin; d.Win = Win; d.Cin = Cin; d.ldx = ldx; d.x_bstride = (long)Hin * Win * ldx;
-        d.in_sh = sh; d.in_sw = sw;
-        d.ntaps = kh * kw; d.TW = kw; d.tap_sh = 1; d.tap_sw = 1; d.tap_h0 = -pt; d.tap_w0 = -pl;
-        d.log2Cin = ilog2_exact(Cin);
-        d.Cout = Cout; d.Hlim = Hout; d.Wlim = Wout;
-        d.ldy = ldy; d.y_rstride = (long)Wout * ldy; d.y_bstride = (long)Hout * Wout * ldy;
-        return d;
-    }
-
-    // tfw.fully_connected (core.py:43-93) on dense rows
-    void fc(const float* x, int M, int K, int ldx, const std::string& name, int N, bool relu, float* y, int ldy, int rep = 1) {
-        layer = name;
-        IgemmDesc d;
-        d.x = x; d.w = c->p("pk:" + name + "/weights"); d.y = y; d.bias = c->v(name + "/biases");
-        d.M = M; d.N = N; d.K = K; d.Kpad = (K + 15) / 16 * 16;
-        d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = K; d.ldx = ldx; d.x_bstride = ldx;
-        d.ntaps = 1; d.Cout = N; d.Hlim = 1; d.Wlim = 1; d.ldy = ldy; d.y_rstride = ldy; d.y_bstride = ldy;
-        d.relu_out = relu;
-        gemm(d, rep);
-    }
-
-    // tfw.deconv_2d (core.py:96-153) as a stride-1 conv with a depth-to-space epilogue
-    void deconv(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int a0, int a1, int Ylim,
-                long y_bstride, long y_row0) {
-        const std::string name = "separation/deconv" + std::to_string(l + 1);
-        layer = name;
-        const int kh = AENC_K[l][0], kw = AENC_K[l][1], sh = AENC_S[l][0], sw = AENC_S[l][1];
-        const int Cout = l == 0 ? c->nsep : AENC_F[l - 1];
-        const int Hout = Hin * sh + kh - sh, Wout = Win * sw + kw - sw;
-        const int nth = cdiv(kh, sh), ntw = cdiv(kw, sw);
-        IgemmDesc d;
-        d.x = x; d.w = c->p("pk:" + name + "/weights"); d.bias = c->v(name + "/biases");
-        d.Hg = (a1 > a0 ? a1 - a0 : cdiv(Hout, sh)); d.g_h0 = a0; d.Wg = cdiv(Wout, sw);
-        d.M = c->B * d.Hg * d.Wg; d.N = sh * sw * Cout; d.K = nth * ntw * Cin; d.Kpad = (d.K + 15) / 16 * 16;
-        d.Hin = Hin; d.Win = Win; d.Cin = Cin; d.ldx = Cin; d.x_bstride = (long)Hin * Win * Cin;
-        d.ntaps = nth * ntw; d.TW = ntw; d.tap_sh = -1; d.tap_sw = -1; d.log2Cin = ilog2_exact(Cin);
-        d.dsh = sh; d.dsw = sw; d.Cout = Cout;
-        d.Hlim = Ylim > 0 ? Ylim : Hout; d.Wlim = Wout;
-        d.ldy = ldy; d.y_rstride = (long)Wout * ldy;
-        d.y_bstride = y_bstride > 0 ? y_bstride : (long)Hout * Wout * ldy;
-        d.y = y - y_row0 * d.y_rstride;
-        d.relu_out = relu;
-        gemm(d);
-    }
-
-    double* bn_acc(int layer_index) { return reinterpret_cast<double*>(c->p("bnacc" + sfx)) + (size_t)layer_index * 2 * 512; }
-    // batch-norm of layer `bn_name` by reference to its statistics accumulators (consumers finalize in-kernel)
-    BnRef bn_ref(int layer_index, const std::string& bn_name, long count) {
-        BnRef r;
-        r.acc = bn_acc(layer_index);
-        r.gamma = c->v(bn_name + "/bn/gamma");
-        r.beta = c->v(bn_name + "/bn/beta");
-        r.inv_count = 1.0 / (double)count;
-        r.eps = 1e-3f;
-        return r;
-    }
-
-    // conv of the ResNet trunk: raw output + batch statistics into accumulator `bn_index`; `bn_in` = the producer's
-    // batch-norm + ReLU applied to the input on the fly
-    void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
-                 const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index, const std::string& plan_key = "",
-                 const void* planes = nullptr) {
-        if (rc) return;
-        IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
-                                Cout, Hout, Wout);
-        if (planes) {                       // the input as pre-split bf16 planes (p3.hip); x may be null then
-            d.xp3 = planes;
-            d.p3_np = c->B * Hin * (Win + 1);
-            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
-            d.xp3_bytes = (unsigned)p3_bytes(c->B, Hin, Win, Cin);
-        }
-        d.bn_in = bn_in;
-        d.stats = bn_acc(bn_index);
-        layer = plan_key.empty() ? name : plan_key;
-        contract(d);
-    }
-
-    // ResNet18 -> conv5_2 in training-mode BN (resnet.py:123-236); returns the [B,7,14,512] output
-    const float* resnet(const float* img, const std::string& scope) {
-        const int B = c->B;
-        int li = 0;
-        if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
-            rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
-        layer = scope + "/pad";
-        timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
-        // conv1 7x7/2 SAME == VALID 7x8 (8th tap column = zero weights) on the padded 4-channel image
-        int H = 0, W = 0;
-        if (!rc && wait_before_mfma) {
-            if (hipStreamWaitEvent(s, wait_before_mfma, 0) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "hipStreamWaitEvent failed");
-            wait_before_mfma = nullptr;
-        }
-        {
-            const std::string name = scope + "/conv1/conv";
-            IgemmDesc d = conv_desc(c->p("xpad" + sfx), 229, 454, 4, 4, c->p("pk:" + name + "/weights"), 7, 8, 2, 2, false, 64,
-                                    c->p("y0" + sfx), 64, H, W);
-            d.stats = bn_acc(li);
-            layer = name;
-            contract(d);
-            const BnRef bn = bn_ref(li, name, (long)B * H * W);
-            if (c->use_p3 && c->p3_from_stage <= 2)       // pooled block input as fp32 (residual) AND as planes (operand of conv2_1/conv_1)
-                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s); });
-            else
-                timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
-            ++li;
-            H = (H + 1) / 2; W = (W + 1) / 2;
-        }
-        float* xin = c->p("rx0" + sfx);
-        float* xout = c->p("rx1" + sfx);
-        int cin = 64;
-        const int couts[4] = {64, 128, 256, 512};
-        for (int st = 0; st < 4; ++st) {
-            const int cout = couts[st];
-            for (int unit = 1; unit <= 2; ++unit) {
-                const std::string pfx = scope + "/conv" + std::to_string(st + 2) + "_" + std::to_string(unit);
-                const bool first = unit == 1 && cin != cout;
-                const int stride = first ? 2 : 1;
-                int Ho = 0, Wo = 0;
-                const float* shortcut = xin;
-                if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
-                    IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
-                                            cout, c->p("rsc" + sfx), cout, Ho, Wo);
-                    layer = pfx + "/shortcut";
-                    gemm(d, 1, false);
-                    shortcut = c->p("rsc" + sfx);
-                }
-                // Pre-split planes pay where the tensors are small next to the contraction: per residual block the plane-writing
-                // passes cost 77 / 38 / 27 / 22 us (stage 2..5, batch 32) against ~30 / 15 / 8 / 5 us for the fp32 BN passes they
-                // replace, while conv3p saves ~19 us per conv at every stage (profiles/r02_*): stage 2 stays on igemm3dw.
-                const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage;
-                void* planes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;
-                // stride-1 conv_1: its input planes were written by the pool / the previous block's merge
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "",
-                        stride == 1 ? planes : nullptr);
-                const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
-                ++li;
-                int H2, W2;
-                if (p3_here) {
-                    // relu(bn1(y1)) -> planes (one elementwise pass), conv_2 on the planes, then the residual merge, which also
-                    // writes the planes of the block output when the next conv_1 is a stride-1 3x3 (unit 1 of a stage)
-                    layer = pfx + "/bn1-relu";
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, 1, nullptr, planes, B, Ho, Wo, cout, s); });
-                    conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes);
-                    const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
-                    layer = pfx + "/merge";
-                    const bool next_p3 = unit == 1;      // the next conv_1 is a stride-1 3x3 of this stage
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s); });
-                    ++li;
-                    std::swap(xin, xout);
-                    H = Ho; W = Wo; cin = cout;
-                    continue;
-                }
-                // conv_2 input = relu(bn1(y1)): on the fly in the conv's fragment path, or materialised once
-                // (cheaper for the small late-stage tensors, where every wave would redo the transform)
-                const std::string l2 = pfx + "/conv_2";
-                auto run_prologue = [&] { conv_bn(c->p("ry1" + sfx), Ho, Wo, cout, l2, 3, 1, cout, bn1, c->p("ry2" + sfx), H2, W2, li); };
-                auto run_materialized = [&](const std::string& key) {
-                    layer = pfx + "/bn1-relu";
-                    timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, c->p("ry1n" + sfx), (long)B * Ho * Wo, cout, s); });
-                    conv_bn(c->p("ry1n" + sfx), Ho, Wo, cout, l2, 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, key);
-                };
-                if (c->tuning && !rc) {
-                    run_prologue();
-                    const float t_pro = c->plan[l2].us;
-                    (void)hipEventRecord(c->tune_e0, s);
-                    (void)bn_apply_relu_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, c->p("ry1n" + sfx), (long)B * Ho * Wo, cout, s);
-                    (void)hipEventRecord(c->tune_e1, s);
-                    (void)hipEventSynchronize(c->tune_e1);
-                    float ms = 0.f;
-                    (void)hipEventElapsedTime(&ms, c->tune_e0, c->tune_e1);
-                    if (!rc && hipMemsetAsync(bn_acc(li), 0, (size_t)2 * cout * sizeof(double), s) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "memset failed");
-                    run_materialized(l2 + "#mat");
-                    const float t_mat = c->plan[l2 + "#mat"].us + ms * 1e3f;
-                    c->materialize[l2] = t_mat < t_pro;
-                    if (!c->materialize[l2] && !rc) {        // leave the prologue result in place
-                        if (hipMemsetAsync(bn_acc(li), 0, (size_t)2 * cout * sizeof(double), s) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "memset failed");
-                        c->tuning = false; run_prologue(); c->tuning = true;
-                    }
-                } else if (c->materialize.count(l2) && c->materialize[l2]) {
-                    run_materialized(l2 + "#mat");
-                } else {
-                    run_prologue();
-                }
-                const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
-                layer = pfx + "/merge";
-                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
-                ++li;
-                std::swap(xin, xout);
-                H = Ho; W = Wo; cin = cout;
-            }
-        }
-        return xin;
-    }
-};
-
-}  // namespace sagen
 
 int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s) {
     if (!c || !audio || !out) return fail(SAGEN_ERR_NULL, "sagen_forward: null argument");
@@ -855,7 +336,8 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         const std::string enc = e == 0 ? "video" : "flow";
         Fwd& w = (e == 1 && c->has_video) ? g : f;
         w.sfx = (e == 1 && c->has_video) ? "_b" : "";
-        const float* feat = w.resnet(e == 0 ? video : flow, enc + "_encoder");          // [B,7,14,512]
+        const float* feat = c->train_mode ? w.resnet_train(e == 0 ? video : flow, enc + "_encoder")      // (retains every activation)
+                                          : w.resnet(e == 0 ? video : flow, enc + "_encoder");          // [B,7,14,512]
         w.fc(feat, B * 98, 512, 512, "bottleneck/" + enc + "-fc-red", 128, true, c->p("fcred" + w.sfx), 128);
         w.fc(c->p("fcred" + w.sfx), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
         choff += 512;

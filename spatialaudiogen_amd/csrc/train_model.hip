@@ -1,0 +1,525 @@
+// The training step of the path (reference train.py:137-236): forward with retained activations, the loss `stft/avg`
+// (model.py:122-127, 156-159), and the backward pass of SptAudioGen.inference_ops (model.py:356-434) - what tf.gradients builds
+// under opt.minimize (myutils.py:220-221) - written as explicit launches:
+//   * weight gradients: wgrad_kernel (wgrad.hip), straight into the caller's gradient buckets (TF variable layouts);
+//   * data gradients: the forward's own implicit-GEMM kernels on re-packed filters - a stride-1 conv's dx is a conv of dy with
+//     the tap-reversed / channel-transposed filter; a strided conv's dx is its conv2d_transpose (depth-to-space form); a
+//     conv2d_transpose's dx is the strided VALID conv of dy; an FC's dx is dy . W^T;
+//   * training-mode batch-norm backward, ReLU masks, bias sums, max-pool routing, tile / concat fan-in (backward.hip);
+//   * the mask -> iSTFT -> mix adjoint (fft.hip).
+// Nothing before the first trainable layer is differentiated (the STFT magnitude and the video frame have no parameters
+// upstream).  The optimiser (fused Adam over flat buckets) and the gradient all-reduce live above the ABI (train.py).
+#include "model.h"
+
+namespace sagen {
+
+static const int RS_H[4] = {56, 28, 14, 7}, RS_W[4] = {112, 56, 28, 14}, RS_C[4] = {64, 128, 256, 512};
+constexpr int CACC_SLOT = 1024;            // doubles per bias-gradient accumulator
+constexpr int CACC_SLOTS = 48;
+constexpr size_t WGWS_FLOATS = (size_t)24 << 20;
+
+static inline int ceil4(int x) { return (x + 3) / 4 * 4; }
+static inline int ceil16(int x) { return (x + 15) / 16 * 16; }
+
+enum PkdKind { PKD_NONE = 0, PKD_FLIPT, PKD_STRIDED, PKD_DECONV, PKD_ROWS };
+
+struct PkdSpec { PkdKind kind = PKD_NONE; int N = 0, K = 0, kh = 0, kw = 0, sh = 1, sw = 1, a = 0, b = 0; };
+
+// how the data-gradient filter of a "/weights" variable is packed
+static PkdSpec pkd_spec(const VarSpec& vs) {
+    PkdSpec p;
+    const std::string& n = vs.name;
+    if (n.find("/deconv") != std::string::npos) {                   // [kh,kw,Cout,Cin]: dx = VALID strided conv of dy
+        p.kind = PKD_DECONV; p.kh = (int)vs.shape[0]; p.kw = (int)vs.shape[1]; p.a = (int)vs.shape[2]; p.b = (int)vs.shape[3];
+        p.N = p.b; p.K = p.kh * p.kw * p.a;
+    } else if (vs.ndim == 2) {                                      // [in,out]: dx = dy . W^T
+        p.kind = PKD_ROWS; p.a = (int)vs.shape[0]; p.b = (int)vs.shape[1];
+        p.N = p.a; p.K = ceil4(p.b);
+    } else if (n.rfind("audio_encoder/", 0) == 0) {
+        const int l = n[std::string("audio_encoder/conv").size()] - '1';
+        if (l == 0) return p;                                       // the spectrogram has no gradient
+        p.kind = PKD_STRIDED; p.kh = AENC_K[l][0]; p.kw = AENC_K[l][1]; p.sh = AENC_S[l][0]; p.sw = AENC_S[l][1];
+        p.a = (int)vs.shape[2]; p.b = (int)vs.shape[3];
+        p.N = p.sh * p.sw * p.a; p.K = cdiv(p.kh, p.sh) * cdiv(p.kw, p.sw) * p.b;
+    } else if (n.find("/conv1/conv/") != std::string::npos) {
+        return p;                                                   // the video frame has no gradient
+    } else {                                                        // ResNet 3x3 / 1x1
+        p.kh = (int)vs.shape[0]; p.kw = (int)vs.shape[1]; p.a = (int)vs.shape[2]; p.b = (int)vs.shape[3];
+        const bool strided = n.find("/shortcut/") != std::string::npos || (n.find("/conv_1/") != std::string::npos && p.a != p.b);
+        if (strided) { p.kind = PKD_STRIDED; p.sh = p.sw = 2; p.N = 4 * p.a; p.K = cdiv(p.kh, 2) * cdiv(p.kw, 2) * p.b; }
+        else { p.kind = PKD_FLIPT; p.N = p.a; p.K = p.kh * p.kw * p.b; }
+    }
+    return p;
+}
+
+static bool is_weights(const std::string& n) { return n.size() >= 8 && n.compare(n.size() - 8, 8, "/weights") == 0; }
+
+static void train_carve(sagen_ctx* c) {
+    if (c->tws_floats) return;
+    const int B = c->B, nsep = c->nsep, Cb = c->Cb;
+    const int ldc = ceil4(3 * (nsep + 1));
+    c->talloc("t:dpred", (size_t)B * 4800 * 3);
+    c->talloc("t:pred", (size_t)B * 4800 * 3);
+    c->talloc("t:loss", 64);
+    c->talloc("t:cacc", (size_t)CACC_SLOTS * CACC_SLOT * 2);
+    c->talloc("t:wgws", WGWS_FLOATS);
+    c->talloc("t:ddmask", (size_t)B * 31 * 1024 * nsep);
+    c->talloc("t:mbw", mask_istft_bwd_scratch_floats(B, nsep));
+    c->talloc("t:dcoeffs", (size_t)B * 3 * ldc);
+    for (int i = 0; i < c->cfg.n_loc_units; ++i) {
+        c->talloc("t:g:loc" + std::to_string(i + 1), (size_t)B * 3 * c->cfg.loc_units[i]);
+        c->talloc("t:dy:loc" + std::to_string(i + 1), (size_t)B * 3 * c->cfg.loc_units[i]);
+    }
+    c->talloc("t:g:bott_loc", (size_t)B * 3 * Cb);
+    c->talloc("t:g:bott_sep", (size_t)B * 3 * Cb);
+    for (int l = 1; l <= 5; ++l) {
+        const size_t px = (size_t)B * c->enc_h[l] * c->enc_w[l];
+        c->talloc("t:dcat" + std::to_string(l), px * 2 * c->enc_c[l]);
+        c->talloc("t:dy:conv" + std::to_string(l), px * c->enc_c[l]);
+        if (l <= 4) {
+            c->talloc("t:dydec" + std::to_string(l), px * c->enc_c[l]);
+            c->talloc("t:g:conv" + std::to_string(l), px * c->enc_c[l]);
+        }
+    }
+    c->talloc("t:g:fcfeats", (size_t)B * 3 * 512);
+    c->talloc("t:dy:fcfeats", (size_t)B * 3 * 512);
+    c->talloc("t:dy:audiofc", (size_t)B * 3 * 1024);
+    c->talloc("t:g:conv5_fc", (size_t)B * 3 * 3072);
+    for (int set = 0; set < 2; ++set) {
+        const std::string x = set ? "_b" : "";
+        if (set == 0 ? !(c->has_video || c->has_flow) : !(c->has_video && c->has_flow)) continue;
+        const size_t stage = (size_t)B * 56 * 112 * 64;
+        c->talloc("t:x0" + x, stage);
+        for (int k = 0; k < 8; ++k) {
+            const size_t sz = (size_t)B * RS_H[k / 2] * RS_W[k / 2] * RS_C[k / 2];
+            for (const char* nm : {"t:y1:", "t:a1:", "t:y2:", "t:out:"}) c->talloc(nm + std::to_string(k) + x, sz);
+        }
+        for (const char* nm : {"t:A0", "t:A1", "t:Z0", "t:Z1", "t:S", "t:DY", "t:DA"}) c->talloc(nm + x, stage);
+        c->talloc("t:dz0" + x, (size_t)B * 112 * 224 * 64);
+        c->talloc("t:bnbacc" + x, (size_t)24 * 2 * 512 * 2);
+        c->talloc("t:stemtmp" + x, (size_t)7 * 32 * 64);
+        c->talloc("t:g:feat" + x, (size_t)B * 98 * 512);
+        c->talloc("t:g:fcred" + x, (size_t)B * 98 * 128);
+        c->talloc("t:dy:fcred" + x, (size_t)B * 98 * 128);
+        c->talloc("t:g:vfc" + x, (size_t)B * 512);
+        c->talloc("t:dy:vfc" + x, (size_t)B * 512);
+    }
+    for (const auto& vs : c->vars) {
+        if (!is_weights(vs.name)) continue;
+        const PkdSpec p = pkd_spec(vs);
+        if (p.kind == PKD_NONE) continue;
+        c->talloc("pkd:" + vs.name, packed_split_floats((size_t)p.N * ceil16(p.K)));
+    }
+}
+
+// data-gradient filter packs, once per step (the optimiser rewrote the variables)
+static int repack_dgrad(sagen_ctx* c, hipStream_t s) {
+    for (const auto& vs : c->vars) {
+        if (!is_weights(vs.name)) continue;
+        const PkdSpec p = pkd_spec(vs);
+        if (p.kind == PKD_NONE) continue;
+        const float* src = c->v(vs.name);
+        float* dst = c->p("pkd:" + vs.name);
+        const int Kpad = ceil16(p.K);
+        int rc = SAGEN_OK;
+        switch (p.kind) {
+            case PKD_FLIPT: rc = pack_conv_flipT_launch(src, p.kh * p.kw, p.a, p.b, dst, Kpad, s); break;
+            case PKD_STRIDED: rc = pack_deconv_launch(src, p.kh, p.kw, p.a, p.b, p.sh, p.sw, dst, p.N, Kpad, s); break;   // HWIO = [kh,kw,"Cout"=Cin,"Cin"=Cout]
+            case PKD_DECONV: rc = pack_conv_launch(src, p.kh * p.kw, p.a, p.a, p.b, dst, p.N, Kpad, s); break;          // [kh,kw,Cout,Cin] read as HWIO
+            case PKD_ROWS: rc = pack_rows_launch(src, p.a, p.b, dst, Kpad, s); break;
+            default: break;
+        }
+        if (!rc) rc = pack_split_launch(dst, p.N, Kpad, s);
+        if (rc) return rc;
+    }
+    return SAGEN_OK;
+}
+
+struct Bwd : Fwd {
+    int cslot = 0;
+    Bwd(sagen_ctx* ctx, hipStream_t st) { c = ctx; s = st; }
+
+    float* grad(const std::string& v) { return c->grad_ptr[c->var_index.at(v)]; }
+    double* cacc_next() {
+        if (cslot >= CACC_SLOTS) { if (!rc) rc = fail(SAGEN_ERR_WORKSPACE, "bias accumulator slots exhausted"); return nullptr; }
+        return reinterpret_cast<double*>(c->p("t:cacc")) + (size_t)(cslot++) * CACC_SLOT;
+    }
+
+    // dy = (ga + gb) * (act > 0); with `bias_var` also the bias gradient sum_rows dy
+    void relu_bwd(const std::string& label, const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy,
+                  int lddy, long R, int C, const std::string& bias_var) {
+        if (rc) return;
+        layer = label;
+        double* acc = bias_var.empty() ? nullptr : cacc_next();
+        if (rc) return;
+        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, s); });
+        if (acc) timed("acc_to_f32_kernel", 0.0, [&] { return acc_to_f32_launch(acc, grad(bias_var), C, s); });
+    }
+
+    WgradDesc wdesc(const float* g, int HG, int WG, int ldg, int Cg, const float* dd, int Hd, int Wd, int ldd, int Cd, int kh, int kw,
+                    int sh, int sw, int h0, int w0) {
+        WgradDesc d;
+        d.g = g; d.d = dd; d.B = c->B; d.Hd = Hd; d.Wd = Wd; d.HG = HG; d.WG = WG; d.ldg = ldg; d.Cg = Cg; d.ldd = ldd; d.Cd = Cd;
+        d.g_rstride = (unsigned)((long)WG * ldg); d.g_bstride = (unsigned)((long)HG * WG * ldg);
+        d.d_rstride = (unsigned)((long)Wd * ldd); d.d_bstride = (unsigned)((long)Hd * Wd * ldd);
+        d.sh = sh; d.sw = sw; d.TH = kh; d.TW = kw; d.h0 = h0; d.w0 = w0;
+        return d;
+    }
+    void wgrad(const std::string& label, WgradDesc d, float* out) {
+        if (rc) return;
+        layer = label;
+        d.out = out;
+        d.ws = c->p("t:wgws");
+        d.splitk = wgrad_pick_splitk(d, c->cap("t:wgws"));
+        const double flops = 2.0 * d.B * d.Hd * d.Wd * d.TH * d.TW * d.Cg * d.Cd;
+        timed("wgrad_kernel", flops, [&] { return wgrad_launch(d, s); });
+    }
+
+    // ---- data gradients on the forward's contraction kernels ----
+    // stride-1 SAME conv (kh x kw odd): dx = conv(dy, flipped / transposed filter)
+    void dgrad_s1(const std::string& name, const float* dy, int H, int W, int Cout, int Cin, float* dx) {
+        if (rc) return;
+        int Ho, Wo;
+        IgemmDesc d = conv_desc(dy, H, W, Cout, Cout, c->p("pkd:" + name + "/weights"), 3, 3, 1, 1, true, Cin, dx, Cin, Ho, Wo);
+        layer = "dgrad:" + name;
+        contract(d);
+    }
+    // conv with stride (sh, sw) and NO padding before (VALID, or TF SAME with pad_before = 0): dx = conv2d_transpose(dy) cropped to
+    // [H, W], as a stride-1 conv over dy whose N index is (ry, rx, ci) with a depth-to-space epilogue
+    void dgrad_strided(const std::string& name, const float* dy, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int H, int W,
+                       int Cin, float* dx, int ldy) {
+        if (rc) return;
+        const int nth = cdiv(kh, sh), ntw = cdiv(kw, sw);
+        IgemmDesc d;
+        d.x = dy; d.w = c->p("pkd:" + name + "/weights"); d.y = dx;
+        d.Hg = cdiv(H, sh); d.Wg = cdiv(W, sw);
+        d.M = c->B * d.Hg * d.Wg; d.N = sh * sw * Cin; d.K = nth * ntw * Cout; d.Kpad = ceil16(d.K);
+        d.Hin = Ho; d.Win = Wo; d.Cin = Cout; d.ldx = Cout; d.x_bstride = (long)Ho * Wo * Cout;
+        d.ntaps = nth * ntw; d.TW = ntw; d.tap_sh = -1; d.tap_sw = -1; d.log2Cin = ilog2_exact(Cout);
+        d.dsh = sh; d.dsw = sw; d.Cout = Cin; d.Hlim = H; d.Wlim = W;
+        d.ldy = ldy; d.y_rstride = (long)W * ldy; d.y_bstride = (long)H * W * ldy;
+        layer = "dgrad:" + name;
+        contract(d);
+    }
+    // fully_connected: dx[M][K] = dy[M][N] . W^T   (dy rows padded with zeros to a multiple of 4)
+    void dgrad_fc(const std::string& name, const float* dy, int lddy, int M, int N, int K, float* dx, int lddx) {
+        if (rc) return;
+        IgemmDesc d;
+        d.x = dy; d.w = c->p("pkd:" + name + "/weights"); d.y = dx;
+        d.M = M; d.N = K; d.K = ceil4(N); d.Kpad = ceil16(d.K);
+        d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = d.K; d.ldx = lddy; d.x_bstride = lddy;
+        d.ntaps = 1; d.Cout = K; d.Hlim = 1; d.Wlim = 1; d.ldy = lddx; d.y_rstride = lddx; d.y_bstride = lddx;
+        layer = "dgrad:" + name;
+        gemm(d);
+    }
+    // y = act(x W + b) backward: weights (and, through `dx`, the input).  dy [M][N] with row stride lddy.
+    void fc_bwd(const std::string& name, const float* x, int ldx, int M, int K, const float* dy, int lddy, int N, float* dx, int lddx) {
+        WgradDesc w = wdesc(x, 1, 1, ldx, K, dy, 1, 1, lddy, N, 1, 1, 1, 1, 0, 0);
+        w.B = M;
+        wgrad("wgrad:" + name, w, grad(name + "/weights"));
+        if (dx) dgrad_fc(name, dy, lddy, M, N, K, dx, lddx);
+    }
+
+    // ---- ResNet18 trunk (resnet.py:123-236) backward; gfeat = dL/d(conv5_2 output) [B,7,14,512] ----
+    double* bnb_acc(int li) { return reinterpret_cast<double*>(c->p("t:bnbacc" + sfx)) + (size_t)li * 2 * 512; }
+    // training-mode BN of layer `li` backward: dz = (ga + gb) * (act > 0) -> dy (and dz), dgamma, dbeta
+    void bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
+                float* dy, float* dz) {
+        if (rc) return;
+        const BnRef bn = bn_ref(li, bn_name, npix);
+        double* acc = bnb_acc(li);
+        layer = "bnbwd:" + bn_name;
+        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, act, y, bn, npix, C, acc, s); });
+        timed("bn_bwd_apply_kernel", 0.0, [&] {
+            return bn_bwd_apply_launch(ga, gb, act, y, bn, acc, npix, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s); });
+    }
+
+    void resnet_bwd(const std::string& scope, const float* gfeat) {
+        const int B = c->B;
+        const float* ga = gfeat;
+        const float* gb = nullptr;
+        float* DY = c->p("t:DY" + sfx); float* DA = c->p("t:DA" + sfx); float* S = c->p("t:S" + sfx);
+        for (int k = 7; k >= 0 && !rc; --k) {
+            const int st = k / 2, unit = k % 2 + 1;
+            const int cout = RS_C[st], cin = (unit == 1 && st > 0) ? RS_C[st - 1] : cout;
+            const bool first = unit == 1 && st > 0;
+            const int Ho = RS_H[st], Wo = RS_W[st], H = first ? 2 * Ho : Ho, W = first ? 2 * Wo : Wo;
+            const long npix = (long)B * Ho * Wo;
+            const std::string pfx = scope + "/conv" + std::to_string(st + 2) + "_" + std::to_string(unit);
+            const std::string ks = std::to_string(k) + sfx;
+            const float* xin = k == 0 ? c->p("t:x0" + sfx) : c->p("t:out:" + std::to_string(k - 1) + sfx);
+            const float* y1 = c->p("t:y1:" + ks); const float* a1 = c->p("t:a1:" + ks);
+            const float* y2 = c->p("t:y2:" + ks); const float* out = c->p("t:out:" + ks);
+            float* A = c->p(std::string(k & 1 ? "t:A1" : "t:A0") + sfx);
+            float* Z = c->p(std::string(k & 1 ? "t:Z1" : "t:Z0") + sfx);
+            const int li1 = 1 + 2 * k, li2 = 2 + 2 * k;
+            // out = relu(bn2(y2) + shortcut)
+            bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z);
+            wgrad("wgrad:" + pfx + "/conv_2", wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_2/weights"));
+            dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA);
+            // a1 = relu(bn1(y1))
+            bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY, nullptr);
+            if (first) {
+                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
+                dgrad_strided(pfx + "/conv_1", DY, Ho, Wo, cout, 3, 3, 2, 2, H, W, cin, A, cin);
+                wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));
+                dgrad_strided(pfx + "/shortcut", Z, Ho, Wo, cout, 1, 1, 2, 2, H, W, cin, S, cin);
+                gb = S;
+            } else {
+                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_1/weights"));
+                dgrad_s1(pfx + "/conv_1", DY, H, W, cout, cin, A);
+                gb = Z;
+            }
+            ga = A;
+        }
+        if (rc) return;
+        // pool + stem: x0 = maxpool(relu(bn0(y0)))  (resnet.py:133-135)
+        const std::string name = scope + "/conv1/conv";
+        float* dz0 = c->p("t:dz0" + sfx);
+        const BnRef bn0 = bn_ref(0, name, (long)B * 112 * 224);
+        layer = "poolbwd:" + scope;
+        timed("maxpool_bwd_kernel", 0.0, [&] { return maxpool_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, s); });
+        bn_bwd(name, 0, dz0, nullptr, nullptr, c->p("y0" + sfx), (long)B * 112 * 224, 64, dz0, nullptr);       // (in place: elementwise)
+        // 7x7/2 over the zero-bordered 4-channel frame: the 7 (+1 zero) horizontal taps x 4 channels are 32 contiguous floats
+        WgradDesc w = wdesc(c->p("xpad" + sfx), 229, 454, 4, 32, dz0, 112, 224, 64, 64, 7, 1, 2, 2, 0, 0);
+        wgrad("wgrad:" + name, w, c->p("t:stemtmp" + sfx));
+        layer = "wgrad:" + name;
+        timed("stem_wgrad_unpack_kernel", 0.0, [&] { return stem_wgrad_unpack_launch(c->p("t:stemtmp" + sfx), grad(name + "/weights"), s); });
+    }
+
+    // ---- everything after the loss ----
+    void run() {
+        const int B = c->B, nsep = c->nsep, Cb = c->Cb;
+        const int ldc = ceil4(3 * (nsep + 1)), ncoef = 3 * (nsep + 1);
+        const int nloc = c->cfg.n_loc_units;
+        float* dcoeffs = c->p("t:dcoeffs");
+        // mask -> iSTFT -> mix adjoint: d(deconv1 output rows 44..66) into the zero-bordered buffer (virtual rows 40..70), d(coeffs)
+        layer = "separation/mask-istft-mix:bwd";
+        timed("mask_istft_bwd_kernel", 0.0, [&] {
+            return mask_istft_mix_bwd_launch(c->p("dmask"), 23L * 1024 * nsep, 1, c->p("spec"), c->p("coeffs"), c->p("t:dpred"), B, nsep,
+                                             c->p("t:ddmask"), 31L * 1024 * nsep, -3, dcoeffs, ldc, c->p("t:mbw"), s); });
+
+        // localization FCs (model.py:241-271): coeffs = fc_last(relu(fc..(bott)))
+        {
+            const std::string last = "localization/fc" + std::to_string(nloc + 1);
+            const float* dy = dcoeffs;
+            int lddy = ldc, N = ncoef;
+            relu_bwd("bias:" + last, dcoeffs, ldc, nullptr, 0, nullptr, 0, nullptr, 0, (long)B * 3, ncoef, last + "/biases");
+            for (int i = nloc; i >= 0; --i) {
+                const std::string name = "localization/fc" + std::to_string(i + 1);
+                const float* x = i == 0 ? c->p("bott") : c->p("loc" + std::to_string(i));
+                const int K = i == 0 ? Cb : c->cfg.loc_units[i - 1];
+                float* dx = i == 0 ? c->p("t:g:bott_loc") : c->p("t:g:loc" + std::to_string(i));
+                fc_bwd(name, x, K, B * 3, K, dy, lddy, N, dx, K);
+                if (i > 0) {
+                    float* dyn = c->p("t:dy:loc" + std::to_string(i));
+                    relu_bwd("relu:localization/fc" + std::to_string(i), dx, K, nullptr, 0, x, K, dyn, K, (long)B * 3, K,
+                             "localization/fc" + std::to_string(i) + "/biases");
+                    dy = dyn; lddy = K; N = K;
+                }
+            }
+        }
+
+        // separation decoder (model.py:282-311): deconv1 is linear; deconv5..2 are ReLU'd and concatenated with the encoder skips
+        {
+            const std::string name = "separation/deconv1";
+            const float* ddm = c->p("t:ddmask");
+            relu_bwd("bias:" + name, ddm, nsep, nullptr, 0, nullptr, 0, nullptr, 0, (long)B * 31 * 1024, nsep, name + "/biases");
+            // live grid rows 10..16 of cat1 <-> buffer rows 4*i' + p (virtual rows 40..70)
+            WgradDesc w = wdesc(ddm, 31, 1024, nsep, nsep, c->p("cat1") + (size_t)10 * 127 * 64, 7, 127, 64, 64, 7, 16, 4, 8, 0, 0);
+            w.d_bstride = 31u * 127u * 64u;
+            wgrad("wgrad:" + name, w, grad(name + "/weights"));
+            int Ho, Wo;
+            IgemmDesc d = conv_desc(ddm, 31, 1024, nsep, nsep, c->p("pkd:" + name + "/weights"), 7, 16, 4, 8, false, 64,
+                                    c->p("t:dcat1") + (size_t)10 * 127 * 64, 64, Ho, Wo);
+            d.y_bstride = 31L * 127 * 64;              // rows outside 10..16 keep the zeros written at bind
+            layer = "dgrad:" + name;
+            contract(d);
+        }
+        for (int l = 1; l <= 4 && !rc; ++l) {          // deconv_{l+1}: cat_{l+1} -> decoder half of cat_l
+            const std::string name = "separation/deconv" + std::to_string(l + 1);
+            const int C = c->enc_c[l], H = c->enc_h[l], W = c->enc_w[l];
+            const int Cn = 2 * c->enc_c[l + 1], Hn = c->enc_h[l + 1], Wn = c->enc_w[l + 1];
+            const float* dcat = c->p("t:dcat" + std::to_string(l));
+            float* dyd = c->p("t:dydec" + std::to_string(l));
+            relu_bwd("relu:" + name, dcat, 2 * C, nullptr, 0, c->p("cat" + std::to_string(l)), 2 * C, dyd, C, (long)B * H * W, C, name + "/biases");
+            wgrad("wgrad:" + name, wdesc(dyd, H, W, C, C, c->p("cat" + std::to_string(l + 1)), Hn, Wn, Cn, Cn, AENC_K[l][0], AENC_K[l][1],
+                                         AENC_S[l][0], AENC_S[l][1], 0, 0), grad(name + "/weights"));
+            int Ho, Wo;
+            IgemmDesc d = conv_desc(dyd, H, W, C, C, c->p("pkd:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1], AENC_S[l][0], AENC_S[l][1],
+                                    false, Cn, c->p("t:dcat" + std::to_string(l + 1)), Cn, Ho, Wo);
+            if (Ho != Hn || Wo != Wn) { rc = fail(SAGEN_ERR_SHAPE, "deconv%d backward geometry", l + 1); return; }
+            layer = "dgrad:" + name;
+            contract(d);
+        }
+        // fc-feats (model.py:287-294): tiled over the 6 frequency columns of cat5
+        {
+            float* g = c->p("t:g:fcfeats");
+            float* dy = c->p("t:dy:fcfeats");
+            layer = "tile:separation/fc-feats";
+            timed("sum_rows_kernel", 0.0, [&] { return sum_rows_launch(c->p("t:dcat5") + 512, 1024, nullptr, 0, 6, (long)B * 3, 512, g, 512, s); });
+            relu_bwd("relu:separation/fc-feats", g, 512, nullptr, 0, c->p("cat5") + 512, 6 * 1024, dy, 512, (long)B * 3, 512, "separation/fc-feats/biases");
+            fc_bwd("separation/fc-feats", c->p("bott"), Cb, B * 3, Cb, dy, 512, 512, c->p("t:g:bott_sep"), Cb);
+        }
+        const float* gbl = c->p("t:g:bott_loc");
+        const float* gbs = c->p("t:g:bott_sep");
+        // bottleneck (model.py:203-239), audio part: audio-fc over (w, c) of conv5
+        {
+            float* dy = c->p("t:dy:audiofc");
+            relu_bwd("relu:bottleneck/audio-fc", gbl, Cb, gbs, Cb, c->p("bott"), Cb, dy, 1024, (long)B * 3, 1024, "bottleneck/audio-fc/biases");
+            WgradDesc w = wdesc(c->p("cat5"), 3, 6, 1024, 512, dy, 3, 1, 1024, 1024, 1, 6, 1, 1, 0, 0);
+            wgrad("wgrad:bottleneck/audio-fc", w, grad("bottleneck/audio-fc/weights"));
+            dgrad_fc("bottleneck/audio-fc", dy, 1024, B * 3, 1024, 3072, c->p("t:g:conv5_fc"), 3072);
+        }
+        // audio encoder (model.py:161-187), conv5 .. conv1
+        for (int l = 5; l >= 1 && !rc; --l) {
+            const std::string name = "audio_encoder/conv" + std::to_string(l);
+            const int C = c->enc_c[l], H = c->enc_h[l], W = c->enc_w[l];
+            const int off = l == 5 ? 0 : C;
+            const float* ga = c->p("t:dcat" + std::to_string(l)) + off;
+            const float* gb2 = l == 5 ? c->p("t:g:conv5_fc") : c->p("t:g:conv" + std::to_string(l));
+            float* dy = c->p("t:dy:conv" + std::to_string(l));
+            relu_bwd("relu:" + name, ga, 2 * C, gb2, C, c->p("cat" + std::to_string(l)) + off, 2 * C, dy, C, (long)B * H * W, C, name + "/biases");
+            const int kh = AENC_K[l - 1][0], kw = AENC_K[l - 1][1], sh = AENC_S[l - 1][0], sw = AENC_S[l - 1][1];
+            if (l == 1) {
+                // Cin = 1: the 16 taps along frequency are 16 contiguous floats of the magnitude row (pixel stride 1 float)
+                WgradDesc w = wdesc(c->p("mag"), 127, 1024, 1, kw, dy, H, W, C, C, kh, 1, sh, sw, 0, 0);
+                wgrad("wgrad:" + name, w, grad(name + "/weights"));
+            } else {
+                const int Cp = c->enc_c[l - 1], Hp = c->enc_h[l - 1], Wp = c->enc_w[l - 1];
+                const float* x = c->p("cat" + std::to_string(l - 1)) + Cp;            // encoder half of cat_{l-1}
+                wgrad("wgrad:" + name, wdesc(x, Hp, Wp, 2 * Cp, Cp, dy, H, W, C, C, kh, kw, sh, sw, 0, 0), grad(name + "/weights"));
+                dgrad_strided(name, dy, H, W, C, kh, kw, sh, sw, Hp, Wp, Cp, c->p("t:g:conv" + std::to_string(l - 1)), Cp);
+            }
+        }
+        // visual encoders: bottleneck FCs (video-fc tiled over the 3 steps), then the trunk
+        int choff = 1024;
+        for (int e = 0; e < 2 && !rc; ++e) {
+            const bool on = e == 0 ? c->has_video : c->has_flow;
+            if (!on) continue;
+            const std::string enc = e == 0 ? "video" : "flow";
+            sfx = (e == 1 && c->has_video) ? "_b" : "";
+            float* g = c->p("t:g:vfc" + sfx);
+            float* dy = c->p("t:dy:vfc" + sfx);
+            layer = "tile:bottleneck/" + enc + "-fc";
+            timed("sum_rows_kernel", 0.0, [&] { return sum_rows_launch(gbl + choff, Cb, gbs + choff, Cb, 3, (long)B, 512, g, 512, s); });
+            relu_bwd("relu:bottleneck/" + enc + "-fc", g, 512, nullptr, 0, c->p("bott") + choff, 3 * Cb, dy, 512, (long)B, 512,
+                     "bottleneck/" + enc + "-fc/biases");
+            fc_bwd("bottleneck/" + enc + "-fc", c->p("fcred" + sfx), 98 * 128, B, 98 * 128, dy, 512, 512, c->p("t:g:fcred" + sfx), 98 * 128);
+            float* dyr = c->p("t:dy:fcred" + sfx);
+            relu_bwd("relu:bottleneck/" + enc + "-fc-red", c->p("t:g:fcred" + sfx), 128, nullptr, 0, c->p("fcred" + sfx), 128, dyr, 128,
+                     (long)B * 98, 128, "bottleneck/" + enc + "-fc-red/biases");
+            fc_bwd("bottleneck/" + enc + "-fc-red", c->p("t:out:7" + sfx), 512, B * 98, 512, dyr, 128, 128, c->p("t:g:feat" + sfx), 512);
+            resnet_bwd(enc + "_encoder", c->p("t:g:feat" + sfx));
+            choff += 512;
+        }
+    }
+};
+
+}  // namespace sagen
+
+size_t sagen_train_workspace_bytes_impl(sagen_ctx* c) {
+    train_carve(c);
+    return c->tws_floats * sizeof(float);
+}
+
+int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving, void* tws,
+                          size_t tws_bytes, hipStream_t s) {
+    if (!c || !grads || !tws) return fail(SAGEN_ERR_NULL, "sagen_train_bind: null argument");
+    if (!c->bound) return fail(SAGEN_ERR_WEIGHTS, "sagen_train_bind: bind the weights first");
+    if (!c->freq_mask) return fail(SAGEN_ERR_UNSUPPORTED, "the training step implements separation 'unet_mask' (the configuration train.py trains)");
+    train_carve(c);
+    if (tws_bytes < c->tws_floats * sizeof(float))
+        return fail(SAGEN_ERR_WORKSPACE, "train workspace has %zu bytes, need %zu", tws_bytes, c->tws_floats * sizeof(float));
+    if (((uintptr_t)tws) % 256) return fail(SAGEN_ERR_WORKSPACE, "train workspace must be 256-byte aligned");
+    c->tws = (float*)tws;
+    std::vector<float*> gp(c->vars.size(), nullptr), mp(c->vars.size(), nullptr);
+    for (int pass = 0; pass < 2; ++pass) {
+        const sagen_tensor* ts = pass ? moving : grads;
+        const int n = pass ? n_moving : n_grads;
+        for (int i = 0; i < n && ts; ++i) {
+            const sagen_tensor& t = ts[i];
+            if (!t.name || !t.data) return fail(SAGEN_ERR_NULL, "tensor %d has a null name or data pointer", i);
+            auto it = c->var_index.find(t.name);
+            if (it == c->var_index.end()) continue;
+            const VarSpec& vs = c->vars[it->second];
+            bool ok = t.ndim == vs.ndim;
+            for (int k = 0; ok && k < vs.ndim; ++k) ok = t.shape[k] == vs.shape[k];
+            if (!ok) return fail(SAGEN_ERR_WEIGHTS, "gradient / moving-average tensor %s has the wrong shape", t.name);
+            if (((uintptr_t)t.data) % 16) return fail(SAGEN_ERR_WEIGHTS, "tensor %s is not 16-byte aligned", t.name);
+            (pass ? mp : gp)[it->second] = const_cast<float*>(t.data);
+        }
+    }
+    for (size_t i = 0; i < c->vars.size(); ++i) {
+        const std::string& nm = c->vars[i].name;
+        if (nm.find("/moving_") != std::string::npos) continue;
+        if (!gp[i]) return fail(SAGEN_ERR_WEIGHTS, "no gradient buffer for variable %s", nm.c_str());
+    }
+    c->grad_ptr = gp;
+    c->mov_ptr = mp;
+    // buffers whose untouched parts must be zero: the border rows of d(mask), the pad column of d(coeffs), the dead rows of d(cat1)
+    for (const char* nm : {"t:ddmask", "t:dcoeffs", "t:dcat1"})
+        SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
+    c->train_ready = true;
+    return SAGEN_OK;
+}
+
+int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
+                          const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s) {
+    if (!c || !audio || !target) return fail(SAGEN_ERR_NULL, "sagen_train_step: null argument");
+    if (!c->train_ready) return fail(SAGEN_ERR_WORKSPACE, "sagen_train_step: call sagen_train_bind first");
+    if (c->tuning) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_train_step during autotune");
+    int rc = sagen_repack_impl(c, s);                  // the optimiser updated the variables in place
+    if (!rc) rc = repack_dgrad(c, s);
+    if (rc) return rc;
+    float* pred = pred_out ? pred_out : c->p("t:pred");
+    c->train_mode = true;
+    rc = sagen_forward_impl(c, audio, video, flow, pred, s);
+    c->train_mode = false;
+    if (rc) return rc;
+    double* loss = reinterpret_cast<double*>(c->p("t:loss"));
+    Bwd b(c, s);
+    b.layer = "loss";
+    b.timed("stft_loss_grad_kernel", 0.0, [&] { return stft_loss_grad_launch(pred, target, mask, c->B, c->p("t:dpred"), loss, s); });
+    if (b.rc) return b.rc;
+    if (loss_out) SAGEN_HIP_CHECK(hipMemcpyAsync(loss_out, loss, sizeof(double), hipMemcpyDeviceToDevice, s));
+    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("t:cacc"), 0, c->tbufs.at("t:cacc").n * sizeof(float), s));
+    for (const char* nm : {"t:bnbacc", "t:bnbacc_b"})
+        if (c->tbufs.count(nm)) SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
+    b.run();
+    if (b.rc) return b.rc;
+    if (update_moving) {
+        // contrib batch_norm update ops (core.py:210, decay 0.99; run with the train op through UPDATE_OPS, train.py:147-148)
+        for (int e = 0; e < 2; ++e) {
+            if (!(e == 0 ? c->has_video : c->has_flow)) continue;
+            const std::string scope = e == 0 ? "video_encoder" : "flow_encoder";
+            b.sfx = (e == 1 && c->has_video) ? "_b" : "";
+            for (int li = 0; li < 17; ++li) {
+                std::string name;
+                int C;
+                long count;
+                if (li == 0) { name = scope + "/conv1/conv"; C = 64; count = (long)c->B * 112 * 224; }
+                else {
+                    const int k = (li - 1) / 2, st = k / 2;
+                    name = scope + "/conv" + std::to_string(st + 2) + "_" + std::to_string(k % 2 + 1) + ((li - 1) % 2 ? "/conv_2" : "/conv_1");
+                    C = RS_C[st]; count = (long)c->B * RS_H[st] * RS_W[st];
+                }
+                float* mm = c->mov_ptr[c->var_index.at(name + "/bn/moving_mean")];
+                float* mv = c->mov_ptr[c->var_index.at(name + "/bn/moving_variance")];
+                if (!mm || !mv) continue;
+                rc = bn_moving_update_launch(b.bn_ref(li, name, count), mm, mv, C, 0.99f, s);
+                if (rc) return rc;
+            }
+        }
+    }
+    return SAGEN_OK;
+}
+
+int sagen_train_get_buffer_impl(const sagen_ctx* c, const char* name, const float** data, size_t* n) {
+    if (!c->tws) return fail(SAGEN_ERR_WORKSPACE, "no train workspace bound");
+    auto it = c->tbufs.find(name);
+    if (it == c->tbufs.end()) return fail(SAGEN_ERR_SHAPE, "unknown train buffer %s", name);
+    *data = c->tws + it->second.off;
+    *n = it->second.n;
+    return SAGEN_OK;
+}

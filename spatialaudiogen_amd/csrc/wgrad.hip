@@ -1,0 +1,291 @@
+// Weight gradients of every contraction of the path (conv / conv2d_transpose / fully_connected) as ONE kernel.
+//
+// Backward of tf.nn.convolution (core.py:206), tf.nn.conv2d_transpose (core.py:140) and tf.matmul (core.py:79) with respect
+// to their filters, i.e. what tf.gradients builds for train.py:147-149 (opt.minimize, myutils.py:220-221).  All three are
+//
+//     dW[t][g][d] = sum over p = (b, i, j) of  G[b, i*sh + th(t) + h0, j*sw + tw(t) + w0, g] * D[b, i, j, d]
+//
+// with D the tensor on the coarse grid and G the tensor that is gathered with the tap displacement:
+//   conv  (HWIO weights [kh,kw,Cin,Cout]) : G = layer input x,   D = dL/dy          -> dW[tap][cin][cout]
+//   deconv ([kh,kw,Cout,Cin], core.py:118): G = dL/dy (fine),    D = layer input x  -> dW[tap][cout][cin]
+//   FC    ([in,out])                      : one tap, 1x1 grid    G = x, D = dL/dy   -> dW[in][out]
+// so the result lands directly in the TF variable layout (= the gradient bucket of train.py: AdamBuckets).
+//
+// Design (CDNA4): the contraction index is the PIXEL, which is the slow dimension of both NHWC operands - [k][m] and [k][n]
+// tiles.  That is the layout the fp32 matrix instruction wants (v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5],
+// B[k=l>>5][j=l&31] - 32 consecutive channels of one pixel per half-wave), so both tiles go global -> LDS by LDS-DMA exactly
+// as they lie in memory (no transpose, no register staging, no ds_write) and fragments are contiguous ds_read_b32/b64;
+// the bf16x3 route of the forward kernels would need both operands transposed AND split in the loop.
+//  * workgroup = (tap, 128|64 channels of G, 128|64 channels of D, pixel range z); 4 waves as 2x2; K tile = 16 pixels;
+//    3-stage LDS ring with counted vmcnt, DMA issue spread between the MFMAs (same skeleton as igemm.hip);
+//  * pixel -> (b, i, j) by two mul-hi divisions per DMA instruction; padding / out-of-range pixels / channel tails set
+//    bit 31 of the buffer offset and the hardware range check writes zeros;
+//  * with two 32-row sub-tiles per wave the sub-tile index is the LOW bit of the channel (row r of sub-tile ti is channel
+//    2r + ti), so one ds_read_b64 feeds both sub-tiles; the epilogue undoes the permutation;
+//  * pixel ranges (split-K) write raw partials, reduced by splitk_reduce_kernel in a fixed order (deterministic gradients);
+//    the block index is remapped so that the tiles of one pixel range share an XCD (L2).
+#include "igemm_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace sagen {
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradDesc d) {
+    constexpr int BK = 16;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_CPR = BM / 4, B_CPR = BN / 4;              // 16-byte chunks per pixel row of the tile
+    constexpr int A_RPI = 64 / A_CPR, B_RPI = 64 / B_CPR;      // pixel rows per DMA instruction (64 lanes x 16 B)
+    constexpr int A_DMA = BK / A_RPI, B_DMA = BK / B_RPI;
+    static_assert(A_DMA % 4 == 0 && B_DMA % 4 == 0, "every wave issues the same number of DMA instructions");
+    constexpr int A_PW = A_DMA / 4, B_PW = B_DMA / 4;
+    constexpr int PER = A_PW + B_PW;
+    constexpr int STAGES = 3;
+    constexpr int TILE_F = (BM + BN) * BK;
+    constexpr int NMFMA = (BK / 2) * MT * NT;
+
+    __shared__ __attribute__((aligned(16))) float smem[STAGES * TILE_F];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kk = lane >> 5;
+
+    // block -> (pixel range z, tap, channel tiles); blocks of one XCD (bid % 8) get a contiguous run, so one z stays on one L2
+    const int ntaps = d.TH * d.TW;
+    const int tiles_g = (d.Cg + BM - 1) / BM, tiles_d = (d.Cd + BN - 1) / BN;
+    const int ntile = ntaps * tiles_g * tiles_d;
+    int n;
+    {
+        const int gm = gridDim.x, bid = blockIdx.x;
+        const int q = gm >> 3, r = gm & 7, xcd = bid & 7, j = bid >> 3;
+        n = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int z = n / ntile;
+    int rem = n - z * ntile;
+    const int tap = rem / (tiles_g * tiles_d);
+    rem -= tap * (tiles_g * tiles_d);
+    const int tg = rem / tiles_d, td = rem - tg * tiles_d;
+    const int th = tap / d.TW, tw = tap - th * d.TW;
+    const int g0 = tg * BM, d0 = td * BN;
+    const int roff = th + d.h0, coff = tw + d.w0;
+
+    const int nchunks = (d.P + BK - 1) / BK;
+    const int per_z = (nchunks + d.splitk - 1) / d.splitk;
+    const int kc0 = z * per_z;
+    const int kc1 = min(nchunks, kc0 + per_z);
+
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.g, 0, d.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.d, 0, d.d_bytes, 0x00020000);
+
+    // per-lane constants of the loaders
+    const unsigned a_cb = (unsigned)(g0 + 4 * (lane % A_CPR)), b_cb = (unsigned)(d0 + 4 * (lane % B_CPR));
+    const unsigned a_cbad = a_cb < (unsigned)d.Cg ? 0u : OOB, b_cbad = b_cb < (unsigned)d.Cd ? 0u : OOB;
+    unsigned a_voff[A_PW], b_voff[B_PW];
+    int i_stage = 0;
+
+    // pixel p -> byte offsets of its D row and of its (tap-displaced) G row; OOB when outside
+    auto pixel = [&](unsigned p, unsigned& goff, unsigned& doff) {
+        const unsigned r = d.Wd == 1 ? p : __umulhi(p, d.magic_w);
+        const unsigned jj = p - r * (unsigned)d.Wd;
+        const unsigned b = d.Hd == 1 ? r : __umulhi(r, d.magic_h);
+        const unsigned ii = r - b * (unsigned)d.Hd;
+        const bool ok = p < (unsigned)d.P;
+        doff = ok ? (b * d.d_bstride + ii * d.d_rstride + jj * (unsigned)d.ldd) * 4u : OOB;
+        const int gi = (int)ii * d.sh + roff, gj = (int)jj * d.sw + coff;
+        const bool gok = ok && (unsigned)gi < (unsigned)d.HG && (unsigned)gj < (unsigned)d.WG;
+        goff = gok ? (b * d.g_bstride + (unsigned)gi * d.g_rstride + (unsigned)gj * (unsigned)d.ldg) * 4u : OOB;
+    };
+    auto begin_issue = [&](int kc, int stage) {
+        i_stage = stage;
+        const unsigned pbase = (unsigned)kc * BK;
+        if constexpr (BM == BN) {
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j) {
+                unsigned go, dof;
+                pixel(pbase + (unsigned)((wave + 4 * j) * A_RPI + lane / A_CPR), go, dof);
+                a_voff[j] = (go + a_cb * 4u) | a_cbad;
+                b_voff[j] = (dof + b_cb * 4u) | b_cbad;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j) {
+                unsigned go, dof;
+                pixel(pbase + (unsigned)((wave + 4 * j) * A_RPI + lane / A_CPR), go, dof);
+                a_voff[j] = (go + a_cb * 4u) | a_cbad;
+            }
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j) {
+                unsigned go, dof;
+                pixel(pbase + (unsigned)((wave + 4 * j) * B_RPI + lane / B_CPR), go, dof);
+                b_voff[j] = (dof + b_cb * 4u) | b_cbad;
+            }
+        }
+    };
+    auto issue_one = [&](int g) {
+        float* st = smem + i_stage * TILE_F;
+        if (g < A_PW) dma16(g_rsrc, st + (wave + 4 * g) * 256, a_voff[g], 0);
+        else dma16(d_rsrc, st + BK * BM + (wave + 4 * (g - A_PW)) * 256, b_voff[g - A_PW], 0);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int ntiles = kc1 - kc0;
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < ntiles) {
+            begin_issue(kc0 + t, t);
+#pragma unroll
+            for (int g = 0; g < PER; ++g) issue_one(g);
+        }
+    if (ntiles > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    lds_barrier();
+
+    int stage = 0;
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const bool more = kc + (STAGES - 1) < kc1;
+        int istage = stage + (STAGES - 1);
+        if (istage >= STAGES) istage -= STAGES;
+        if (more) begin_issue(kc + (STAGES - 1), istage);
+        const float* As = smem + stage * TILE_F + wm * WM + MT * li;
+        const float* Bs = smem + stage * TILE_F + BK * BM + wn * WN + NT * li;
+        float af[BK / 2][MT], bf[BK / 2][NT];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int krow = 2 * s + kk;
+            if constexpr (MT == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(As + krow * BM);
+                af[s][0] = v.x; af[s][1] = v.y;
+            } else {
+                af[s][0] = As[krow * BM];
+            }
+            if constexpr (NT == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(Bs + krow * BN);
+                bf[s][0] = v.x; bf[s][1] = v.y;
+            } else {
+                bf[s][0] = Bs[krow * BN];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+                    const int idx = (s * MT + i) * NT + j;
+#pragma unroll
+                    for (int g = 0; g < PER; ++g)
+                        if (idx == (g + 1) * NMFMA / (PER + 1) - 1 && more) issue_one(g);
+                }
+        if (more) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+        lds_barrier();
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+    }
+
+    // epilogue.  C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); row r of sub-tile i is channel MT*r + i
+    float* out = d.splitk > 1 ? d.ws + (size_t)z * ntaps * d.Cg * d.Cd : d.out;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = (e & 3) + 8 * (e >> 2) + 4 * kk;
+            const int g = g0 + wm * WM + MT * rr + i;
+            if (g >= d.Cg) continue;
+            float* orow = out + ((size_t)tap * d.Cg + g) * d.Cd;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int dd = d0 + wn * WN + NT * li + j;
+                if (dd < d.Cd) orow[dd] = acc[i][j][e];
+            }
+        }
+}
+
+// plain reference of the same contraction (one thread per output element, fp64 accumulation): SAGEN_WGRAD_REF=1 routes every
+// weight gradient through it - a debugging aid that isolates the MFMA kernel from the rest of the backward pass
+__global__ __launch_bounds__(256) void wgrad_ref_kernel(const WgradDesc d) {
+    const long total = (long)d.TH * d.TW * d.Cg * d.Cd;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int dd = (int)(idx % d.Cd);
+    long r = idx / d.Cd;
+    const int g = (int)(r % d.Cg);
+    const int tap = (int)(r / d.Cg);
+    const int th = tap / d.TW, tw = tap - th * d.TW;
+    double acc = 0.0;
+    for (int b = 0; b < d.B; ++b)
+        for (int i = 0; i < d.Hd; ++i) {
+            const int gi = i * d.sh + th + d.h0;
+            if ((unsigned)gi >= (unsigned)d.HG) continue;
+            for (int j = 0; j < d.Wd; ++j) {
+                const int gj = j * d.sw + tw + d.w0;
+                if ((unsigned)gj >= (unsigned)d.WG) continue;
+                acc += (double)d.g[(size_t)b * d.g_bstride + (size_t)gi * d.g_rstride + (size_t)gj * d.ldg + g] *
+                       (double)d.d[(size_t)b * d.d_bstride + (size_t)i * d.d_rstride + (size_t)j * d.ldd + dd];
+            }
+        }
+    d.out[idx] = (float)acc;
+}
+
+static unsigned magic_of(int dv) { return dv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1ull); }
+
+size_t wgrad_ws_floats(const WgradDesc& d, int splitk) { return splitk > 1 ? (size_t)splitk * d.TH * d.TW * d.Cg * d.Cd : 0; }
+
+int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats) {
+    const int bm = d.Cg > 64 ? 128 : 64, bn = d.Cd > 64 ? 128 : 64;
+    const long ntile = (long)d.TH * d.TW * cdiv(d.Cg, bm) * cdiv(d.Cd, bn);
+    const long P = (long)d.B * d.Hd * d.Wd;
+    const long nchunks = (P + 15) / 16;
+    long sk = std::max<long>(1, std::min<long>((1024 + ntile - 1) / ntile, nchunks / 8));
+    const size_t per = (size_t)d.TH * d.TW * d.Cg * d.Cd;
+    while (sk > 1 && sk * per > ws_capacity_floats) --sk;
+    return (int)std::min<long>(sk, 256);
+}
+
+int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
+    WgradDesc d = d_in;
+    if (!d.g || !d.d || !d.out) return fail(SAGEN_ERR_NULL, "wgrad: null operand");
+    if (d.B <= 0 || d.Hd <= 0 || d.Wd <= 0 || d.Cg <= 0 || d.Cd <= 0 || d.TH <= 0 || d.TW <= 0 || d.sh <= 0 || d.sw <= 0)
+        return fail(SAGEN_ERR_SHAPE, "wgrad: bad dimensions");
+    if (d.Cg % 4 || d.ldg <= 0 || d.ldd % 4 || (d.Cd % 4 && d.ldd < (d.Cd + 3) / 4 * 4))
+        return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: Cg=%d must be a multiple of 4, D rows must be padded to a multiple of 4 floats (Cd=%d ldd=%d)", d.Cg, d.Cd, d.ldd);
+    if (((uintptr_t)d.g | (uintptr_t)d.d) % 16) return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: operands must be 16-byte aligned");
+    const long P = (long)d.B * d.Hd * d.Wd;
+    const long gb = ((long)(d.B - 1) * d.g_bstride + (long)d.HG * d.g_rstride) * 4 + 64, db = ((long)(d.B - 1) * d.d_bstride + (long)d.Hd * d.d_rstride) * 4 + 64;
+    if (gb >= (1L << 31) || db >= (1L << 31) || P >= (1L << 24) || (long)P * d.Wd >= (1L << 32))
+        return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: operand exceeds 2 GiB buffer addressing / 2^24 pixels (use a smaller batch)");
+    d.P = (int)P;
+    d.g_bytes = (unsigned)gb; d.d_bytes = (unsigned)db;
+    d.magic_w = magic_of(d.Wd); d.magic_h = magic_of(d.Hd);
+    static const bool use_ref = getenv("SAGEN_WGRAD_REF") != nullptr;
+    const long total = (long)d.TH * d.TW * d.Cg * d.Cd;
+    if (use_ref) {
+        hipLaunchKernelGGL(wgrad_ref_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, d);
+        SAGEN_LAUNCH_CHECK();
+        return SAGEN_OK;
+    }
+    if (d.splitk < 1) d.splitk = 1;
+    if (d.splitk > 1 && !d.ws) return fail(SAGEN_ERR_WORKSPACE, "wgrad: split-K needs a workspace");
+    const int bm = d.Cg > 64 ? 128 : 64, bn = d.Cd > 64 ? 128 : 64;
+    const long blocks = (long)d.TH * d.TW * cdiv(d.Cg, bm) * cdiv(d.Cd, bn) * d.splitk;
+    if (blocks >= (1L << 30)) return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: grid too large");
+    const dim3 grid((unsigned)blocks);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, d);
+    else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, s, d);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, d);
+    SAGEN_LAUNCH_CHECK();
+    if (d.splitk > 1)
+        return splitk_reduce_launch(d.ws, d.splitk, d.TH * d.TW * d.Cg, d.Cd, nullptr, 0, d.out, d.Cd, 1, nullptr, s);
+    return SAGEN_OK;
+}
+
+}  // namespace sagen

@@ -160,3 +160,75 @@ def assemble_wyzx(audio, ambi_yzx, snd_contx=48000):
     out = torch.empty(B, dur, 4, dtype=torch.float32, device=audio.device)
     check(_lib.lib().sagen_assemble_wyzx(_ptr(audio), _ptr(ambi_yzx), _ptr(out), B, n, snd_contx, dur, _stream()))
     return out
+
+
+# ---- backward, op level (the gradients tf.gradients builds for the wrappers above; include/sagen.h) -----------------------
+def wgrad(g, d, kh, kw, stride=(1, 1), origin=(0, 0), split=True):
+    """dw[th,tw,cg,cd] = sum_{b,i,j} G[b, i*sh+th+h0, j*sw+tw+w0, :] (x) D[b,i,j,:].  conv_2d: G = x, D = dy, origin = -pad_before
+    -> HWIO; deconv_2d: G = dy, D = x -> [kh,kw,Cout,Cin]; fully_connected: 2-D G [M,K], D [M,N] -> [K,N]."""
+    g, d = _f32(g, 'g'), _f32(d, 'd')
+    if g.dim() == 2:
+        g, d = g[:, None, None, :], d[:, None, None, :]
+    B, HG, WG, CG = g.shape
+    _, HD, WD, CD = d.shape
+    l = _lib.lib()
+    dw = torch.empty(kh, kw, CG, CD, dtype=torch.float32, device=g.device)
+    scratch = _scratch(l.sagen_wgrad_scratch_bytes(kh, kw, CG, CD), g.device) if split else None
+    check(l.sagen_wgrad(_ptr(g), B, HG, WG, CG, _ptr(d), HD, WD, CD, kh, kw, stride[0], stride[1], origin[0], origin[1], _ptr(dw),
+                        _ptr(scratch), scratch.numel() * 4 if split else 0, _stream()))
+    return dw
+
+
+def conv_2d_bwd_data(dy, weights, in_hw, stride=1, padding='SAME'):
+    """Input gradient of conv_2d: dy [B,Ho,Wo,Cout], weights HWIO -> dx [B,H,W,Cin]."""
+    dy, weights = _f32(dy, 'dy'), _f32(weights, 'weights')
+    B, Ho, Wo, cout = dy.shape
+    kh, kw, cin, cout2 = weights.shape
+    assert cout2 == cout
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    H, W = in_hw
+    l = _lib.lib()
+    dx = torch.empty(B, H, W, cin, dtype=torch.float32, device=dy.device)
+    scratch = _scratch(l.sagen_conv2d_bwd_data_scratch_bytes(kh, kw, cin, cout, sh, sw), dy.device)
+    check(l.sagen_conv2d_bwd_data(_ptr(dy), B, Ho, Wo, cout, _ptr(weights), kh, kw, cin, sh, sw, {'VALID': 0, 'SAME': 1}[padding], H, W,
+                                  _ptr(dx), _ptr(scratch), scratch.numel() * 4, _stream()))
+    return dx
+
+
+def bn_bwd(g, y, stats, gamma, beta, act=None, g2=None, eps=1e-3, want_dz=False):
+    """Training-mode batch-norm backward at the raw conv output y [.., C] (stats from conv_2d(return_bn_stats=True)):
+    dz = (g + g2) * (act > 0) -> (dy, dgamma, dbeta[, dz])."""
+    g, y = _f32(g, 'g'), _f32(y, 'y')
+    C_ = y.shape[-1]
+    npix = y.numel() // C_
+    dy = torch.empty_like(y)
+    dz = torch.empty_like(y) if want_dz else None
+    dgamma = torch.empty(C_, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(C_, dtype=torch.float32, device=y.device)
+    scratch = torch.empty(2 * C_, dtype=torch.float64, device=y.device)
+    check(_lib.lib().sagen_bn_bwd(_ptr(g), _ptr(g2), _ptr(act), _ptr(y), _ptr(stats), _ptr(_f32(gamma, 'gamma')), _ptr(_f32(beta, 'beta')), eps,
+                                  npix, C_, _ptr(dy), _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(scratch), scratch.numel() * 8, _stream()))
+    return (dy, dgamma, dbeta, dz) if want_dz else (dy, dgamma, dbeta)
+
+
+def maxpool3x3s2_bwd(y0, stats, gamma, beta, pooled, g, g2=None, eps=1e-3):
+    """Backward of maxpool3x3s2(relu(bn(y0))) to the BN output: y0 [B,H,W,C] raw conv output, pooled / g [B,Ho,Wo,C]."""
+    y0 = _f32(y0, 'y0')
+    B, H, W, C_ = y0.shape
+    dz = torch.empty_like(y0)
+    check(_lib.lib().sagen_maxpool3x3s2_bwd(_ptr(y0), _ptr(stats), _ptr(_f32(gamma, 'gamma')), _ptr(_f32(beta, 'beta')), eps, _ptr(_f32(pooled, 'pooled')),
+                                            _ptr(_f32(g, 'g')), _ptr(g2), _ptr(dz), B, H, W, C_, _stream()))
+    return dz
+
+
+def mask_istft_mix_bwd(dmask, spec, coeffs, dpred):
+    """Adjoint of mask_istft_mix: dpred [B,4800,3] -> (d_dmask [B,28,1024,K], d_coeffs [B,3,3,K+1])."""
+    dmask, spec, coeffs, dpred = _f32(dmask, 'dmask'), _f32(spec, 'spec'), _f32(coeffs, 'coeffs'), _f32(dpred, 'dpred')
+    B, ntr = dmask.shape[0], dmask.shape[3]
+    l = _lib.lib()
+    dd = torch.empty_like(dmask)
+    dc = torch.empty_like(coeffs)
+    scratch = _scratch(l.sagen_mask_istft_mix_bwd_scratch_bytes(B, ntr), dmask.device)
+    check(l.sagen_mask_istft_mix_bwd(_ptr(dmask), _ptr(spec), _ptr(coeffs), _ptr(dpred), B, ntr, _ptr(dd), _ptr(dc), _ptr(scratch),
+                                     scratch.numel() * 4, _stream()))
+    return dd, dc

@@ -1,0 +1,312 @@
+"""Backward pass on the device (csrc/wgrad.hip, backward.hip, fft.hip adjoint, train_model.hip) against fp64 autograd over the
+independent torch-CPU restatement (oracle/torch_ref.py): every op-level gradient kernel on the geometries of the path and on odd
+ones, then every variable's gradient of the whole network, then a 3-step Adam trajectory (reference train.py:137-236).
+Tolerances are stated per test; all calls go through the C ABI."""
+import numpy as np
+import pytest
+
+from util import rng, ensure_lib, rel_rms_err, rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    ensure_lib()
+    return torch
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _conv_ref(T, x, w, stride, padding, dy):
+    """fp64 autograd of tf.nn.convolution (oracle/torch_ref.conv2d_tf): returns (dx NHWC, dw HWIO)."""
+    from oracle.torch_ref import conv2d_tf
+    xt = T.as_tensor(x, dtype=T.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = T.as_tensor(w, dtype=T.float64).requires_grad_(True)
+    y = conv2d_tf(xt, wt, stride, padding)
+    y.backward(T.as_tensor(dy, dtype=T.float64).permute(0, 3, 1, 2))
+    return xt.grad.permute(0, 2, 3, 1).numpy(), wt.grad.numpy(), tuple(y.shape[2:])
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, kh, kw, sh, sw, padding
+    (3, 12, 20, 64, 64, 3, 3, 1, 1, 'SAME'),        # ResNet stage 2 shape class (64x64 tile)
+    (2, 10, 18, 64, 128, 3, 3, 2, 2, 'SAME'),       # conv3_1/conv_1: stride 2, pad (0,1)
+    (2, 10, 18, 64, 128, 1, 1, 2, 2, 'SAME'),       # shortcut
+    (2, 7, 14, 128, 256, 3, 3, 1, 1, 'SAME'),       # 128x128 tile, small image (edge handling dominates)
+    (2, 9, 13, 256, 128, 3, 3, 1, 1, 'SAME'),       # odd sizes, Cg > Cd
+    (2, 15, 31, 32, 64, 3, 7, 2, 4, 'VALID'),       # audio conv2
+    (2, 15, 31, 64, 128, 3, 5, 2, 2, 'VALID'),      # audio conv3
+    (3, 7, 14, 128, 256, 3, 5, 1, 1, 'VALID'),      # audio conv4
+    (2, 16, 16, 16, 32, 5, 3, 3, 2, 'VALID'),       # ragged: rows / columns the strided conv never reads
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_weight_and_data_gradients(T, case):
+    from spatialaudiogen_amd import ops
+    B, H, W, Cin, Cout, kh, kw, sh, sw, padding = case
+    r = rng(sum(v for v in case if isinstance(v, int)))
+    x = r.normal(size=(B, H, W, Cin)).astype(np.float32)
+    w = (r.normal(size=(kh, kw, Cin, Cout)) / np.sqrt(kh * kw * Cin)).astype(np.float32)
+    if padding == 'SAME':
+        Ho, Wo = -(-H // sh), -(-W // sw)
+        pt = max((Ho - 1) * sh + kh - H, 0) // 2
+        pl = max((Wo - 1) * sw + kw - W, 0) // 2
+    else:
+        Ho, Wo, pt, pl = (H - kh) // sh + 1, (W - kw) // sw + 1, 0, 0
+    dy = r.normal(size=(B, Ho, Wo, Cout)).astype(np.float32)
+    dx_ref, dw_ref, hw = _conv_ref(T, x, w, (sh, sw), padding, dy)
+    assert hw == (Ho, Wo)
+    xd, wd, dyd = T.as_tensor(x).cuda(), T.as_tensor(w).cuda(), T.as_tensor(dy).cuda()
+    for split in (True, False):
+        dw = ops.wgrad(xd, dyd, kh, kw, (sh, sw), (-pt, -pl), split=split).cpu().numpy()
+        assert rel_rms_err(dw, dw_ref) < 2e-6, ('wgrad', split, rel_rms_err(dw, dw_ref))
+    if Cout & (Cout - 1) == 0 and (sh == 1 or (pt == 0 and pl == 0)):
+        dx = ops.conv_2d_bwd_data(dyd, wd, (H, W), (sh, sw), padding).cpu().numpy()
+        assert rel_rms_err(dx, dx_ref) < 2e-5, ('dgrad', rel_rms_err(dx, dx_ref))
+
+
+def test_deconv_and_fc_weight_gradients(T):
+    """conv2d_transpose: G = dy (fine grid), D = x (coarse grid); fully_connected: one tap on a 1x1 grid."""
+    from spatialaudiogen_amd import ops
+    from oracle.torch_ref import deconv2d_tf
+    r = rng(77)
+    for (B, H, W, Cin, Cout, kh, kw, sh, sw) in [(2, 5, 10, 256, 128, 3, 5, 1, 1), (2, 7, 14, 128, 64, 3, 5, 2, 2), (2, 6, 9, 64, 32, 7, 16, 4, 8)]:
+        x = r.normal(size=(B, H, W, Cin)).astype(np.float32)
+        w = (r.normal(size=(kh, kw, Cout, Cin)) / np.sqrt(kh * kw * Cin)).astype(np.float32)
+        xt = T.as_tensor(x, dtype=T.float64).permute(0, 3, 1, 2)
+        wt = T.as_tensor(w, dtype=T.float64).requires_grad_(True)
+        y = deconv2d_tf(xt, wt, (sh, sw))
+        dy = r.normal(size=tuple(y.shape)).astype(np.float32)
+        y.backward(T.as_tensor(dy, dtype=T.float64))
+        dyd = T.as_tensor(dy).cuda().permute(0, 2, 3, 1).contiguous()
+        dw = ops.wgrad(dyd, T.as_tensor(x).cuda(), kh, kw, (sh, sw), (0, 0)).cpu().numpy()
+        assert dw.shape == w.shape and rel_rms_err(dw, wt.grad.numpy()) < 2e-6, (kh, kw, rel_rms_err(dw, wt.grad.numpy()))
+    for (M, K, N) in [(96, 1536, 512), (32, 12544, 512), (96, 512, 100), (7, 64, 64)]:
+        x = r.normal(size=(M, K)).astype(np.float32)
+        dy = r.normal(size=(M, N)).astype(np.float32)
+        dw = ops.wgrad(T.as_tensor(x).cuda(), T.as_tensor(dy).cuda(), 1, 1).cpu().numpy()[0, 0]
+        ref = x.astype(np.float64).T @ dy.astype(np.float64)
+        assert rel_rms_err(dw, ref) < 2e-6, (M, K, N, rel_rms_err(dw, ref))
+
+
+def test_batch_norm_backward(T):
+    """conv -> training-mode BN -> (+ residual) -> ReLU, gradient at the raw conv output, gamma and beta vs fp64 autograd."""
+    from spatialaudiogen_amd import ops
+    from oracle.torch_ref import bn_train
+    import torch.nn.functional as F
+    r = rng(5)
+    for (B, H, W, C) in [(4, 9, 11, 64), (2, 7, 14, 512), (3, 5, 6, 128)]:
+        y = (r.normal(size=(B, H, W, C)) * r.uniform(0.5, 2.0, size=C) + r.normal(size=C)).astype(np.float32)
+        gamma, beta = r.uniform(0.5, 1.5, size=C).astype(np.float32), r.normal(0, 0.2, size=C).astype(np.float32)
+        res = r.normal(size=y.shape).astype(np.float32)
+        g1, g2 = r.normal(size=y.shape).astype(np.float32), r.normal(size=y.shape).astype(np.float32)
+        yt = T.as_tensor(y, dtype=T.float64).permute(0, 3, 1, 2).requires_grad_(True)
+        gt_, bt = T.as_tensor(gamma, dtype=T.float64).requires_grad_(True), T.as_tensor(beta, dtype=T.float64).requires_grad_(True)
+        out = F.relu(bn_train(yt, gt_, bt) + T.as_tensor(res, dtype=T.float64).permute(0, 3, 1, 2))
+        out.backward(T.as_tensor(g1.astype(np.float64) + g2, dtype=T.float64).permute(0, 3, 1, 2))
+        yd = T.as_tensor(y).cuda()
+        stats = T.stack([yd.double().sum((0, 1, 2)), (yd.double() ** 2).sum((0, 1, 2))]).contiguous()
+        act = T.as_tensor(_nhwc(out.detach()).numpy().astype(np.float32)).cuda()
+        dy, dgam, dbet, dz = ops.bn_bwd(T.as_tensor(g1).cuda(), yd, stats, T.as_tensor(gamma).cuda(), T.as_tensor(beta).cuda(), act=act,
+                                        g2=T.as_tensor(g2).cuda(), want_dz=True)
+        assert rel_rms_err(dy.cpu().numpy(), _nhwc(yt.grad).numpy()) < 2e-5
+        assert rel_rms_err(dgam.cpu().numpy(), gt_.grad.numpy()) < 1e-5 and rel_rms_err(dbet.cpu().numpy(), bt.grad.numpy()) < 1e-5
+        assert np.array_equal(dz.cpu().numpy(), (g1 + g2) * (act.cpu().numpy() > 0))
+
+
+def test_maxpool_backward(T):
+    from spatialaudiogen_amd import ops
+    from oracle.torch_ref import bn_train, _same
+    import torch.nn.functional as F
+    r = rng(8)
+    for (B, H, W, C) in [(2, 12, 20, 64), (2, 11, 9, 64)]:
+        y0 = r.normal(size=(B, H, W, C)).astype(np.float32)
+        gamma, beta = r.uniform(0.5, 1.5, size=C).astype(np.float32), r.normal(0, 0.3, size=C).astype(np.float32)
+        yd = T.as_tensor(y0).cuda()
+        stats = T.stack([yd.double().sum((0, 1, 2)), (yd.double() ** 2).sum((0, 1, 2))]).contiguous()
+        sc, sh = ops.bn_finalize(stats, (B, H, W, C), T.as_tensor(gamma).cuda(), T.as_tensor(beta).cuda())
+        pooled = ops.maxpool3x3s2(yd, sc, sh)
+        g = r.normal(size=tuple(pooled.shape)).astype(np.float32)
+        # reference: autograd through relu(bn) -> padded max-pool, gradient taken at the BN OUTPUT z
+        yt = T.as_tensor(y0, dtype=T.float64).permute(0, 3, 1, 2)
+        z = bn_train(yt, T.as_tensor(gamma, dtype=T.float64), T.as_tensor(beta, dtype=T.float64)).detach().requires_grad_(True)
+        pt, pb = _same(H, 3, 2)
+        pl, pr = _same(W, 3, 2)
+        p = F.max_pool2d(F.pad(F.relu(z), (pl, pr, pt, pb), value=float('-inf')), 3, 2)
+        assert rel_rms_err(pooled.cpu().numpy(), _nhwc(p.detach()).numpy()) < 1e-5
+        p.backward(T.as_tensor(g, dtype=T.float64).permute(0, 3, 1, 2))
+        dz = ops.maxpool3x3s2_bwd(yd, stats, T.as_tensor(gamma).cuda(), T.as_tensor(beta).cuda(), pooled, T.as_tensor(g).cuda())
+        assert rel_rms_err(dz.cpu().numpy(), _nhwc(z.grad).numpy()) < 1e-6
+
+
+def _mix_ref(T, dmask, spec_full, coeffs):
+    """fp64 restatement of the separation tail (model.py:326-347, myutils.py:181-211, model.py:421-434) with autograd."""
+    B, _, _, K = dmask.shape
+    m = T.sigmoid(dmask.permute(0, 3, 1, 2))                                  # [B,K,28,1024]
+    y = T.fft.ifft(spec_full[:, None] * m, dim=-1).real
+    ola = T.zeros(B, K, 27 * 256 + 1024, dtype=T.float64)
+    for f in range(28):
+        ola[:, :, f * 256:f * 256 + 1024] += y[:, :, f]
+    xs = (ola / 4.)[:, :, 768:768 + 6400][:, :, 448:448 + 4800]
+    step = T.arange(4800) // 1600
+    return T.einsum('bnok,bkn->bno', coeffs[..., :-1][:, step], xs) + coeffs[..., -1][:, step]
+
+
+def test_mask_istft_mix_adjoint(T):
+    from spatialaudiogen_amd import ops
+    r = rng(21)
+    for K in (32, 16):
+        B = 2
+        audio = r.normal(size=(B, 52799)).astype(np.float32)
+        dmask = r.normal(size=(B, 28, 1024, K)).astype(np.float32)
+        coeffs = (0.3 * r.normal(size=(B, 3, 3, K + 1))).astype(np.float32)
+        dpred = r.normal(size=(B, 4800, 3)).astype(np.float32)
+        _, spec = ops.stft_mag(T.as_tensor(audio).cuda(), 46, 173, 89, 117)
+        sp = spec.cpu().double()
+        half = T.complex(sp[..., 0], sp[..., 1])                              # [B,28,513]
+        full = T.cat([half, T.conj(half[:, :, 1:512].flip(-1))], -1)
+        dm = T.as_tensor(dmask, dtype=T.float64).requires_grad_(True)
+        co = T.as_tensor(coeffs, dtype=T.float64).requires_grad_(True)
+        out = _mix_ref(T, dm, full, co)
+        got = ops.mask_istft_mix(T.as_tensor(dmask).cuda(), spec, T.as_tensor(coeffs).cuda()).cpu().numpy()
+        assert rel_rms_err(got, out.detach().numpy()) < 1e-5
+        out.backward(T.as_tensor(dpred, dtype=T.float64))
+        dd, dc = ops.mask_istft_mix_bwd(T.as_tensor(dmask).cuda(), spec, T.as_tensor(coeffs).cuda(), T.as_tensor(dpred).cuda())
+        assert rel_rms_err(dc.cpu().numpy(), co.grad.numpy()) < 2e-5, rel_rms_err(dc.cpu().numpy(), co.grad.numpy())
+        assert rel_rms_err(dd.cpu().numpy(), dm.grad.numpy()) < 2e-5, rel_rms_err(dd.cpu().numpy(), dm.grad.numpy())
+        assert np.all(dd.cpu().numpy()[:, 0] == 0) and np.all(dd.cpu().numpy()[:, 24:] == 0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# whole network
+# ------------------------------------------------------------------------------------------------------------------------
+def _setup(T, encoders, B, seed, mask=None):
+    from spatialaudiogen_amd.model import SptAudioGen, SptAudioGenParams
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    from oracle.torch_ref import TorchRef
+    specs = variable_specs(encoders)
+    P = init_weights(specs, seed=seed, mode='test')
+    inp = synth_inputs(B, encoders, seed=1234 + seed)
+    r = rng(100 + seed)
+    target = (0.2 * r.normal(size=(B, 4800, 3))).astype(np.float32)
+    net = SptAudioGen(1, encoders=list(encoders), separation='unet_mask', params=SptAudioGenParams())
+    net.load_variables(P)
+    ref = TorchRef(P, encoders, dtype=T.float64)
+    return net, ref, P, inp, target
+
+
+def _grad_table(tr, grads_ref):
+    rows = []
+    for k, gr in grads_ref.items():
+        g = tr.grad(k).cpu().numpy()
+        rows.append((k, rel_rms_err(g, gr), rms(gr)))
+    return rows
+
+
+@pytest.mark.parametrize('encoders,B,seed', [(('audio',), 2, 3), (('audio', 'video'), 4, 0), (('audio', 'video', 'flow'), 2, 1)])
+def test_every_variable_gradient_matches_fp64_autograd(T, encoders, B, seed):
+    """dL/dvariable for every trainable variable (154 for audio+video) vs fp64 autograd of the independent torch-CPU graph.
+    Bar: relative RMS error <= 1e-3 per variable (fp32 arithmetic through 20 batch-norm layers), median <= 1e-4; the loss
+    itself to 1e-5 and the prediction to the forward's own bar."""
+    from spatialaudiogen_amd.train import Trainer
+    net, ref, P, inp, target = _setup(T, list(encoders), B, seed)
+    mask = np.ones((B, 4), np.float32)
+    mask[0, 2] = 0.0                                              # a WXY-only clip: no Z target (feeder.py:312-314)
+    loss_ref, grads_ref, pred_ref, ig = ref.loss_and_grads(inp['audio'], inp.get('video'), inp.get('flow'), target, mask[:, 1:],
+                                                           keep=('localization/coeffs', 'separation/deconv1'))
+    tr = Trainer(net, batch=B)
+    loss = tr.forward_backward(inp['audio'], inp.get('video'), inp.get('flow'), target, mask, update_moving=False)
+    T.cuda.synchronize()
+    assert rel_rms_err(tr.pred.cpu().numpy(), pred_ref) < 1e-3
+    assert abs(float(loss) - loss_ref) <= 1e-4 * abs(loss_ref), (float(loss), loss_ref)
+    # the two tensors the decoder's adjoint produces, before any contraction
+    dco = tr.buffer('t:dcoeffs').cpu().numpy().reshape(B, 3, 100)[:, :, :99].reshape(B, 3, 3, 33)
+    assert rel_rms_err(dco, ig['localization/coeffs']) < 1e-4, rel_rms_err(dco, ig['localization/coeffs'])
+    ddm = tr.buffer('t:ddmask').cpu().numpy().reshape(B, 31, 1024, 32)
+    ref_dm = np.transpose(ig['separation/deconv1'], (0, 2, 3, 1))[:, 40:71]
+    assert rel_rms_err(ddm, ref_dm) < 1e-4, rel_rms_err(ddm, ref_dm)
+    rows = _grad_table(tr, grads_ref)
+    bad = [(k, e, m) for k, e, m in rows if not (e <= 1e-3)]
+    errs = sorted(e for _, e, _ in rows)
+    report = '\n'.join('%-60s err %.2e  rms %.2e' % r_ for r_ in rows)
+    assert not bad, 'gradient mismatch in %d of %d variables\n%s' % (len(bad), len(rows), report)
+    assert errs[len(errs) // 2] <= 1e-4, report
+    print('\n[%s B=%d] gradient rel-RMS error: median %.2e  max %.2e (%s)' % ('+'.join(encoders), B, errs[len(errs) // 2], errs[-1],
+                                                                             max(rows, key=lambda t: t[1])[0]))
+
+
+def test_weight_gradients_do_not_depend_on_the_mfma_kernel(T):
+    """SAGEN_WGRAD_REF=1 routes every weight gradient through the plain one-thread-per-element kernel: same gradients."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_backward import _setup
+from spatialaudiogen_amd.train import Trainer
+net, ref, P, inp, target = _setup(torch, ['audio', 'video'], 2, 5)
+tr = Trainer(net, batch=2)
+tr.forward_backward(inp['audio'], inp.get('video'), None, target)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **{k.replace('/', '|'): tr.grad(k).cpu().numpy() for k in tr.opt.layout})
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    out = []
+    for ref_mode in (False, True):
+        fn = tempfile.mktemp(suffix='.npz')
+        env = dict(os.environ)
+        if ref_mode:
+            env['SAGEN_WGRAD_REF'] = '1'
+        subprocess.run([sys.executable, '-c', code % (root, os.path.join(root, 'tests')), fn], check=True, env=env, timeout=900)
+        out.append(dict(np.load(fn)))
+    for k in out[0]:
+        if k.endswith('weights'):
+            assert rel_rms_err(out[0][k], out[1][k]) < 5e-6, (k, rel_rms_err(out[0][k], out[1][k]))
+        else:
+            assert np.array_equal(out[0][k], out[1][k]), k
+
+
+def test_three_adam_steps_follow_the_fp64_trajectory(T):
+    """Trainer.step x3 (forward, loss, backward, fused Adam, filter re-pack) vs fp64 autograd + the oracle's TF-1.4 Adam."""
+    from oracle import np_oracle as O
+    from oracle.torch_ref import TorchRef
+    from spatialaudiogen_amd.train import Trainer
+    enc, B = ['audio', 'video'], 2
+    net, ref, P, inp, target = _setup(T, enc, B, 7)
+    tr = Trainer(net, batch=B, lr=1e-3, lr_iters=2, lr_decay=0.5)
+    state = {k: (np.asarray(v, np.float64), np.zeros(v.shape), np.zeros(v.shape)) for k, v in P.items() if '/moving_' not in k}
+    losses, losses_ref = [], []
+    for step in range(3):
+        loss, lr = tr.step(inp['audio'], inp.get('video'), None, target)
+        losses.append(float(loss))
+        cur = dict(P)
+        cur.update({k: v[0] for k, v in state.items()})
+        r = TorchRef(cur, enc, dtype=T.float64)
+        lref, g, _, _ = r.loss_and_grads(inp['audio'], inp.get('video'), None, target)
+        losses_ref.append(lref)
+        lr_ref = O.exponential_decay_staircase(1e-3, step, 2, 0.5)
+        assert lr == pytest.approx(lr_ref)
+        for k in state:
+            state[k] = O.adam_tf(state[k][0], g[k], state[k][1], state[k][2], step + 1, lr_ref)
+    assert np.allclose(losses, losses_ref, rtol=2e-3), (losses, losses_ref)
+    got = tr.variables()
+    # Adam normalises the step to ~lr per element whatever the gradient's size: compare the UPDATE (new - initial), which is what
+    # the step computed, and allow for sign flips of elements whose gradient is at rounding level
+    errs = []
+    for k in state:
+        upd = got[k].cpu().numpy().astype(np.float64) - np.asarray(P[k], np.float64)
+        upd_ref = state[k][0] - np.asarray(P[k], np.float64)
+        errs.append((k, rel_rms_err(upd, upd_ref)))
+    worst = max(errs, key=lambda t: t[1])
+    assert np.median([e for _, e in errs]) < 2e-2 and worst[1] < 0.2, worst
+    # BN moving averages moved towards the batch statistics (decay 0.99, three updates)
+    mm = got['video_encoder/conv1/conv/bn/moving_mean'].cpu().numpy()
+    assert np.abs(mm).max() > 0
