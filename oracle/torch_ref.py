@@ -56,6 +56,15 @@ class TorchRef(object):
         n = torch.arange(self.W, dtype=torch.float64)
         self.hann = (0.5 - 0.5 * torch.cos(2 * math.pi / self.W * n)).to(torch.float32).to(dtype)
         self.ends = {}
+        # optional {layer name: boolean NCHW / row mask}: ReLUs listed here are evaluated as x * mask instead of max(x, 0).  The
+        # gradient tests pass the masks of the DEVICE activations: a ReLU whose input is within rounding distance of 0 may switch
+        # differently in fp32 and fp64, and each such element changes its gradient by 100 % (a relative RMS error of
+        # sqrt(fraction switched), 1e-3..1e-2 in the 1.6M-element ResNet layers) - a property of the comparison, not of the backward
+        self.relu_masks = {}
+
+    def _relu(self, x, key):
+        m = self.relu_masks.get(key)
+        return F.relu(x) if m is None else x * torch.as_tensor(m).to(x.dtype)
 
     def stft(self, audio):                     # [B, 52799] -> [B,200,1024] complex (myutils.py:119-147)
         fr = audio.unfold(1, self.W, self.W // 4)[:, :200]
@@ -67,7 +76,7 @@ class TorchRef(object):
         def cbn(x, name, s, act):
             y = conv2d_tf(x, P[name + '/weights'], (s, s), 'SAME')
             y = bn_train(y, P[name + '/bn/gamma'], P[name + '/bn/beta'])
-            return F.relu(y) if act else y
+            return self._relu(y, name) if act else y
 
         x = cbn(x, scope + '/conv1/conv', 2, True)
         pt, pb = _same(x.shape[2], 3, 2)
@@ -81,13 +90,13 @@ class TorchRef(object):
                 sc = conv2d_tf(x, P[name + '/shortcut/weights'], (2, 2), 'SAME') if first else x
                 y = cbn(x, name + '/conv_1', s, True)
                 y = cbn(y, name + '/conv_2', 1, False)
-                x = F.relu(y + sc)
+                x = self._relu(y + sc, name)
                 self.ends[name] = x
         return x
 
     def fc(self, x, name, act=True):
         y = x @ self.P[name + '/weights'] + self.P[name + '/biases']
-        return F.relu(y) if act else y
+        return self._relu(y, name) if act else y
 
     @torch.no_grad()
     def forward(self, audio, video=None, flow=None):

@@ -137,6 +137,7 @@ static int repack_dgrad(sagen_ctx* c, hipStream_t s) {
 
 struct Bwd : Fwd {
     int cslot = 0;
+    bool split_ok = getenv("SAGEN_BWD_NOSPLIT") == nullptr;      // debugging: no split-K in the data-gradient contractions
     Bwd(sagen_ctx* ctx, hipStream_t st) { c = ctx; s = st; }
 
     float* grad(const std::string& v) { return c->grad_ptr[c->var_index.at(v)]; }
@@ -182,7 +183,7 @@ struct Bwd : Fwd {
         int Ho, Wo;
         IgemmDesc d = conv_desc(dy, H, W, Cout, Cout, c->p("pkd:" + name + "/weights"), 3, 3, 1, 1, true, Cin, dx, Cin, Ho, Wo);
         layer = "dgrad:" + name;
-        contract(d);
+        contract(d, 1, split_ok);
     }
     // conv with stride (sh, sw) and NO padding before (VALID, or TF SAME with pad_before = 0): dx = conv2d_transpose(dy) cropped to
     // [H, W], as a stride-1 conv over dy whose N index is (ry, rx, ci) with a depth-to-space epilogue
@@ -199,7 +200,7 @@ struct Bwd : Fwd {
         d.dsh = sh; d.dsw = sw; d.Cout = Cin; d.Hlim = H; d.Wlim = W;
         d.ldy = ldy; d.y_rstride = (long)W * ldy; d.y_bstride = (long)H * W * ldy;
         layer = "dgrad:" + name;
-        contract(d);
+        contract(d, 1, split_ok);
     }
     // fully_connected: dx[M][K] = dy[M][N] . W^T   (dy rows padded with zeros to a multiple of 4)
     void dgrad_fc(const std::string& name, const float* dy, int lddy, int M, int N, int K, float* dx, int lddx) {
@@ -210,7 +211,7 @@ struct Bwd : Fwd {
         d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = d.K; d.ldx = lddy; d.x_bstride = lddy;
         d.ntaps = 1; d.Cout = K; d.Hlim = 1; d.Wlim = 1; d.ldy = lddx; d.y_rstride = lddx; d.y_bstride = lddx;
         layer = "dgrad:" + name;
-        gemm(d);
+        gemm(d, 1, split_ok);
     }
     // y = act(x W + b) backward: weights (and, through `dx`, the input).  dy [M][N] with row stride lddy.
     void fc_bwd(const std::string& name, const float* x, int ldx, int M, int K, const float* dy, int lddy, int N, float* dx, int lddx) {
@@ -518,7 +519,13 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
 int sagen_train_get_buffer_impl(const sagen_ctx* c, const char* name, const float** data, size_t* n) {
     if (!c->tws) return fail(SAGEN_ERR_WORKSPACE, "no train workspace bound");
     auto it = c->tbufs.find(name);
-    if (it == c->tbufs.end()) return fail(SAGEN_ERR_SHAPE, "unknown train buffer %s", name);
+    if (it == c->tbufs.end()) {
+        auto jt = c->bufs.find(name);              // buffers of the forward's own workspace ("fcred", "y0", "bott", ...)
+        if (jt == c->bufs.end()) return fail(SAGEN_ERR_SHAPE, "unknown train buffer %s", name);
+        *data = c->ws + jt->second.off;
+        *n = jt->second.n;
+        return SAGEN_OK;
+    }
     *data = c->tws + it->second.off;
     *n = it->second.n;
     return SAGEN_OK;

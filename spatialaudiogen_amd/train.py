@@ -257,8 +257,11 @@ class Trainer(object):
         from ._lib import check
         data, n = C.c_void_p(), C.c_size_t()
         check(_lib.lib().sagen_train_get_buffer(self.ctx.handle, name.encode(), C.byref(data), C.byref(n)))
-        off = (data.value - self.train_ws.data_ptr()) // 4
-        return self.train_ws[off:off + n.value]
+        for ws in (self.train_ws, self.ctx.workspace):
+            off = (data.value - ws.data_ptr()) // 4
+            if 0 <= off and off + n.value <= ws.numel():
+                return ws[off:off + n.value]
+        raise RuntimeError('buffer %s lies outside the workspaces' % name)
 
     def variables(self):
         """Current values of every variable (checkpoint content, deploy.py:79 / train.py:223-225)."""
