@@ -14,6 +14,9 @@ all-reduce, RCCL, once at the end of the timed region).  Rank 0 prints ONE JSON 
     av    configs[1]  audio + video encoders, 32 windows per batch                      (default: the configuration the metric is quoted on)
     a     configs[0]  audio encoder only, deploy.py's batch of 10 windows               (the reference's CPU-runnable plumbing case, here on the GPU)
     avf   configs[2]  audio + video + flow encoders, 32 windows per batch
+    train configs[4]  train.py loop: audio + video encoders, batch 32 per GPU, one optimiser step per "step" = forward with retained
+                      activations + stft loss + full backward + gradient all-reduce over the ranks (RCCL, flat buckets) + fused Adam +
+                      filter re-pack; value = ambisonic seconds TRAINED per second (weak scaling)
     eval  configs[3]  YT-All stand-in: 1024 synthetic clips x 9 windows, batches of 16 cut from one global window order and dealt
                       whole to the ranks (spatialaudiogen_amd.evaluate.batch_shard), forward + on-device evaluation_ops per batch,
                       ONE all-reduce of the metric sums at the end; strong scaling (total work fixed); --steps caps the batches per rank
@@ -43,6 +46,9 @@ CONFIGS = {
                  workload='configs[3]: YT-All eval stand-in, 1024 synthetic clips x 9 windows (every 10th window of a 10 s clip), batches of '
                           '16 dealt whole to the ranks, forward + on-device evaluation metrics, one metric all-reduce'),
 }
+CONFIGS['train'] = dict(encoders=['audio', 'video'], batch=32, gflop=8.41, scaling='weak',
+                        workload='configs[4]: train.py loop, audio+video encoders, batch 32 x 0.1 s windows per GPU, Adam step (the reference '
+                                 'optimiser, myutils.py:220) with gradient all-reduce across the GPUs, synthetic batches')
 EVAL_CLIPS, EVAL_WINDOWS_PER_CLIP = 1024, 9
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 32 cycles / SIMD)
@@ -94,6 +100,163 @@ def cpu_baseline(P, inputs, budget_s, encoders, batch):
     }
 
 
+def cpu_baseline_train(P, inputs, target, budget_s, encoders, batch):
+    """One training iteration of the reference-equivalent CPU path: forward + stft loss + autograd backward of
+    oracle/torch_ref.py in fp32 on all host threads (the optimiser update is not included - it is noise next to the backward)."""
+    import torch
+    from oracle.torch_ref import TorchRef
+    threads = torch.get_num_threads()
+    ref = TorchRef(P, encoders, dtype=torch.float32)
+    a = (inputs['audio'], inputs.get('video'), inputs.get('flow'), target)
+    t0 = time.time()
+    ref.loss_and_grads(*a)
+    warm = time.time() - t0
+    times = []
+    t_start = time.time()
+    while len(times) < 1 or (time.time() - t_start < budget_s and len(times) < 10):
+        t0 = time.time()
+        ref.loss_and_grads(*a)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {'value': round(0.1 * batch / med, 3), 'unit': 'ambisonic-s/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d timed training iterations (forward + loss + autograd backward, no optimiser) of %d windows, same synthetic %s '
+                      'batch, fp32, median %.2f s/iteration, warm-up %.2f s; torch-CPU/oneDNN stand-in for the TF1 CPU path'
+                      % (len(times), batch, '+'.join(encoders), med, warm)}
+
+
+def main_train(args, cfg):
+    """--config train: BASELINE configs[4]."""
+    ENCODERS, BATCH = cfg['encoders'], cfg['batch']
+    import torch
+    import torch.distributed as dist
+    from spatialaudiogen_amd.model import SptAudioGen
+    from spatialaudiogen_amd.train import Trainer
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU implementation')
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    backend = os.environ.get('SAGEN_DIST_BACKEND', 'nccl')
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    P = init_weights(variable_specs(ENCODERS), seed=0, mode='bench')           # same replica on every rank
+    inp = synth_inputs(BATCH, ENCODERS, seed=1234 + rank)                      # every rank trains on its own windows
+    target = (inp['audio'][:, 24000:28800, :] * np.array([0.5, 0.25, -0.5], np.float32)).astype(np.float32)
+    net = SptAudioGen(1, encoders=ENCODERS, separation='unet_mask')
+    net.load_variables(P)
+    tr = Trainer(net, batch=BATCH, lr=1e-4, lr_iters=250000, lr_decay=0.5)     # train.py defaults
+    dev = [torch.as_tensor(inp[k]).cuda() if k in inp else None for k in ('audio', 'video', 'flow')] + [torch.as_tensor(target).cuda()]
+
+    # launch plan: tuned on rank 0, broadcast, so that every rank runs the same kernels
+    plan = []
+    if not args.no_autotune:
+        if args.plan_file and os.path.exists(args.plan_file):
+            plan = json.load(open(args.plan_file))['plan']
+        elif rank == 0:
+            plan = tr.autotune(*dev)
+            if args.plan_file:
+                json.dump({'batch': BATCH, 'encoders': ENCODERS, 'plan': plan}, open(args.plan_file, 'w'), indent=1)
+        if world > 1:
+            box = [plan]
+            dist.broadcast_object_list(box, src=0)
+            plan = box[0]
+        tr.load_plan_rows(plan)
+        got = sorted((l, t, k) for l, t, k, _ in tr.plan())
+        want = sorted((l, t if not l.endswith('#materialize') else '-', k) for l, t, k, _ in plan)
+        assert got == want, 'rank %d runs a different launch plan than rank 0' % rank
+        # the tuning step left meaningless gradients / optimiser state untouched (no apply): nothing to undo
+    torch.cuda.synchronize()
+
+    def step():
+        return tr.step(*dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, lr = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    last_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend != 'gloo' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps = args.steps
+    value = 0.1 * BATCH * world * steps / elapsed
+    ms_per_step = 1e3 * elapsed / max(steps, 1)
+
+    # per-launch HIP events of the native runtime over two more steps (forward + backward launches; the optimiser and the
+    # all-reduce are torch-side and appear only in the step time)
+    tr.profile_enable(True)
+    agg, by_phase = {}, {}
+    nprof = 2
+    for _ in range(nprof):
+        tr.forward_backward(*dev)
+        for k, layer, us, fl in tr.profile_report():
+            a = agg.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += us; a[2] += fl
+            ph = 'wgrad' if layer.startswith('wgrad:') else 'dgrad' if layer.startswith('dgrad:') else \
+                'bwd-elementwise' if (':' in layer.split('/')[0] or layer.endswith(':bwd')) else 'forward'
+            b = by_phase.setdefault(ph, [0.0, 0.0])
+            b[0] += us; b[1] += fl
+    tr.profile_enable(False)
+    total_us = sum(a[1] for a in agg.values())
+    total_fl = sum(a[2] for a in agg.values())
+    dom = max(agg, key=lambda k: agg[k][1])
+    n_l, us_l, fl_l = agg[dom]
+    achieved = fl_l / (us_l * 1e-6) / 1e12
+    b3 = dom.startswith('igemm3') or dom.startswith('conv3p')
+    peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
+    step_tflops = total_fl / nprof / (ms_per_step * 1e-3) / 1e12
+    roofline = {
+        'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+        'frac': round(achieved / peak, 4), 'traffic': None, 'traffic_source': None,
+        'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
+                       if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32): the weight-gradient kernel contracts over pixels, K-major operands'),
+        'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
+        'share_of_step_time': round(us_l / total_us, 3),
+        'phases_us_per_step': {k: round(v[0] / nprof, 1) for k, v in sorted(by_phase.items())},
+        'phases_tflops': {k: round(v[1] / (v[0] * 1e-6) / 1e12, 1) for k, v in sorted(by_phase.items()) if v[1] > 0},
+        'whole_step': {'achieved': round(step_tflops, 2), 'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                       'gflop_per_window_launched': round(total_fl / nprof / BATCH / 1e9, 2),
+                       'gflop_per_window_forward_needed_only': cfg['gflop'],
+                       'kernel_time_us_per_step': round(total_us / nprof, 1)},
+    }
+    result = {
+        'metric': 'ambisonic seconds trained/sec (0.1 s windows, 224x448 video; one Adam step per batch)',
+        'value': round(value, 2), 'unit': 'ambisonic-s/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (forward / data gradients: products on the bf16 matrix cores as a 3-way operand split, fp32-equivalent; weight '
+                 'gradients: exact fp32 MFMA; fp32 Adam state)',
+        'data': 'synthetic',
+        'config': {'workload': cfg['workload'], 'name': 'train', 'windows_per_gpu_per_step': BATCH,
+                   'windows_per_s': round(BATCH * world * steps / elapsed, 1), 'optimizer': 'Adam (lr 1e-4), fused over %d flat buckets' % len(tr.opt.params),
+                   'gradient_exchange': 'sum all-reduce of %d buckets (%.0f MB) per step over %d rank(s), %s' % (
+                       len(tr.opt.grads), sum(g.numel() for g in tr.opt.grads) * 4 / 1e6, world, backend if world > 1 else 'none'),
+                   'launch_plan': 'autotuned on rank 0 and broadcast (%d contractions)' % len(plan) if plan else 'shape heuristics',
+                   'weights': 'random init (Xavier / BN identity), same replica on every rank', 'last_loss': last_loss},
+        'roofline': roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline_train(P, inp, target, args.cpu_seconds, ENCODERS, BATCH)
+        cb['gpu_over_cpu'] = round(value / cb['value'], 1)
+        result['cpu_baseline'] = cb
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     cfg = CONFIGS[args.config]
@@ -105,6 +268,8 @@ def main():
                '--master-addr', '127.0.0.1', '--master-port', os.environ.get('MASTER_PORT', '29533'),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    if args.config == 'train':
+        return main_train(args, cfg)
 
     if args.in_flight > 1:
         # several batches in flight: each context stays on its caller's stream (the other batch is the overlap)

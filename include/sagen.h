@@ -245,6 +245,10 @@ int sagen_train_bind(sagen_ctx* ctx, const sagen_tensor* grads, int n_grads, con
                      void* train_workspace, size_t train_workspace_bytes, void* stream);
 int sagen_train_step(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
                      const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream);
+/* sagen_autotune for the training step: one step on these inputs in which every contraction (forward and data gradients) times
+ * its launch candidates; the plan is stored in the ctx.  The gradients it leaves behind are not meaningful.  Synchronises. */
+int sagen_train_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
+                         const float* mask, void* stream);
 /* named buffer of the train workspace (parity tests): e.g. "t:dcoeffs" [B*3][100], "t:ddmask" [B,31,1024,ntracks] (deconv1 output
  * rows 40..70), "t:dpred", "t:g:feat" (dL/d conv5_2) */
 int sagen_train_get_buffer(const sagen_ctx* ctx, const char* name, const float** data, size_t* n_floats);

@@ -73,6 +73,7 @@ SIGNATURES = {
     'sagen_train_workspace_bytes': (_SZ, [_P]),
     'sagen_train_bind': (C.c_int, [_P, C.POINTER(SagenTensor), _I, C.POINTER(SagenTensor), _I, _P, _SZ, _P]),
     'sagen_train_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'sagen_train_autotune': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'sagen_train_get_buffer': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_SZ)]),
     'sagen_wgrad_scratch_bytes': (_SZ, [_I] * 4),
     'sagen_wgrad': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),

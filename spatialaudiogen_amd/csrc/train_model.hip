@@ -469,7 +469,6 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
                           const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s) {
     if (!c || !audio || !target) return fail(SAGEN_ERR_NULL, "sagen_train_step: null argument");
     if (!c->train_ready) return fail(SAGEN_ERR_WORKSPACE, "sagen_train_step: call sagen_train_bind first");
-    if (c->tuning) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_train_step during autotune");
     int rc = sagen_repack_impl(c, s);                  // the optimiser updated the variables in place
     if (!rc) rc = repack_dgrad(c, s);
     if (rc) return rc;
@@ -528,5 +527,24 @@ int sagen_train_get_buffer_impl(const sagen_ctx* c, const char* name, const floa
     }
     *data = c->tws + it->second.off;
     *n = it->second.n;
+    return SAGEN_OK;
+}
+
+// Times every (tile, split-K) candidate of every contraction of the step - the forward's and the data gradients' - on these
+// inputs and stores the plan (same mechanism as sagen_autotune).  The gradients this call leaves behind are not meaningful
+// (candidates overwrite each other's outputs; the L2-cooling memset reuses the mask buffer).
+int sagen_train_autotune_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
+                              const float* mask, hipStream_t s) {
+    if (!c) return fail(SAGEN_ERR_NULL, "sagen_train_autotune: null ctx");
+    if (getenv("SAGEN_NO_AUTOTUNE")) return SAGEN_OK;
+    if (!c->tune_e0) {
+        SAGEN_HIP_CHECK(hipEventCreate(&c->tune_e0));
+        SAGEN_HIP_CHECK(hipEventCreate(&c->tune_e1));
+    }
+    c->tuning = true;
+    const int rc = sagen_train_step_impl(c, audio, video, flow, target, mask, nullptr, nullptr, 0, s);
+    c->tuning = false;
+    if (rc) return rc;
+    SAGEN_HIP_CHECK(hipStreamSynchronize(s));
     return SAGEN_OK;
 }

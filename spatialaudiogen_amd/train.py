@@ -268,3 +268,287 @@ class Trainer(object):
         out = OrderedDict((k, v.clone()) for k, v in self.opt.variables().items())
         out.update((k, v.clone()) for k, v in self.moving.items())
         return out
+
+    # ---- launch plan / per-launch profile of the training context (same native mechanism as SptAudioGen.autotune) ----
+    def autotune(self, audio, video, flow, target, mask=None):
+        """Time every (tile, split-K) candidate of every contraction of the step - forward and data gradients - on these inputs
+        and keep the fastest.  The gradients this call leaves behind are not meaningful.  Returns the plan."""
+        import torch
+        from . import _lib
+        from ._lib import check
+        from .definitions import VIDEO, FLOW
+        a = self._prep(audio, (52799, 1))
+        v = self._prep(video, (1, 224, 448, 3)) if VIDEO in self.net.encoders else None
+        f = self._prep(flow, (1, 224, 448, 3)) if FLOW in self.net.encoders else None
+        t = self._prep(target, (4800, 3))
+        mk = channel_mask(mask, self.batch, self.device)
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(_lib.lib().sagen_train_autotune(self.ctx.handle, p(a), p(v), p(f), p(t), p(mk), stream))
+        return self.plan()
+
+    def plan(self):
+        from . import _lib
+        from ._lib import check
+        buf = C.create_string_buffer(1 << 17)
+        n = _lib.lib().sagen_plan_describe(self.ctx.handle, buf, len(buf))
+        if n < 0:
+            check(n)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            layer, tile, sk, us = line.split('\t')
+            rows.append((layer, tile, int(sk), float(us)))
+        return rows
+
+    def plan_set(self, layer, tile, splitk):
+        from . import _lib
+        from ._lib import check
+        check(_lib.lib().sagen_plan_set(self.ctx.handle, layer.encode(), max(int(tile), 0), int(splitk)))
+
+    def load_plan_rows(self, rows):
+        from .model import SptAudioGen
+        names = SptAudioGen.tile_names()
+        for layer, tile, sk, _ in rows:
+            if layer.endswith('#materialize'):
+                self.plan_set(layer, 0, sk)
+            else:
+                self.plan_set(layer, names.index(tile) if tile in names else 0, max(sk, 1))
+
+    def profile_enable(self, on=True):
+        from . import _lib
+        from ._lib import check
+        check(_lib.lib().sagen_profile_enable(self.ctx.handle, int(on)))
+
+    def profile_report(self):
+        """[(kernel, layer, microseconds, flops)] for every launch of the last step (forward + backward)."""
+        from . import _lib
+        from ._lib import check
+        buf = C.create_string_buffer(1 << 19)
+        n = _lib.lib().sagen_profile_report(self.ctx.handle, buf, len(buf))
+        if n < 0:
+            check(n)
+        rows = []
+        for line in buf.value.decode().splitlines():
+            k, layer, us, fl = line.split('\t')
+            rows.append((k, layer, float(us), float(fl)))
+        return rows
+
+    # ---- checkpoints (tf.train.Saver of train.py:176, 223-225, 234; restored by --resume, train.py:194-200) ----
+    def state_dict(self):
+        """Everything tf.train.Saver would write: variables, BN moving averages, Adam slots (`<var>/Adam`, `<var>/Adam_1`: the
+        `with tf.variable_scope('optimization') and tf.control_dependencies(..)` of train.py:148 enters only the second context, so
+        the slots carry no scope prefix), `beta1_power`, `beta2_power` and the global `step`."""
+        out = OrderedDict()
+        for k in self.opt.layout:
+            out[k] = self.opt.view('params', k).cpu().numpy()
+            out[k + '/Adam'] = self.opt.view('m', k).cpu().numpy()
+            out[k + '/Adam_1'] = self.opt.view('v', k).cpu().numpy()
+        for k, v in self.moving.items():
+            out[k] = v.cpu().numpy()
+        out['step'] = np.asarray(self.opt.step, np.int32)
+        out['beta1_power'] = np.asarray(ADAM_BETA1 ** (self.opt.step + 1), np.float32)     # TF stores beta^t for the NEXT application
+        out['beta2_power'] = np.asarray(ADAM_BETA2 ** (self.opt.step + 1), np.float32)
+        return out
+
+    def load_state_dict(self, state):
+        import torch
+        for k in self.opt.layout:
+            for which, sfx in (('params', ''), ('m', '/Adam'), ('v', '/Adam_1')):
+                if k + sfx in state:
+                    self.opt.view(which, k).copy_(torch.as_tensor(np.asarray(state[k + sfx], np.float32)))
+                elif not sfx:
+                    raise KeyError('variable %s missing from the checkpoint' % k)
+        for k in self.moving:
+            if k in state:
+                self.moving[k].copy_(torch.as_tensor(np.asarray(state[k], np.float32)))
+        self.opt.step = int(np.asarray(state.get('step', 0)))
+
+    def save(self, model_dir, global_step=None):
+        from .checkpoint import save_checkpoint
+        prefix = os.path.join(model_dir, 'model.ckpt' + ('-%d' % global_step if global_step is not None else ''))
+        save_checkpoint(prefix, self.state_dict())
+        return prefix
+
+    def restore(self, model_dir):
+        """tf.train.latest_checkpoint + saver.restore (train.py:196-200); returns the restored global step (0 if none)."""
+        from .checkpoint import latest_checkpoint, load_checkpoint
+        ckpt = latest_checkpoint(model_dir)
+        if not ckpt:
+            return 0
+        self.load_state_dict(load_checkpoint(ckpt))
+        return self.opt.step
+
+
+import os  # noqa: E402
+
+
+def save_params(args, model_dir):
+    """myutils.save_params (myutils.py:28-31): `key: value` lines, read back by deploy.load_params / myutils.load_params."""
+    with open(os.path.join(model_dir, 'train-params.txt'), 'w') as f:
+        for k, v in sorted(vars(args).items()):
+            f.write('{}: {}\n'.format(k, v))
+
+
+def synthetic_batches(encoders, batch, seed=0, pool=2):
+    """Endless synthetic batches of SURVEY 8(d): a small pool of distinct batches, cycled.  The target is the crop of the mono
+    context scaled per channel (a learnable fixed mixing)."""
+    from .weights import synth_inputs
+    items = []
+    for i in range(pool):
+        inp = synth_inputs(batch, encoders, seed=seed + i)
+        tgt = (inp['audio'][:, 24000:28800, :] * np.array([0.5, 0.25, -0.5], np.float32)).astype(np.float32)
+        items.append((inp['audio'], inp.get('video'), inp.get('flow'), tgt, np.ones((batch, 4), np.float32)))
+    i = 0
+    while True:
+        yield items[i % pool]
+        i += 1
+
+
+def folder_batches(db_dir, ids, params, batch, layouts=None, seed=0, samples_per_clip=5):
+    """The training feeder (feeder.py:372-407 with for_eval=False): clips in shuffled order for ever, per clip a SampleReader with
+    shuffled windows, silence skipping and random rotations about z, `samples_per_clip` (NUM_SAMPLING = 5) windows of each; the
+    sample stream is cut into batches.  Yields (audio [B,n,1], video, flow, target [B,4800,3], channel mask [B,4])."""
+    import random
+    from .feeder import SampleReader, img_prep_fcn
+    from .definitions import VIDEO, FLOW
+    rnd = random.Random(seed)
+    thr = 0.01 if 'REC-Street' in str(db_dir) else 0.2                     # feeder.py:312
+    ss, t = int(params.audio_rate * params.context) // 2, int(params.audio_rate * 0.1)
+    buf = []
+    while True:
+        order = list(ids)
+        rnd.shuffle(order)
+        for yid in order:
+            reader = SampleReader(os.path.join(db_dir, yid), ambi_order=params.ambi_order, audio_rate=params.audio_rate,
+                                  video_rate=params.video_rate, context=params.context, duration=0.1,
+                                  return_video=VIDEO in params.encoders, img_prep=img_prep_fcn(), return_flow=FLOW in params.encoders,
+                                  skip_silence_thr=thr, shuffle=True, random_rotations=True)
+            for smp in reader.loop_chunks(samples_per_clip):
+                smp['mask'] = np.asarray((layouts or {}).get(yid, np.ones(4)), np.float32)
+                buf.append(smp)
+                if len(buf) == batch:
+                    amb = np.stack([s_['ambix'] for s_ in buf], 0).astype(np.float32)
+                    st = lambda k: np.stack([s_[k] for s_ in buf], 0).astype(np.float32) if k in buf[0] else None
+                    yield (amb[:, :, :1], st('video'), st('flow'), np.ascontiguousarray(amb[:, ss:ss + t, 1:]),
+                           np.stack([s_['mask'] for s_ in buf], 0))       # train.py:107-111: input W, target Y,Z,X of the centre window
+                    buf = []
+
+
+def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_every=5000, log=print):
+    """The loop of train.py:202-234: one optimiser step per iteration; every `log_every` steps the loss is read back and a NaN
+    aborts the run (train.py:212-213); a checkpoint every `ckpt_every` steps (train.py:223-225) and one at exit (train.py:234),
+    also when the loop dies.  Returns the list of logged (step, loss, lr)."""
+    import math
+    import time
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    history = []
+    t_last, n_last = time.time(), init_step
+    step = init_step
+    try:
+        for step in range(init_step, n_iters):
+            audio, video, flow, target, mask = next(batches)
+            loss, lr = tr.step(audio, video, flow, target, mask)
+            if step % log_every == 0:
+                lv = float(loss)                                            # the only host synchronisation of the loop
+                if math.isnan(lv):
+                    raise ValueError('Training produced a NaN metric or loss.')
+                now = time.time()
+                rate = tr.batch * max(step - n_last, 1) / max(now - t_last, 1e-9)
+                t_last, n_last = now, step
+                history.append((step, lv, lr))
+                if rank == 0:
+                    log('TRAIN | step %d | stft/mse %.6g | lr %.3g | %.1f samples/s per GPU' % (step, lv, lr, rate))
+            if step % ckpt_every == 0 and step != 0 and rank == 0:
+                tr.save(model_dir, global_step=tr.opt.step)
+                log('=' * 60 + '\nCheckpoint saved\n' + '=' * 60)
+    finally:
+        torch.cuda.synchronize()
+        if rank == 0:
+            log('End of training.\nSaving model.')
+            tr.save(model_dir)
+    return history
+
+
+def parse_arguments(argv=None):
+    """The CLI of train.py:15-59 (same option names and defaults), plus --synthetic for runs without a dataset."""
+    import argparse
+    from .definitions import ENCODERS, SEPARATION, FREQ_MASK, NUM_SEP_TRACKS_DEF, SEP_FFT_WINDOW_DEF, CTX_FEATS_FCUNITS_DEF, \
+        SEP_FREQ_MASK_FCUNITS_DEF, LOC_FCUNITS_DEF
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('db_dir', help='Directory containing db ("synthetic" with --synthetic).')
+    ap.add_argument('model_dir', help='Directory to store model.')
+    ap.add_argument('--subset_fn', default='')
+    ap.add_argument('--encoders', nargs='*', type=str.lower, choices=ENCODERS, default=['audio', 'flow', 'video'])
+    ap.add_argument('--separation', type=str.lower, default=FREQ_MASK, choices=SEPARATION)
+    ap.add_argument('--ambi_order', type=int, default=1)
+    ap.add_argument('--audio_rate', type=int, default=48000)
+    ap.add_argument('--video_rate', type=int, default=10)
+    ap.add_argument('--context', type=float, default=1.0)
+    ap.add_argument('--sample_dur', type=float, default=0.1)
+    ap.add_argument('--n_iters', type=int, default=1000000)
+    ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--lr_decay', type=float, default=0.5)
+    ap.add_argument('--lr_iters', type=int, default=250000)
+    ap.add_argument('--batch_size', type=int, default=32)
+    ap.add_argument('--resume', action='store_true')
+    ap.add_argument('--num_sep_tracks', default=NUM_SEP_TRACKS_DEF, type=int)
+    ap.add_argument('--fft_window', default=SEP_FFT_WINDOW_DEF, type=float)
+    ap.add_argument('--context_units', default=CTX_FEATS_FCUNITS_DEF, nargs='+', type=int)
+    ap.add_argument('--freq_mask_units', default=SEP_FREQ_MASK_FCUNITS_DEF, nargs='*', type=int)
+    ap.add_argument('--loc_units', default=LOC_FCUNITS_DEF, nargs='+', type=int)
+    ap.add_argument('--gpu', type=int, default=0)
+    ap.add_argument('--synthetic', action='store_true', help='synthetic inputs / targets instead of a dataset folder')
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args(argv)
+    if len(args.subset_fn) == 0:
+        args.subset_fn = None
+    if args.resume and not os.path.isfile(os.path.join(args.model_dir, 'train-params.txt')):
+        args.resume = False
+    return args
+
+
+def main(argv=None):
+    """train.py:62-236 on the HIP path.  One process per GPU (torchrun): every rank holds a replica, draws its own batches and the
+    gradient buckets are summed over the ranks (RCCL) before the fused Adam step."""
+    import torch
+    from .deploy import load_params
+    from .dist import init_process_group
+    from .model import SptAudioGen, SptAudioGenParams
+    from .weights import init_weights
+    from .evaluate import read_layouts
+    args = parse_arguments(argv)
+    rank, world = init_process_group()
+    if torch.cuda.is_available():
+        torch.cuda.set_device((int(os.environ.get('LOCAL_RANK', args.gpu))) % torch.cuda.device_count())
+    os.makedirs(args.model_dir, exist_ok=True)
+    if args.resume:
+        prm = load_params(args.model_dir)
+        for k in ('encoders', 'separation', 'ambi_order', 'audio_rate', 'video_rate', 'context', 'sample_dur'):
+            setattr(args, k, getattr(prm, k))
+    elif rank == 0:
+        save_params(args, args.model_dir)
+    args.encoders = sorted(args.encoders)
+    net = SptAudioGen(args.ambi_order, audio_rate=args.audio_rate, video_rate=args.video_rate, context=args.context,
+                      sample_duration=args.sample_dur, encoders=list(args.encoders), separation=args.separation,
+                      params=SptAudioGenParams(sep_num_tracks=args.num_sep_tracks, ctx_feats_fc_units=args.context_units,
+                                               loc_fc_units=args.loc_units, sep_freq_mask_fc_units=args.freq_mask_units,
+                                               sep_fft_window=args.fft_window))
+    # initialisers of the reference (core.py:13,34; fc3 ~ N(0, 0.001^2), model.py:255); the same replica on every rank
+    P = init_weights(net.variable_specs(), seed=args.seed, mode='bench', fc3_std=0.001)
+    tr = Trainer(net, batch=args.batch_size, lr=args.lr, lr_iters=args.lr_iters, lr_decay=args.lr_decay, variables=P)
+    init_step = tr.restore(args.model_dir) if args.resume else 0
+    if args.synthetic:
+        batches = synthetic_batches(args.encoders, args.batch_size, seed=1234 + rank)
+    else:
+        ids = [l.strip() for l in open(args.subset_fn)] if args.subset_fn else sorted(os.listdir(args.db_dir))
+        ids = [i for i in ids if i and os.path.isdir(os.path.join(args.db_dir, i))]
+        layouts = read_layouts(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'meta', 'audio_layouts.txt'))
+        from .feeder import BatchPrefetcher
+        batches = iter(BatchPrefetcher(folder_batches(args.db_dir, ids, args, args.batch_size, layouts, seed=args.seed + rank), depth=4))
+    train_loop(tr, batches, args.model_dir, args.n_iters, init_step)
+
+
+if __name__ == '__main__':
+    main()

@@ -62,3 +62,19 @@ def test_bench_eval_config_two_ranks_match_one_rank():
     for k in ('stft', 'lsd', 'mse', 'snr'):
         for a, b in zip(full1['eval_metric_means'][k], full2['eval_metric_means'][k]):
             assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (k, a, b)
+
+
+def test_bench_train_config_line_and_two_ranks():
+    """configs[4]: one Adam step per `step`; the line carries its own roofline (dominant kernel of forward + backward) and phase
+    split; two ranks on this GPU (gloo standing in for RCCL) exchange the gradient buckets and print one line."""
+    ensure_lib()
+    r = _run(['--config', 'train', '--steps', '3'] + FAST)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in r, k
+    assert r['config']['name'] == 'train' and r['config']['workload'].startswith('configs[4]') and r['value'] > 0
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(r['roofline'])
+    ph = r['roofline']['phases_us_per_step']
+    assert ph['wgrad'] > 0 and ph['dgrad'] > 0 and ph['forward'] > 0
+    assert r['config']['last_loss'] == r['config']['last_loss']            # not NaN
+    two = _run(['--config', 'train', '--steps', '2'] + FAST, world=2)
+    assert two['n_gpus'] == 2 and two['value'] > 0 and 'gloo' in two['config']['gradient_exchange']

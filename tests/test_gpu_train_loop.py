@@ -1,0 +1,117 @@
+"""The training driver on the device (spatialaudiogen_amd/train.py; reference train.py:137-236): the loop with its NaN guard and
+checkpoints, --resume through the TF tensor-bundle writer / reader, BN moving-average updates, and the two-rank gradient exchange
+(gloo standing in for RCCL on one GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import ensure_lib, rel_rms_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    assert torch.cuda.is_available()
+    ensure_lib()
+    return torch
+
+
+def _trainer(T, enc=('audio', 'video'), B=2, seed=0, **kw):
+    from spatialaudiogen_amd.model import SptAudioGen
+    from spatialaudiogen_amd.train import Trainer
+    from spatialaudiogen_amd.weights import init_weights
+    net = SptAudioGen(1, encoders=list(enc), separation='unet_mask')
+    P = init_weights(net.variable_specs(), seed=seed, mode='bench', fc3_std=0.05)
+    return Trainer(net, batch=B, variables=P, **kw), P
+
+
+def test_loss_decreases_and_resume_is_bit_identical(T, tmp_path):
+    """6 steps in one go == 3 steps, checkpoint (tensor bundle on disk), a NEW trainer restored from it, 3 more steps - bit for bit
+    (variables, Adam slots, step counter, moving averages all travel through the checkpoint); the loss goes down."""
+    from spatialaudiogen_amd.train import synthetic_batches, train_loop
+    enc, B = ['audio', 'video'], 2
+    d1, d2 = str(tmp_path / 'a'), str(tmp_path / 'b')
+    os.makedirs(d1); os.makedirs(d2)
+    logs = []
+    tr, _ = _trainer(T, enc, B, lr=2e-4)
+    h = train_loop(tr, synthetic_batches(enc, B, seed=5, pool=1), d1, 6, log_every=1, ckpt_every=1000, log=logs.append)
+    assert len(h) == 6 and h[-1][1] < h[0][1], h                       # same batch every step: Adam must reduce the loss
+    full = tr.state_dict()
+    tr2, _ = _trainer(T, enc, B, lr=2e-4)
+    train_loop(tr2, synthetic_batches(enc, B, seed=5, pool=1), d2, 3, log_every=1, log=logs.append)
+    assert os.path.exists(os.path.join(d2, 'model.ckpt.index')) and os.path.exists(os.path.join(d2, 'checkpoint'))
+    tr3, _ = _trainer(T, enc, B, seed=99, lr=2e-4)                     # different initial weights: everything must come from the checkpoint
+    assert tr3.restore(d2) == 3
+    train_loop(tr3, synthetic_batches(enc, B, seed=5, pool=1), d2, 6, init_step=3, log_every=1, log=logs.append)
+    resumed = tr3.state_dict()
+    assert set(resumed) == set(full)
+    for k in full:
+        assert np.array_equal(np.asarray(full[k]), np.asarray(resumed[k])), k
+    mm = full['video_encoder/conv2_1/conv_1/bn/moving_mean']
+    assert np.abs(mm).max() > 0 and int(full['step']) == 6
+
+
+def test_nan_guard_stops_the_loop_and_still_saves(T, tmp_path):
+    from spatialaudiogen_amd.train import synthetic_batches, train_loop
+
+    def poisoned():
+        for i, b in enumerate(synthetic_batches(['audio'], 2, seed=1, pool=1)):
+            if i == 2:
+                a = b[0].copy(); a[0, 100, 0] = np.nan
+                b = (a,) + b[1:]
+            yield b
+    tr, _ = _trainer(T, ('audio',), 2)
+    with pytest.raises(ValueError, match='NaN'):
+        train_loop(tr, poisoned(), str(tmp_path), 10, log_every=1, log=lambda *_: None)
+    assert os.path.exists(os.path.join(str(tmp_path), 'model.ckpt.index'))          # train.py:229-234: saved in `finally`
+
+
+CHILD = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_train_loop import _trainer
+from spatialaudiogen_amd.dist import init_process_group
+from spatialaudiogen_amd.train import synthetic_batches
+rank, world = init_process_group()
+tr, _ = _trainer(torch, ('audio', 'video'), 2, lr=1e-4)
+b = synthetic_batches(['audio', 'video'], 2, seed=7 + (rank if os.environ.get('DIFFERENT_DATA') else 0), pool=1)
+for _ in range(2):
+    tr.step(*next(b))
+torch.cuda.synchronize()
+if rank == 0:
+    np.savez(sys.argv[1], **{k.replace('/', '|'): v.cpu().numpy() for k, v in tr.variables().items()})
+'''
+
+
+def _run_ranks(world, out, extra_env=None):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(extra_env or {})
+        if world > 1:
+            env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SAGEN_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, '-c', CHILD % (ROOT, os.path.join(ROOT, 'tests')), out], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+    return dict(np.load(out))
+
+
+def test_two_ranks_with_the_same_batches_equal_one_rank(T, tmp_path):
+    """Gradient exchange: sum all-reduce of the flat buckets, 1/world folded into Adam.  Two ranks that draw the SAME batches
+    must land on exactly the single-rank parameters (x + x is exact, 0.5 (2x) is exact); with different batches they must not."""
+    one = _run_ranks(1, str(tmp_path / 'one.npz'))
+    two = _run_ranks(2, str(tmp_path / 'two.npz'))
+    for k in one:
+        assert np.array_equal(one[k], two[k]), k
+    diff = _run_ranks(2, str(tmp_path / 'diff.npz'), {'DIFFERENT_DATA': '1'})
+    assert rel_rms_err(diff['separation|deconv1|weights'], one['separation|deconv1|weights']) > 1e-9
