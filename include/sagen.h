@@ -269,7 +269,8 @@ int sagen_conv2d_bwd_data(const float* dy, int batch, int hout, int wout, int co
                           int sh, int sw, int padding, int h, int w, float* dx, void* scratch, size_t scratch_bytes, void* stream);
 /* contrib batch_norm (training mode) backward: dz = (ga + gb) * (act > 0) (gb, act nullable) is the gradient at the BN output;
  * bn_stats = the accumulators sagen_conv2d filled for the raw conv output y.  dy = gradient at y; dz (nullable) = the masked
- * gradient itself; dgamma / dbeta [C].  scratch: 2*C doubles, 8-byte aligned. */
+ * gradient itself; dgamma / dbeta [C].  scratch: sagen_bn_bwd_scratch_bytes(c) bytes, 16-byte aligned. */
+size_t sagen_bn_bwd_scratch_bytes(int c);
 int sagen_bn_bwd(const float* ga, const float* gb, const float* act, const float* y, const float* bn_stats, const float* gamma,
                  const float* beta, float eps, int64_t n_pixels, int c, float* dy, float* dz, float* dgamma, float* dbeta,
                  void* scratch, size_t scratch_bytes, void* stream);

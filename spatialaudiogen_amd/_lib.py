@@ -79,6 +79,7 @@ SIGNATURES = {
     'sagen_wgrad': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     'sagen_conv2d_bwd_data_scratch_bytes': (_SZ, [_I] * 6),
     'sagen_conv2d_bwd_data': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
+    'sagen_bn_bwd_scratch_bytes': (_SZ, [_I]),
     'sagen_bn_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I64, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     'sagen_maxpool3x3s2_bwd': (C.c_int, [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'sagen_mask_istft_mix_bwd_scratch_bytes': (_SZ, [_I, _I]),

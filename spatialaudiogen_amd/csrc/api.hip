@@ -463,6 +463,8 @@ int sagen_conv2d_bwd_data(const float* dy, int batch, int hout, int wout, int co
     });
 }
 
+size_t sagen_bn_bwd_scratch_bytes(int c) { return align_up((size_t)2 * c * sizeof(double), 256) + reduce_scratch_floats(c) * sizeof(float); }
+
 /* bn_stats = the fp64 (sum, sumsq) accumulators sagen_conv2d filled for the raw conv output y */
 int sagen_bn_bwd(const float* ga, const float* gb, const float* act, const float* y, const float* bn_stats, const float* gamma,
                  const float* beta, float eps, int64_t n_pixels, int c, float* dy, float* dz, float* dgamma, float* dbeta,
@@ -470,11 +472,11 @@ int sagen_bn_bwd(const float* ga, const float* gb, const float* act, const float
     return guarded([&]() -> int {
         hipStream_t s = (hipStream_t)stream;
         if (!ga || !y || !bn_stats || !gamma || !beta || !dy || !scratch) return fail(SAGEN_ERR_NULL, "sagen_bn_bwd: null argument");
-        if (scratch_bytes < (size_t)2 * c * sizeof(double) || ((uintptr_t)scratch) % 8) return fail(SAGEN_ERR_WORKSPACE, "sagen_bn_bwd: scratch too small / unaligned");
+        if (scratch_bytes < sagen_bn_bwd_scratch_bytes(c) || ((uintptr_t)scratch) % 16) return fail(SAGEN_ERR_WORKSPACE, "sagen_bn_bwd: scratch too small / unaligned");
         BnRef bn;
         bn.acc = (const double*)bn_stats; bn.gamma = gamma; bn.beta = beta; bn.inv_count = 1.0 / (double)n_pixels; bn.eps = eps;
-        SAGEN_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)2 * c * sizeof(double), s));
-        int rc = bn_bwd_reduce_launch(ga, gb, act, y, bn, n_pixels, c, (double*)scratch, s);
+        float* part = (float*)((char*)scratch + align_up((size_t)2 * c * sizeof(double), 256));
+        int rc = bn_bwd_reduce_launch(ga, gb, act, y, bn, n_pixels, c, (double*)scratch, part, s);
         if (rc) return rc;
         return bn_bwd_apply_launch(ga, gb, act, y, bn, (const double*)scratch, n_pixels, c, dy, dz, dgamma, dbeta, s);
     });

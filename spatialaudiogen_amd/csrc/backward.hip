@@ -23,43 +23,65 @@ static int aligned_grid(long n4, int C4) {
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// per-channel block reduction of `nv` float4 partials per thread -> fp64 atomics.  Requires every thread of the block to call.
-// fast path: 256 % C4 == 0 (thread t owns channels 4*(t % C4)); otherwise per-thread atomics (tiny tensors only).
+// Per-channel sums without atomics: every workgroup reduces its threads' float4 partials through LDS and writes ONE row of
+// per-channel partials, part[block][NV][C]; partials_finish_kernel then adds the rows in a fixed order in fp64 (deterministic,
+// and no same-address atomic chains: 4096 workgroups x 128 fp64 atomics on 128 addresses took 300 us per batch-norm layer).
+// Requires 256 % C4 == 0 (thread t owns channels 4*(t % C4)).
+constexpr int RED_MAX_BLOCKS = 1024;
 template <int NV>
-__device__ __forceinline__ void channel_reduce(const float4 (&v)[NV], int C4, int c4, double* acc, int C) {
+__device__ __forceinline__ void channel_partials(const float4 (&v)[NV], int C4, float* part) {
     __shared__ float4 red[NV][256];
     const int tid = threadIdx.x;
-    if (256 % C4 == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) red[k][tid] = v[k];
-        __syncthreads();
-        if (tid < C4) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                float4 s = red[k][tid];
-                for (int t = tid + C4; t < 256; t += C4) s = add4(s, red[k][t]);
-                double* a = acc + (long)k * C + 4 * tid;
-                atomicAdd(a + 0, (double)s.x); atomicAdd(a + 1, (double)s.y); atomicAdd(a + 2, (double)s.z); atomicAdd(a + 3, (double)s.w);
-            }
-        }
-    } else {
+    for (int k = 0; k < NV; ++k) red[k][tid] = v[k];
+    __syncthreads();
+    if (tid < C4) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            double* a = acc + (long)k * C + 4 * c4;
-            if (4 * c4 + 0 < C) atomicAdd(a + 0, (double)v[k].x);
-            if (4 * c4 + 1 < C) atomicAdd(a + 1, (double)v[k].y);
-            if (4 * c4 + 2 < C) atomicAdd(a + 2, (double)v[k].z);
-            if (4 * c4 + 3 < C) atomicAdd(a + 3, (double)v[k].w);
+            float4 s = red[k][tid];
+            for (int t = tid + C4; t < 256; t += C4) s = add4(s, red[k][t]);
+            *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * NV + k) * (4 * C4) + 4 * tid) = s;
         }
     }
 }
+
+// acc[i] = sum_b part[b][i] (fp64), i < n: 32 columns x 8 row slices per workgroup
+__global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ part, int nblocks, int n, double* __restrict__ acc) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
+    double s = 0.0;
+    if (i < n)
+        for (int b = sl; b < nblocks; b += 8) s += (double)part[(size_t)b * n + i];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        acc[i] = t;
+    }
+}
+
+static int reduce_grid(long n4, int C4) {
+    long g = std::min<long>(cdiv(n4, 256 * 4), RED_MAX_BLOCKS);
+    g = std::max<long>(g, 1);
+    if ((g * 256) % C4) {
+        long a = 256, b = C4;
+        while (b) { const long t = a % b; a = b; b = t; }
+        const long unit = C4 / a;
+        g = std::max<long>(unit, g / unit * unit);
+    }
+    return (int)g;
+}
+size_t reduce_scratch_floats(int C) { return (size_t)RED_MAX_BLOCKS * 2 * ((C + 3) / 4 * 4); }
 
 // -----------------------------------------------------------------------------------------
 // dy = (ga + gb) * (act > 0)  [+ per-channel sum of dy = the bias gradient of tf.nn.bias_add, core.py:28]
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ ga, int lda, const float* __restrict__ gb, int ldb,
                                                        const float* __restrict__ act, int ldact, float* __restrict__ dy, int lddy,
-                                                       long n4, int C4, double* __restrict__ colsum, int C) {
+                                                       long n4, int C4, double* __restrict__ colsum, int C, float* __restrict__ part) {
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 sum[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -73,11 +95,17 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
         if (dy) *reinterpret_cast<float4*>(dy + row * lddy + 4 * c4) = v;
         sum[0] = add4(sum[0], v);
     }
-    if (colsum) channel_reduce<1>(sum, C4, c4, colsum, C);
+    if (part) channel_partials<1>(sum, C4, part);
+    else if (colsum) {                       // odd widths (tiny tensors only): one fp64 atomic per thread and channel
+        const float vv[4] = {sum[0].x, sum[0].y, sum[0].z, sum[0].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * c4 + k < C) atomicAdd(colsum + 4 * c4 + k, (double)vv[k]);
+    }
 }
 
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
-                    int C, double* colsum, hipStream_t s) {
+                    int C, double* colsum, float* scratch, hipStream_t s) {
     if (!ga || (!dy && !colsum)) return fail(SAGEN_ERR_NULL, "relu_bwd: null argument");
     const int Cp = (C + 3) / 4 * 4;
     if (lda % 4 || (gb && ldb % 4) || (act && ldact % 4) || (dy && lddy % 4) || lda < Cp)
@@ -85,8 +113,15 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
     if (((uintptr_t)ga | (uintptr_t)gb | (uintptr_t)act | (uintptr_t)dy) % 16) return fail(SAGEN_ERR_UNSUPPORTED, "relu_bwd: operands must be 16-byte aligned");
     const int C4 = Cp / 4;
     const long n4 = R * C4;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(aligned_grid(n4, C4)), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, n4, C4, colsum, C);
+    const bool fast = colsum && scratch && 256 % C4 == 0;
+    if (colsum && !fast) SAGEN_HIP_CHECK(hipMemsetAsync(colsum, 0, (size_t)Cp * sizeof(double), s));
+    const int grid = colsum ? reduce_grid(n4, C4) : aligned_grid(n4, C4);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, n4, C4, colsum, C, fast ? scratch : nullptr);
     SAGEN_LAUNCH_CHECK();
+    if (fast) {
+        hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(Cp, 32)), dim3(256), 0, s, scratch, grid, Cp, colsum);
+        SAGEN_LAUNCH_CHECK();
+    }
     return SAGEN_OK;
 }
 
@@ -122,7 +157,7 @@ __device__ __forceinline__ float4 masked_sum(const float4* ga, const float4* gb,
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb,
                                                             const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
-                                                            long n4, int C4, double* __restrict__ acc) {
+                                                            long n4, int C4, float* __restrict__ part) {
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 mean, invstd;
     bn_moments4(bn, 4 * C4, c4, mean, invstd);
@@ -134,16 +169,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
         sum[1].x = fmaf(dz.x, (v.x - mean.x) * invstd.x, sum[1].x); sum[1].y = fmaf(dz.y, (v.y - mean.y) * invstd.y, sum[1].y);
         sum[1].z = fmaf(dz.z, (v.z - mean.z) * invstd.z, sum[1].z); sum[1].w = fmaf(dz.w, (v.w - mean.w) * invstd.w, sum[1].w);
     }
-    channel_reduce<2>(sum, C4, c4, acc, 4 * C4);
+    channel_partials<2>(sum, C4, part);
 }
 
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, hipStream_t s) {
-    if (!ga || !y || !bn.acc || !acc) return fail(SAGEN_ERR_NULL, "bn_bwd_reduce: null argument");
+                         double* acc, float* scratch, hipStream_t s) {
+    if (!ga || !y || !bn.acc || !acc || !scratch) return fail(SAGEN_ERR_NULL, "bn_bwd_reduce: null argument");
     if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_reduce: C=%d must be 4 * a divisor of 256", C);
     const long n4 = n_pixels * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(aligned_grid(n4, C / 4)), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
-                       (const float4*)act, (const float4*)y, bn, n4, C / 4, acc);
+    const int grid = reduce_grid(n4, C / 4);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
+                       (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch);
+    SAGEN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, scratch, grid, 2 * C, acc);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

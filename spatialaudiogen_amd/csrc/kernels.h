@@ -211,15 +211,19 @@ int wgrad_launch(const WgradDesc& d, hipStream_t s);
 int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats);
 
 // -----------------------------------------------------------------------------------------
-// backward elementwise / reductions (backward.hip).  fp64 accumulators are zeroed by the caller.
+// backward elementwise / reductions (backward.hip)
 // -----------------------------------------------------------------------------------------
-// dy[r][c] = (ga[r][c] + gb[r][c]) * (act[r][c] > 0); gb / act / dy nullable; colsum (fp64 [C], atomics) nullable: sum_r dy
+// scratch of the per-channel reductions below: per-workgroup partial rows, summed in a fixed order (no atomics)
+size_t reduce_scratch_floats(int C);
+// dy[r][c] = (ga[r][c] + gb[r][c]) * (act[r][c] > 0); gb / act / dy nullable; colsum (fp64 [C]) nullable: sum_r dy (overwritten);
+// scratch >= reduce_scratch_floats(C) floats (without it, or for widths that do not divide 256 lanes: fp64 atomics)
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
-                    int C, double* colsum, hipStream_t s);
+                    int C, double* colsum, float* scratch, hipStream_t s);
 // training-mode batch-norm backward (core.py:6,209-210 under tf.gradients).  dz = (ga + gb) * (act > 0) (act nullable);
-// xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat)
+// xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat) (overwritten);
+// scratch >= reduce_scratch_floats(C) floats
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, hipStream_t s);
+                         double* acc, float* scratch, hipStream_t s);
 // dy = gamma*invstd*(dz - acc0/N - xhat*acc1/N) (+ dz to `dz_out`, nullable); writes dgamma = acc1, dbeta = acc0 (nullable)
 int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
                         long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s);

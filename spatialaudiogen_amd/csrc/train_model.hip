@@ -63,6 +63,7 @@ static void train_carve(sagen_ctx* c) {
     c->talloc("t:loss", 64);
     c->talloc("t:cacc", (size_t)CACC_SLOTS * CACC_SLOT * 2);
     c->talloc("t:wgws", WGWS_FLOATS);
+    c->talloc("t:redws", reduce_scratch_floats(1024));
     c->talloc("t:ddmask", (size_t)B * 31 * 1024 * nsep);
     c->talloc("t:mbw", mask_istft_bwd_scratch_floats(B, nsep));
     c->talloc("t:dcoeffs", (size_t)B * 3 * ldc);
@@ -153,7 +154,7 @@ struct Bwd : Fwd {
         layer = label;
         double* acc = bias_var.empty() ? nullptr : cacc_next();
         if (rc) return;
-        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, s); });
+        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p("t:redws"), s); });
         if (acc) timed("acc_to_f32_kernel", 0.0, [&] { return acc_to_f32_launch(acc, grad(bias_var), C, s); });
     }
 
@@ -230,7 +231,7 @@ struct Bwd : Fwd {
         const BnRef bn = bn_ref(li, bn_name, npix);
         double* acc = bnb_acc(li);
         layer = "bnbwd:" + bn_name;
-        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, act, y, bn, npix, C, acc, s); });
+        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, act, y, bn, npix, C, acc, c->p("t:redws"), s); });
         timed("bn_bwd_apply_kernel", 0.0, [&] {
             return bn_bwd_apply_launch(ga, gb, act, y, bn, acc, npix, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s); });
     }
@@ -483,9 +484,6 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     b.timed("stft_loss_grad_kernel", 0.0, [&] { return stft_loss_grad_launch(pred, target, mask, c->B, c->p("t:dpred"), loss, s); });
     if (b.rc) return b.rc;
     if (loss_out) SAGEN_HIP_CHECK(hipMemcpyAsync(loss_out, loss, sizeof(double), hipMemcpyDeviceToDevice, s));
-    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("t:cacc"), 0, c->tbufs.at("t:cacc").n * sizeof(float), s));
-    for (const char* nm : {"t:bnbacc", "t:bnbacc_b"})
-        if (c->tbufs.count(nm)) SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
     b.run();
     if (b.rc) return b.rc;
     if (update_moving) {

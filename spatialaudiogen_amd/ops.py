@@ -205,7 +205,7 @@ def bn_bwd(g, y, stats, gamma, beta, act=None, g2=None, eps=1e-3, want_dz=False)
     dz = torch.empty_like(y) if want_dz else None
     dgamma = torch.empty(C_, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(C_, dtype=torch.float32, device=y.device)
-    scratch = torch.empty(2 * C_, dtype=torch.float64, device=y.device)
+    scratch = torch.empty((int(_lib.lib().sagen_bn_bwd_scratch_bytes(C_)) + 7) // 8, dtype=torch.float64, device=y.device)
     check(_lib.lib().sagen_bn_bwd(_ptr(g), _ptr(g2), _ptr(act), _ptr(y), _ptr(stats), _ptr(_f32(gamma, 'gamma')), _ptr(_f32(beta, 'beta')), eps,
                                   npix, C_, _ptr(dy), _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(scratch), scratch.numel() * 8, _stream()))
     return (dy, dgamma, dbeta, dz) if want_dz else (dy, dgamma, dbeta)

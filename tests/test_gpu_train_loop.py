@@ -64,7 +64,7 @@ def test_nan_guard_stops_the_loop_and_still_saves(T, tmp_path):
     def poisoned():
         for i, b in enumerate(synthetic_batches(['audio'], 2, seed=1, pool=1)):
             if i == 2:
-                a = b[0].copy(); a[0, 100, 0] = np.nan
+                a = b[0].copy(); a[0, 25000, 0] = np.nan
                 b = (a,) + b[1:]
             yield b
     tr, _ = _trainer(T, ('audio',), 2)
