@@ -377,9 +377,23 @@ def main():
         net.load_plan(BATCH, args.plan_file)
         plan = net.plan(BATCH)
     elif not args.no_autotune:
-        plan = net.autotune(*a0)
-        if args.plan_file and rank == 0:
-            net.save_plan(BATCH, args.plan_file)
+        # tuned on rank 0 and broadcast: every rank (and every context in flight) runs the SAME kernels - independent tunings can
+        # settle on different tiles for near-ties, which would make the ranks' step times (and rounding) differ
+        if rank == 0:
+            plan = net.autotune(*a0)
+            if args.plan_file:
+                net.save_plan(BATCH, args.plan_file)
+        if world > 1:
+            box = [plan]
+            dist.broadcast_object_list(box, src=0)
+            plan = [tuple(r) for r in box[0]]
+            if rank != 0:
+                net.inference_ops(*a0, out=outs[0])           # creates the context
+                tn = SptAudioGen.tile_names()
+                for layer, tile, sk, _ in plan:
+                    net.plan_set(BATCH, layer, tn.index(tile) if tile in tn else 0, sk)
+            mine = sorted((l, t, k) for l, t, k, _ in net.plan(BATCH))
+            assert mine == sorted((l, t, k) for l, t, k, _ in plan), 'rank %d runs a different launch plan than rank 0' % rank
     names = SptAudioGen.tile_names()
     from spatialaudiogen_amd.streams import pick_concurrent_streams
     streams.extend(pick_concurrent_streams(NF))

@@ -267,12 +267,16 @@ class FlowFrames(object):
         self.flow_prep = flow_prep
 
     def frames(self, first, count, rotation=None):
-        raw = self.jpgs.frames(first, count, rotation).astype(np.float32)
+        # the reference's op order and rounding points (feeder.py:147-160): the limits are float64, so each in-place update of the
+        # float32 frames is computed in double and rounded once; the angle scale is a Python scalar (float32 arithmetic)
+        out = self.jpgs.frames(first, count, rotation).astype(np.float32)
         lo = self.limits[first:first + count, 0].reshape(-1, 1, 1)
         hi = self.limits[first:first + count, 1].reshape(-1, 1, 1)
-        mag = raw[..., 2] * ((hi - lo) / 255.) + lo
-        ang = raw[..., 0] * ((2 * np.pi) / 255.)
-        out = np.stack([mag * np.cos(ang), mag * np.sin(ang), mag], -1).astype(np.float32)
+        out[..., 2] *= (hi - lo) / 255.
+        out[..., 2] += lo
+        out[..., 0] *= (2 * np.pi) / 255.
+        out[..., 1] = out[..., 2] * np.sin(out[..., 0])
+        out[..., 0] = out[..., 2] * np.cos(out[..., 0])
         return self.flow_prep(out) if self.flow_prep is not None else out
 
     def get_by_index(self, start_time, size, rotation=None):

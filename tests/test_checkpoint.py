@@ -103,3 +103,39 @@ def test_writer_records_tensor_crcs_and_loader_checks_them(tmp_path):
     with pytest.raises(ValueError, match='crc32c'):
         ck.load_checkpoint(prefix)
     assert ck.load_checkpoint(prefix, verify=False)['a/weights'].shape == (3, 4)
+
+
+def test_whole_bundle_assembled_by_hand(tmp_path):
+    """Footer + metaindex + index block + several prefix-compressed data blocks + shard file written by tests/bundle_by_hand.py (an
+    independent statement of the on-disk format with its own CRC32C and varint code; save_checkpoint is not involved), read through
+    load_checkpoint with verification on; then one flipped payload byte must fail the per-tensor crc."""
+    import bundle_by_hand as bh
+    assert bh.crc32c(b'123456789') == 0xE3069283 and bh.crc32c(b'\x00' * 32) == 0x8A9136AA      # RFC 3720 known answers
+    r = np.random.Generator(np.random.PCG64(3))
+    V = {'audio_encoder/conv1/weights': r.normal(size=(7, 16, 1, 32)).astype(np.float32),
+         'audio_encoder/conv1/biases': r.normal(size=(32,)).astype(np.float32),
+         'audio_encoder/conv1/biases/Adam': np.zeros(32, np.float32),
+         'video_encoder/conv2_1/conv_1/bn/gamma': r.uniform(0.5, 1.5, size=(64,)).astype(np.float32),
+         'video_encoder/conv2_1/conv_1/bn/moving_variance': np.ones(64, np.float32),
+         'localization/fc3/weights': r.normal(size=(512, 99)).astype(np.float32),
+         'beta1_power': np.array(0.81, np.float32), 'step': np.array(150000, np.int64), 'x64': r.normal(size=(3, 5))}
+    for i in range(40):                                            # enough keys for several data blocks / restart points
+        V['separation/deconv%d/extra_%02d' % (i % 5 + 1, i)] = r.normal(size=(i % 7 + 1,)).astype(np.float32)
+    prefix = str(tmp_path / 'model.ckpt-150000')
+    bh.write_bundle(prefix, V, entries_per_block=7, restart_every=3, crc_below=1 << 30)
+    assert ck.latest_checkpoint(str(tmp_path)) == prefix
+    entries, header = ck.read_index(prefix + '.index')
+    assert header['num_shards'] == 1 and set(entries) == set(V)
+    assert entries['localization/fc3/weights']['shape'] == (512, 99) and entries['step']['shape'] == ()
+    got = ck.load_checkpoint(prefix, verify=True)
+    assert set(got) == set(V)
+    for k in V:
+        assert got[k].dtype == V[k].dtype and got[k].shape == V[k].shape and np.array_equal(got[k], V[k]), k
+    only = ck.load_checkpoint(prefix, names={'audio_encoder/conv1/biases'})
+    assert list(only) == ['audio_encoder/conv1/biases']
+    fn = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(fn, 'rb').read())
+    raw[entries['localization/fc3/weights']['offset'] + 17] ^= 0x40
+    open(fn, 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='crc32c'):
+        ck.load_checkpoint(prefix, verify=True)

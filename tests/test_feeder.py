@@ -71,6 +71,13 @@ def test_sample_reader_matches_in_memory_clip(tmp_path):
         ang = raw[..., 0] * (2 * np.pi) / 255.
         assert np.allclose(a['flow'][0, ..., 2], mag) and np.allclose(a['flow'][0, ..., 0], mag * np.cos(ang), atol=1e-5)
         assert np.allclose(a['flow'][0, ..., 1], mag * np.sin(ang), atol=1e-5)
+        # bit-exact against the reference's rounding points (feeder.py:147-160), restated with explicit casts: the float64 limits
+        # make the two magnitude updates double-precision operations rounded to float32 once each; the angle is scaled in float32
+        m32 = (raw[..., 2].astype(np.float64) * ((lims[fi, 1] - lims[fi, 0]) / 255.)).astype(np.float32)
+        m32 = (m32.astype(np.float64) + lims[fi, 0]).astype(np.float32)
+        a32 = raw[..., 0] * np.float32((2 * np.pi) / 255.)
+        assert np.array_equal(a['flow'][0, ..., 2], m32)
+        assert np.array_equal(a['flow'][0, ..., 0], m32 * np.cos(a32)) and np.array_equal(a['flow'][0, ..., 1], m32 * np.sin(a32))
     assert rd.get() is None and clip.get() is None
 
 

@@ -78,3 +78,13 @@ def test_bench_train_config_line_and_two_ranks():
     assert r['config']['last_loss'] == r['config']['last_loss']            # not NaN
     two = _run(['--config', 'train', '--steps', '2'] + FAST, world=2)
     assert two['n_gpus'] == 2 and two['value'] > 0 and 'gloo' in two['config']['gradient_exchange']
+
+
+def test_four_ranks_share_one_tuned_plan():
+    """--gpus 4 (gloo, four ranks on this GPU) WITH autotune: rank 0 tunes, the plan is broadcast, every rank asserts it runs the
+    same kernels (bench.py) - for the headline configuration and for the training step."""
+    ensure_lib()
+    r = _run(['--config', 'av', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extra-legs', '--in-flight', '1'], world=4)
+    assert r['n_gpus'] == 4 and r['value'] > 0 and r['config']['launch_plan'].startswith('autotuned')
+    t = _run(['--config', 'train', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], world=4)
+    assert t['n_gpus'] == 4 and t['value'] > 0 and t['config']['launch_plan'].startswith('autotuned')
