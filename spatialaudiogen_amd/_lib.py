@@ -40,6 +40,7 @@ SIGNATURES = {
     'sagen_variable_spec': (C.c_int, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     'sagen_bind_weights': (C.c_int, [_P, C.POINTER(SagenTensor), _I, _P, _SZ, _P]),
     'sagen_forward': (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    'sagen_forward_u8': (C.c_int, [_P, _P, _P, _P, _P, _P]),
     'sagen_assemble_wyzx': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'sagen_get_intermediate': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]),

@@ -9,6 +9,7 @@ struct sagen_ctx;
 int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg);
 int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* workspace, size_t workspace_bytes, hipStream_t s);
 int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
+int sagen_forward_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video_u8, const float* flow, float* out, hipStream_t s);
 void sagen_destroy_impl(sagen_ctx* c);
 size_t sagen_workspace_bytes_impl(const sagen_ctx* c);
 int sagen_num_variables_impl(const sagen_ctx* c);
@@ -90,6 +91,9 @@ int sagen_bind_weights(sagen_ctx* ctx, const sagen_tensor* tensors, int n, void*
 int sagen_forward(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {
     return guarded([&] { return sagen_forward_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
 }
+int sagen_forward_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video_u8, const float* flow, float* ambi_yzx, void* stream) {
+    return guarded([&] { return sagen_forward_u8_impl(ctx, audio, video_u8, flow, ambi_yzx, (hipStream_t)stream); });
+}
 int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                            int64_t* pixel_stride) {
     if (!ctx || !name || !data || !ndim || !shape || !pixel_stride) return fail(SAGEN_ERR_NULL, "sagen_get_intermediate: null argument");
@@ -136,7 +140,10 @@ int sagen_stft_mag(const float* audio, int batch, int n_samples, int f0, int f1,
 size_t sagen_conv2d_scratch_bytes(int batch, int h, int w, int kh, int kw, int cin, int cout) {
     if (cin == 3) return pk_bytes(cout, (long)kh * kw * 4) + align_up((size_t)batch * (h + kh) * (w + kw) * 4 * sizeof(float), 256);
     // 3x3 convs may run on pre-split activation planes (conv3p.hip): room for them behind the packed filter
-    const size_t planes = (kh == 3 && kw == 3 && cin % 16 == 0) ? align_up(p3_bytes(batch, h, w, cin), 256) : 0;
+    // (only where that path can run: below the 2 GiB buffer-addressing limit.  The query cannot see stride / padding, so a caller
+    // that sizes its scratch with pk_bytes alone - the pre-P3 formula - is still served, by the fp32-activation kernels.)
+    const size_t pb = (kh == 3 && kw == 3 && cin % 16 == 0) ? p3_bytes(batch, h, w, cin) : 0;
+    const size_t planes = (pb > 0 && pb < (1UL << 31)) ? align_up(pb, 256) : 0;
     return pk_bytes(cout, (long)kh * kw * cin) + planes;
 }
 
@@ -154,8 +161,9 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
         if (batch <= 0 || h <= 0 || w <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || cout <= 0)
             return fail(SAGEN_ERR_SHAPE, "sagen_conv2d: bad dimensions");
         if ((in_scale == nullptr) != (in_shift == nullptr)) return fail(SAGEN_ERR_NULL, "sagen_conv2d: in_scale/in_shift must come together");
-        if (scratch_bytes < sagen_conv2d_scratch_bytes(batch, h, w, kh, kw, cin, cout))
-            return fail(SAGEN_ERR_WORKSPACE, "sagen_conv2d: scratch too small");
+        const size_t need_min = cin == 3 ? sagen_conv2d_scratch_bytes(batch, h, w, kh, kw, cin, cout) : pk_bytes(cout, (long)kh * kw * (cin == 1 ? 1 : cin));
+        if (scratch_bytes < need_min) return fail(SAGEN_ERR_WORKSPACE, "sagen_conv2d: scratch too small");
+        const bool room_for_planes = scratch_bytes >= sagen_conv2d_scratch_bytes(batch, h, w, kh, kw, cin, cout);
         int Hout, Wout, pt = 0, pb = 0, pl = 0, pr = 0;
         if (padding == 1) {
             Hout = cdiv(h, sh); Wout = cdiv(w, sw);
@@ -205,7 +213,7 @@ int sagen_conv2d(const float* x, int batch, int h, int w, int cin, const float* 
         d.w_split = 1;
         if (bn_stats) SAGEN_HIP_CHECK(hipMemsetAsync(bn_stats, 0, (size_t)2 * cout * sizeof(double), s));
         static const bool no_p3 = getenv("SAGEN_NO_P3") != nullptr || getenv("SAGEN_FP32_ONLY") != nullptr;
-        if (!no_p3 && sh == 1 && sw == 1 && padding == 1 && cin % 16 == 0 && igemm_p3_eligible(d) &&
+        if (!no_p3 && room_for_planes && sh == 1 && sw == 1 && padding == 1 && cin % 16 == 0 && igemm_p3_eligible(d) &&
             p3_bytes(batch, h, w, cin) < (1UL << 31)) {
             // dense 3x3 stride-1 SAME: one elementwise pass applies the input BN+ReLU (if any) and writes the three bf16
             // planes; the contraction then runs LDS-DMA -> MFMA only (conv3p.hip)

@@ -391,7 +391,11 @@ int conv3p_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     IgemmDesc d = d_in;
     if (!d.xp3 || d.p3_np <= 0) return fail(SAGEN_ERR_NULL, "conv3p: the P3 activation planes are missing");
     if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: no split-K");
-    if ((long)(d.p3_np + 512) * (d.Win + 1) >= (1L << 32)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: too many pixels for 32-bit index arithmetic");
+    // the two mul-hi divisions (pixel / (Win+1), then row / Hin) are exact while dividend * divisor < 2^32; plane offsets are 32-bit
+    if ((long)(d.p3_np + 512) * (d.Win + 1) >= (1L << 32) || ((long)(d.p3_np + 512) / (d.Win + 1) + 1) * d.Hin >= (1L << 32))
+        return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: too many pixels for 32-bit index arithmetic");
+    if ((long)d.p3_np * 96 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)
+        return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: the activation planes exceed 2 GiB buffer addressing (use a smaller batch)");
     if (cdiv(d.p3_np, 62) * (long)cdiv(d.N, 64) >= (1L << 24)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3p: too many tiles");
     d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)(d.Win + 1)) + 1u;
     d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hin) + 1u;

@@ -170,6 +170,34 @@ __global__ __launch_bounds__(256) void pad_nhwc3to4_kernel(const float* __restri
     }
 }
 
+// the same from uint8 frames, with the reference's pixel normalisation x / 255. - 0.5 (myutils.py:88-89, applied by the feeder to
+// the decoded uint8 frame in double precision and stored as float32) fused in: the host ships 1 byte per sample instead of 4
+__global__ __launch_bounds__(256) void pad_u8_nhwc3to4_kernel(const unsigned char* __restrict__ x, float4* __restrict__ y, int B, int H,
+                                                              int W, int Hp, int Wp, int pt, int pl) {
+    const long total = (long)B * Hp * Wp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i;
+        const int w = (int)(p % Wp) - pl; p /= Wp;
+        const int h = (int)(p % Hp) - pt;
+        const int b = (int)(p / Hp);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            const unsigned char* src = x + (((long)b * H + h) * W + w) * 3;
+            v.x = (float)((double)src[0] / 255.0 - 0.5); v.y = (float)((double)src[1] / 255.0 - 0.5); v.z = (float)((double)src[2] / 255.0 - 0.5);
+        }
+        y[i] = v;
+    }
+}
+
+int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s) {
+    const int Hp = H + pt + pb, Wp = W + pl + pr;
+    const long total = (long)B * Hp * Wp;
+    const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
+    hipLaunchKernelGGL(pad_u8_nhwc3to4_kernel, dim3(grid), dim3(256), 0, s, x, (float4*)y, B, H, W, Hp, Wp, pt, pl);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s) {
     const int Hp = H + pt + pb, Wp = W + pl + pr;
     const long total = (long)B * Hp * Wp;

@@ -140,6 +140,8 @@ int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, 
 // [B,H,W,3] -> zero-bordered [B,H+pt+pb,W+pl+pr,4]
 int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr,
                         hipStream_t s);
+// uint8 frames -> normalised (x/255 - 0.5) zero-bordered 4-channel fp32
+int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s);
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);

@@ -92,6 +92,7 @@ struct sagen_ctx {
     // gradient activations, data-gradient filter packs, fp64 accumulators.  `train_mode` makes the forward retain.
     bool train_mode = false;
     bool train_ready = false;
+    bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
     size_t tws_floats = 0;
     float* tws = nullptr;
     std::map<std::string, Buf> tbufs;
@@ -445,7 +446,10 @@ struct Fwd {
         if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
-        timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
+        if (c->video_u8 && scope == "video_encoder")
+            timed("pad_u8_nhwc3to4_kernel", 0.0, [&] { return pad_u8_nhwc3to4_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
+        else
+            timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         // conv1 7x7/2 SAME == VALID 7x8 (8th tap column = zero weights) on the padded 4-channel image
         int H = 0, W = 0;
         if (!rc && wait_before_mfma) {
@@ -563,7 +567,10 @@ struct Fwd {
         if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
-        timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
+        if (c->video_u8 && scope == "video_encoder")
+            timed("pad_u8_nhwc3to4_kernel", 0.0, [&] { return pad_u8_nhwc3to4_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
+        else
+            timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         int H = 0, W = 0;
         if (!rc && wait_before_mfma) {
             if (hipStreamWaitEvent(s, wait_before_mfma, 0) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "hipStreamWaitEvent failed");

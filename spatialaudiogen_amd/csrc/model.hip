@@ -395,6 +395,14 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
                                      c->p("frames"), s); });
     return f.rc;
 }
+int sagen_forward_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video_u8, const float* flow, float* out, hipStream_t s) {
+    if (!c) return fail(SAGEN_ERR_NULL, "sagen_forward_u8: null ctx");
+    if (!c->has_video) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_forward_u8: the video encoder is not enabled");
+    c->video_u8 = true;
+    const int rc = sagen_forward_impl(c, audio, reinterpret_cast<const float*>(video_u8), flow, out, s);
+    c->video_u8 = false;
+    return rc;
+}
 void sagen_destroy_impl(sagen_ctx* c) {
     if (!c) return;
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);

@@ -33,15 +33,17 @@ def init_process_group(backend=None):
 
 
 class MetricReducer(object):
-    """Per-rank float64 (sum, count) per metric + sample count -> global means with ONE all-reduce (2*18+1 doubles for the
-    on-graph metrics of eval.py:125-133).  Non-finite per-sample values (the SNR of a masked channel is 0/0) are left
-    out of that metric's mean and count."""
+    """Per-rank float64 sums per metric + sample count -> global means with ONE all-reduce (3*18+1 doubles for the on-graph
+    metrics of eval.py:125-133).  `reduce()` returns the reference's statistic: np.mean over ALL samples (eval.py:223), so a
+    non-finite per-sample value makes that metric's mean non-finite, exactly as in the reference.  The means over the finite
+    samples only, and how many there were, are kept beside it (`finite_means`, `finite_counts`) as a diagnostic."""
 
     def __init__(self, names, device=None):
         import torch
         self.names = list(names)
         self.k = len(self.names)
-        self.buf = torch.zeros(2 * self.k + 1, dtype=torch.float64, device=device)
+        self.buf = torch.zeros(3 * self.k + 1, dtype=torch.float64, device=device)
+        self.finite_means, self.finite_counts = {}, {}
 
     def add_rows(self, rows):
         """rows [n, k]: one row of metric values per sample."""
@@ -49,7 +51,8 @@ class MetricReducer(object):
         import torch
         rows = np.asarray(rows, np.float64).reshape(-1, self.k)
         ok = np.isfinite(rows)
-        upd = np.concatenate([np.where(ok, rows, 0.0).sum(0), ok.sum(0).astype(np.float64), [float(rows.shape[0])]])
+        with np.errstate(invalid='ignore'):
+            upd = np.concatenate([rows.sum(0), np.where(ok, rows, 0.0).sum(0), ok.sum(0).astype(np.float64), [float(rows.shape[0])]])
         self.buf += torch.as_tensor(upd, dtype=torch.float64, device=self.buf.device)
 
     def add(self, values, count):
@@ -61,6 +64,10 @@ class MetricReducer(object):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.buf)
-        sums, cnts = self.buf[:self.k], self.buf[self.k:2 * self.k]
-        vals = (sums / cnts.clamp(min=1.0)).tolist()
-        return dict(zip(self.names, vals)), int(self.buf[-1].item())
+        k = self.k
+        n = float(self.buf[-1].item())
+        sums, fsums, cnts = self.buf[:k], self.buf[k:2 * k], self.buf[2 * k:3 * k]
+        vals = (sums / max(n, 1.0)).tolist()
+        self.finite_means = dict(zip(self.names, (fsums / cnts.clamp(min=1.0)).tolist()))
+        self.finite_counts = dict(zip(self.names, [int(c) for c in cnts.tolist()]))
+        return dict(zip(self.names, vals)), int(n)

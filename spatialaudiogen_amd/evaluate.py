@@ -159,7 +159,7 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
         ev.run_batch([smp['id'] for smp in samples], stack('ambix'), stack('video'), stack('flow'),
                      np.stack([layouts.get(yid, np.ones(4)) for yid, _ in wins], 0))
 
-    # global means: ONE all-reduce of per-key (sum over finite values, finite count) + sample count
+    # global means (np.mean over every sample, eval.py:223): ONE all-reduce of per-key sums (+ finite-only sums / counts) + sample count
     red = MetricReducer(METRIC_KEYS, device=net.device if world > 1 and torch.cuda.is_available() and
                         torch.distributed.get_backend() != 'gloo' else None)
     rows = np.asarray(ev.rows, np.float64).reshape(-1, len(METRIC_KEYS))
@@ -180,6 +180,10 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
             for ids_r, rows_r in zip(all_ids, all_rows):
                 for sid, row in zip(ids_r, rows_r):
                     f.write('{} | {}\n'.format(sid, ' '.join(str(v) for v in row)))
+        short = {k: c for k, c in red.finite_counts.items() if c < count}
+        if short:        # the means above are np.mean over all samples (eval.py:223): a non-finite sample shows there; say how many
+            print('EVAL | non-finite per-sample values: ' + ', '.join('%s %d/%d finite (finite-only mean %.6g)' % (k, c, count, red.finite_means[k])
+                                                                     for k, c in sorted(short.items())))
         dropped = len(plan) - count
         if dropped:
             print('EVAL | %d trailing windows (a partial batch of %d) were not evaluated' % (dropped, BATCH_SIZE))

@@ -184,7 +184,15 @@ class SptAudioGen(object):
                 raise ValueError('%s has shape %s, expected [B,%s]' % (name, tuple(t.shape), ','.join(map(str, tail))))
             return t
         audio = prep(audio, 'audio', (self.snd_size, 1))
-        video = prep(video, 'video', (1, 224, 448, 3)) if VIDEO in self.encoders else None
+        if isinstance(video, np.ndarray) and video.dtype == np.uint8:
+            video = torch.as_tensor(video)
+        video_u8 = isinstance(video, torch.Tensor) and video.dtype == torch.uint8 and VIDEO in self.encoders
+        if video_u8:          # decoded frames as they are: the x/255 - 0.5 of the feeder (myutils.py:88-89) runs on the device
+            if tuple(video.shape[1:]) != (1, 224, 448, 3):
+                raise ValueError('video has shape %s, expected [B,1,224,448,3]' % (tuple(video.shape),))
+            video = video.to(device=self.device).contiguous()
+        else:
+            video = prep(video, 'video', (1, 224, 448, 3)) if VIDEO in self.encoders else None
         flow = prep(flow, 'flow', (1, 224, 448, 3)) if FLOW in self.encoders else None
         if VIDEO in self.encoders and video is None:
             raise ValueError('video encoder enabled but no video given')
@@ -196,7 +204,8 @@ class SptAudioGen(object):
             out = torch.empty(B, self.snd_dur, self.geom.num_out, dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        check(_lib.lib().sagen_forward(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
+        fwd = _lib.lib().sagen_forward_u8 if video_u8 else _lib.lib().sagen_forward
+        check(fwd(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
         return out
 
     # ---- evaluation metrics (model.py:110-154) -----------------------------------------------------

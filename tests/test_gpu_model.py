@@ -229,3 +229,21 @@ def test_full_benchmark_batch_against_the_independent_cpu_reference(T):
     plan = net.autotune(inp['audio'], inp['video'])
     assert any(row[1].startswith('igemm3') for row in plan)
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
+
+
+def test_uint8_video_entry_point_is_bit_identical(T):
+    """sagen_forward_u8: frames as uint8, x/255 - 0.5 (myutils.py:88-89) fused into the device-side pad pass - the output must equal,
+    bit for bit, the forward on the float32 frames the feeder would have produced (double-precision divide, one rounding)."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=2, mode='test')
+    inp = synth_inputs(3, enc, seed=77)
+    r = np.random.Generator(np.random.PCG64(5))
+    u8 = r.integers(0, 256, size=(3, 1, 224, 448, 3)).astype(np.uint8)
+    f32 = (u8 / 255. - 0.5).astype(np.float32)                      # feeder.img_prep_fcn on the decoded frame
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    a = net.inference_ops(inp['audio'], f32).cpu().numpy()
+    b = net.inference_ops(inp['audio'], u8).cpu().numpy()
+    c = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
+    assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)

@@ -96,10 +96,13 @@ def test_eval_batches_do_not_depend_on_the_world_size():
                 assert got == ref
 
 
-def test_metric_reducer_skips_non_finite_values():
+def test_metric_reducer_keeps_the_reference_mean_and_reports_the_finite_one():
+    """np.mean over all samples (eval.py:223): a NaN / inf sample shows in the mean, as in the reference; the finite-only
+    statistics sit beside it."""
     import numpy as np
     from spatialaudiogen_amd.dist import MetricReducer
-    red = MetricReducer(['a', 'b'])
-    red.add_rows(np.array([[1.0, np.nan], [3.0, 4.0], [5.0, np.inf]]))
+    red = MetricReducer(['a', 'b', 'c'])
+    red.add_rows(np.array([[1.0, np.nan, 2.0], [3.0, 4.0, np.inf], [5.0, 6.0, 4.0]]))
     vals, n = red.reduce()
-    assert n == 3 and vals['a'] == 3.0 and vals['b'] == 4.0
+    assert n == 3 and vals['a'] == 3.0 and np.isnan(vals['b']) and np.isinf(vals['c'])
+    assert red.finite_means == {'a': 3.0, 'b': 5.0, 'c': 3.0} and red.finite_counts == {'a': 3, 'b': 2, 'c': 2}
