@@ -215,14 +215,23 @@ def main_train(args, cfg):
     dom = max(agg, key=lambda k: agg[k][1])
     n_l, us_l, fl_l = agg[dom]
     achieved = fl_l / (us_l * 1e-6) / 1e12
-    b3 = dom.startswith('igemm3') or dom.startswith('conv3p')
+    b3 = dom.startswith('igemm3') or dom.startswith('conv3p') or dom.startswith('wgrad3')
     peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
+    traffic, traffic_src = None, None
+    try:     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_train.json')) as f:
+            traffic = json.load(f).get(dom)
+        if traffic is not None:
+            traffic_src = 'profiles/pmc_traffic_train.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x2 per the gfx950 note), launch-weighted mean, not measured in this run'
+    except Exception:
+        pass
     step_tflops = total_fl / nprof / (ms_per_step * 1e-3) / 1e12
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-        'frac': round(achieved / peak, 4), 'traffic': None, 'traffic_source': None,
+        'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
-                       if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32): the weight-gradient kernel contracts over pixels, K-major operands'),
+                       if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
+        'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
         'share_of_step_time': round(us_l / total_us, 3),
         'phases_us_per_step': {k: round(v[0] / nprof, 1) for k, v in sorted(by_phase.items())},

@@ -191,7 +191,7 @@ int adam_update_launch(float* p, const float* g, float* m, float* v, long n, flo
                        float gscale, hipStream_t s);
 
 // -----------------------------------------------------------------------------------------
-// weight gradients (wgrad.hip): dW[t][g][d] = sum_{b,i,j} G[b, i*sh + th + h0, j*sw + tw + w0, g] * D[b, i, j, d]
+// weight gradients (wgrad.hip): dW[t][g][d] = sum_{b,i,j} G[b, i*sh + th*tsh + h0, j*sw + tw*tsw + w0, g] * D[b, i, j, d]
 // (conv: G = input, D = dL/dy; conv2d_transpose: G = dL/dy, D = input; FC: one tap on a 1x1 grid).  Strides in floats.
 // -----------------------------------------------------------------------------------------
 struct WgradDesc {
@@ -204,6 +204,7 @@ struct WgradDesc {
     int ldd = 0, Cd = 0;
     unsigned g_bstride = 0, g_rstride = 0, d_bstride = 0, d_rstride = 0;
     int sh = 1, sw = 1, TH = 1, TW = 1, h0 = 0, w0 = 0;
+    int tsh = 1, tsw = 1;             // tap strides: tap (th, tw) reads G at (i*sh + th*tsh + h0, j*sw + tw*tsw + w0)
     int splitk = 1;
     // filled by wgrad_launch
     int P = 0;
@@ -211,6 +212,7 @@ struct WgradDesc {
 };
 int wgrad_launch(const WgradDesc& d, hipStream_t s);
 int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats);
+const char* wgrad_kernel_name();      // "wgrad3_kernel" (bf16x3, default) | "wgrad_kernel" (exact fp32 MFMA) | "wgrad_ref_kernel"
 
 // -----------------------------------------------------------------------------------------
 // backward elementwise / reductions (backward.hip)

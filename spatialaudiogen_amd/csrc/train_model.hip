@@ -95,7 +95,9 @@ static void train_carve(sagen_ctx* c) {
             const size_t sz = (size_t)B * RS_H[k / 2] * RS_W[k / 2] * RS_C[k / 2];
             for (const char* nm : {"t:y1:", "t:a1:", "t:y2:", "t:out:"}) c->talloc(nm + std::to_string(k) + x, sz);
         }
-        for (const char* nm : {"t:A0", "t:A1", "t:Z0", "t:Z1", "t:S", "t:DY", "t:DA"}) c->talloc(nm + x, stage);
+        // gradient activations of the trunk.  The weight gradients run on the context's second stream, so what they read (dy of conv_2 /
+        // conv_1, dz of the merge) is double-buffered over the block parity: block k may overwrite only what block k+2 left behind
+        for (const char* nm : {"t:A0", "t:A1", "t:Z0", "t:Z1", "t:S", "t:DYc0", "t:DYc1", "t:DYd0", "t:DYd1", "t:DA"}) c->talloc(nm + x, stage);
         c->talloc("t:dz0" + x, (size_t)B * 112 * 224 * 64);
         c->talloc("t:bnbacc" + x, (size_t)24 * 2 * 512 * 2);
         c->talloc("t:stemtmp" + x, (size_t)7 * 32 * 64);
@@ -167,14 +169,37 @@ struct Bwd : Fwd {
         d.sh = sh; d.sw = sw; d.TH = kh; d.TW = kw; d.h0 = h0; d.w0 = w0;
         return d;
     }
-    void wgrad(const std::string& label, WgradDesc d, float* out) {
+    // Weight gradients go to the context's SECOND stream (`wg`): nothing downstream of the backward chain waits for them, and they
+    // are matrix-core bound while the batch-norm / ReLU passes between the data gradients are HBM bound - the two overlap.
+    // Ordering: the wgrad waits for everything enqueued so far on the main stream (its operands' producers); the main stream
+    // waits (aux_fence) before it overwrites a buffer the second stream may still be reading, and joins it at the end of the step.
+    Bwd* wg = nullptr;
+    void wgrad_here(const std::string& label, WgradDesc d, float* out) {
         if (rc) return;
         layer = label;
         d.out = out;
         d.ws = c->p("t:wgws");
         d.splitk = wgrad_pick_splitk(d, c->cap("t:wgws"));
         const double flops = 2.0 * d.B * d.Hd * d.Wd * d.TH * d.TW * d.Cg * d.Cd;
-        timed("wgrad_kernel", flops, [&] { return wgrad_launch(d, s); });
+        timed(wgrad_kernel_name(), flops, [&] { return wgrad_launch(d, s); });
+    }
+    void wgrad(const std::string& label, const WgradDesc& d, float* out) {
+        if (rc) return;
+        if (!wg) { wgrad_here(label, d, out); return; }
+        hipEvent_t e = next_event();
+        if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(wg->s, e, 0) != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "stream fork failed"); return; }
+        wg->wgrad_here(label, d, out);
+        if (wg->rc) rc = wg->rc;
+    }
+    // an event after everything enqueued on the second stream so far (nullptr when there is none)
+    hipEvent_t aux_mark() {
+        if (!wg || rc) return nullptr;
+        hipEvent_t e = next_event();
+        if (!e || hipEventRecord(e, wg->s) != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "hipEventRecord failed"); return nullptr; }
+        return e;
+    }
+    void aux_wait(hipEvent_t e) {
+        if (e && !rc && hipStreamWaitEvent(s, e, 0) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "hipStreamWaitEvent failed");
     }
 
     // ---- data gradients on the forward's contraction kernels ----
@@ -240,8 +265,10 @@ struct Bwd : Fwd {
         const int B = c->B;
         const float* ga = gfeat;
         const float* gb = nullptr;
-        float* DY = c->p("t:DY" + sfx); float* DA = c->p("t:DA" + sfx); float* S = c->p("t:S" + sfx);
+        float* DA = c->p("t:DA" + sfx); float* S = c->p("t:S" + sfx);
+        hipEvent_t done[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (int k = 7; k >= 0 && !rc; --k) {
+            aux_wait(done[k + 2]);           // the weight gradients of block k+2 have read the buffers this block overwrites
             const int st = k / 2, unit = k % 2 + 1;
             const int cout = RS_C[st], cin = (unit == 1 && st > 0) ? RS_C[st - 1] : cout;
             const bool first = unit == 1 && st > 0;
@@ -254,24 +281,27 @@ struct Bwd : Fwd {
             const float* y2 = c->p("t:y2:" + ks); const float* out = c->p("t:out:" + ks);
             float* A = c->p(std::string(k & 1 ? "t:A1" : "t:A0") + sfx);
             float* Z = c->p(std::string(k & 1 ? "t:Z1" : "t:Z0") + sfx);
+            float* DY = c->p(std::string(k & 1 ? "t:DYc1" : "t:DYc0") + sfx);       // dy of conv_2
+            float* DY1 = c->p(std::string(k & 1 ? "t:DYd1" : "t:DYd0") + sfx);      // dy of conv_1
             const int li1 = 1 + 2 * k, li2 = 2 + 2 * k;
             // out = relu(bn2(y2) + shortcut)
             bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z);
             wgrad("wgrad:" + pfx + "/conv_2", wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_2/weights"));
             dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA);
             // a1 = relu(bn1(y1))
-            bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY, nullptr);
+            bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr);
             if (first) {
-                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
-                dgrad_strided(pfx + "/conv_1", DY, Ho, Wo, cout, 3, 3, 2, 2, H, W, cin, A, cin);
+                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
                 wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));
+                dgrad_strided(pfx + "/conv_1", DY1, Ho, Wo, cout, 3, 3, 2, 2, H, W, cin, A, cin);
                 dgrad_strided(pfx + "/shortcut", Z, Ho, Wo, cout, 1, 1, 2, 2, H, W, cin, S, cin);
                 gb = S;
             } else {
-                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_1/weights"));
-                dgrad_s1(pfx + "/conv_1", DY, H, W, cout, cin, A);
+                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_1/weights"));
+                dgrad_s1(pfx + "/conv_1", DY1, H, W, cout, cin, A);
                 gb = Z;
             }
+            done[k] = aux_mark();
             ga = A;
         }
         if (rc) return;
@@ -285,8 +315,10 @@ struct Bwd : Fwd {
         // 7x7/2 over the zero-bordered 4-channel frame: the 7 (+1 zero) horizontal taps x 4 channels are 32 contiguous floats
         WgradDesc w = wdesc(c->p("xpad" + sfx), 229, 454, 4, 32, dz0, 112, 224, 64, 64, 7, 1, 2, 2, 0, 0);
         wgrad("wgrad:" + name, w, c->p("t:stemtmp" + sfx));
-        layer = "wgrad:" + name;
-        timed("stem_wgrad_unpack_kernel", 0.0, [&] { return stem_wgrad_unpack_launch(c->p("t:stemtmp" + sfx), grad(name + "/weights"), s); });
+        Bwd& u = wg ? *wg : *this;              // (on the stream the stem's weight gradient ran on)
+        u.layer = "wgrad:" + name;
+        u.timed("stem_wgrad_unpack_kernel", 0.0, [&] { return stem_wgrad_unpack_launch(c->p("t:stemtmp" + sfx), grad(name + "/weights"), u.s); });
+        if (u.rc) rc = u.rc;
     }
 
     // ---- everything after the loss ----
@@ -328,7 +360,11 @@ struct Bwd : Fwd {
             const float* ddm = c->p("t:ddmask");
             relu_bwd("bias:" + name, ddm, nsep, nullptr, 0, nullptr, 0, nullptr, 0, (long)B * 31 * 1024, nsep, name + "/biases");
             // live grid rows 10..16 of cat1 <-> buffer rows 4*i' + p (virtual rows 40..70)
-            WgradDesc w = wdesc(ddm, 31, 1024, nsep, nsep, c->p("cat1") + (size_t)10 * 127 * 64, 7, 127, 64, 64, 7, 16, 4, 8, 0, 0);
+            // (with fewer than 64 tracks, 64 / nsep neighbouring horizontal taps are folded into the channel index: neighbouring
+            // pixels of the gradient are contiguous, [tw][track] is the variable's own order, and the 64-row tile is full)
+            const int fold = (nsep < 64 && 64 % nsep == 0 && 16 % (64 / nsep) == 0) ? 64 / nsep : 1;
+            WgradDesc w = wdesc(ddm, 31, 1024, nsep, nsep * fold, c->p("cat1") + (size_t)10 * 127 * 64, 7, 127, 64, 64, 7, 16 / fold, 4, 8, 0, 0);
+            w.tsw = fold;
             w.d_bstride = 31u * 127u * 64u;
             wgrad("wgrad:" + name, w, grad(name + "/weights"));
             int Ho, Wo;
@@ -484,7 +520,11 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     b.timed("stft_loss_grad_kernel", 0.0, [&] { return stft_loss_grad_launch(pred, target, mask, c->B, c->p("t:dpred"), loss, s); });
     if (b.rc) return b.rc;
     if (loss_out) SAGEN_HIP_CHECK(hipMemcpyAsync(loss_out, loss, sizeof(double), hipMemcpyDeviceToDevice, s));
+    static const bool one_stream = getenv("SAGEN_BWD_ONE_STREAM") != nullptr;
+    Bwd w(c, c->aux);
+    if (c->aux && !one_stream && !c->tuning) b.wg = &w;
     b.run();
+    if (b.wg) b.aux_wait(b.aux_mark());          // join: the gradients are complete when the caller's stream gets here
     if (b.rc) return b.rc;
     if (update_moving) {
         // contrib batch_norm update ops (core.py:210, decay 0.99; run with the train op through UPDATE_OPS, train.py:147-148)

@@ -24,7 +24,7 @@
 //    2r + ti), so one ds_read_b64 feeds both sub-tiles; the epilogue undoes the permutation;
 //  * pixel ranges (split-K) write raw partials, reduced by splitk_reduce_kernel in a fixed order (deterministic gradients);
 //    the block index is remapped so that the tiles of one pixel range share an XCD (L2).
-#include "igemm_common.h"
+#include "igemm3_common.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradDesc d) {
     const int tg = rem / tiles_d, td = rem - tg * tiles_d;
     const int th = tap / d.TW, tw = tap - th * d.TW;
     const int g0 = tg * BM, d0 = td * BN;
-    const int roff = th + d.h0, coff = tw + d.w0;
+    const int roff = th * d.tsh + d.h0, coff = tw * d.tsw + d.w0;
 
     const int nchunks = (d.P + BK - 1) / BK;
     const int per_z = (nchunks + d.splitk - 1) / d.splitk;
@@ -209,6 +209,203 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradDesc d) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// wgrad3_kernel: the same contraction on the bf16 matrix cores, fp32-equivalent by the 3-way operand split of igemm3.hip
+// (six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulate): 16x the matrix rate of the exact kernel above.
+// The obstacle is the operand layout: the bf16 MFMA wants, per lane, 8 CONSECUTIVE k (= pixels) of one channel, and NHWC has
+// the channels contiguous.  gfx950's LDS transpose read resolves it without any shuffling: the planes are kept in LDS in the
+// natural [pixel][channel] order (each thread splits the 4 channels of one pixel it loaded - one 16-byte load, one 8-byte
+// ds_write per plane) and ds_read_b64_tr_b16 delivers the column-major fragment.  Its lane mapping, measured on MI355X
+// (tools/probe/tr16.py): in every 16-lane group, source lane q hands in 4 contiguous elements, row q/4, columns 4(q%4)..+3 of a
+// 4 x 16 block; destination lane c receives column c, rows 0..3.  So the group (lane>>4) = (k-group g, channel half h) fetches
+// pixels 8g+4r .. +3 (r = 0, 1: two reads make the 8-deep fragment) x channels 16h .. 16h+15 of the 32-row MFMA tile.
+// Plane rows are padded by 64 bytes so that the four pixel rows of a read fall into four different 64-byte bank ranges.
+// Two LDS stages; the global loads of chunk t+2 are in flight while chunk t is contracted and chunk t+1 is split / stored.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int row_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * row_bytes));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+#else
+    return bf16x8{};
+#endif
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradDesc d) {
+    constexpr int BK = 16;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;        // bytes per pixel row of one plane (64 B of padding: bank spread)
+    constexpr int PLA = BK * RSA, PLB = BK * RSB;
+    constexpr int ST = 3 * (PLA + PLB);
+    constexpr int A_CPR = BM / 4, B_CPR = BN / 4;              // float4 chunks per pixel row
+    constexpr int A_RPP = 256 / A_CPR, B_RPP = 256 / B_CPR;    // pixel rows per pass of the 256 threads
+    constexpr int A_PT = BK / A_RPP, B_PT = BK / B_RPP;        // loads per thread and chunk
+    __shared__ __attribute__((aligned(16))) char smem[2 * ST];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntaps = d.TH * d.TW;
+    const int tiles_g = (d.Cg + BM - 1) / BM, tiles_d = (d.Cd + BN - 1) / BN;
+    const int ntile = ntaps * tiles_g * tiles_d;
+    int n;
+    {
+        const int gm = gridDim.x, bid = blockIdx.x;
+        const int q = gm >> 3, r = gm & 7, xcd = bid & 7, j = bid >> 3;
+        n = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int z = n / ntile;
+    int rem = n - z * ntile;
+    const int tap = rem / (tiles_g * tiles_d);
+    rem -= tap * (tiles_g * tiles_d);
+    const int tg = rem / tiles_d, td = rem - tg * tiles_d;
+    const int th = tap / d.TW, tw = tap - th * d.TW;
+    const int g0 = tg * BM, d0 = td * BN;
+    const int roff = th * d.tsh + d.h0, coff = tw * d.tsw + d.w0;
+
+    const int nchunks = (d.P + BK - 1) / BK;
+    const int per_z = (nchunks + d.splitk - 1) / d.splitk;
+    const int kc0 = z * per_z;
+    const int kc1 = min(nchunks, kc0 + per_z);
+
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.g, 0, d.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.d, 0, d.d_bytes, 0x00020000);
+
+    const unsigned a_cb = (unsigned)(g0 + 4 * (tid % A_CPR)), b_cb = (unsigned)(d0 + 4 * (tid % B_CPR));
+    const unsigned a_cbad = a_cb < (unsigned)d.Cg ? 0u : OOB, b_cbad = b_cb < (unsigned)d.Cd ? 0u : OOB;
+    const int a_kp = tid / A_CPR, b_kp = tid / B_CPR;          // pixel row of pass 0
+    const int a_wofs = a_kp * RSA + (tid % A_CPR) * 8, b_wofs = 3 * PLA + b_kp * RSB + (tid % B_CPR) * 8;
+
+    auto pixel = [&](unsigned p, unsigned& goff, unsigned& doff) {
+        const unsigned r = d.Wd == 1 ? p : __umulhi(p, d.magic_w);
+        const unsigned jj = p - r * (unsigned)d.Wd;
+        const unsigned b = d.Hd == 1 ? r : __umulhi(r, d.magic_h);
+        const unsigned ii = r - b * (unsigned)d.Hd;
+        const bool ok = p < (unsigned)d.P;
+        doff = ok ? (b * d.d_bstride + ii * d.d_rstride + jj * (unsigned)d.ldd) * 4u : OOB;
+        const int gi = (int)ii * d.sh + roff, gj = (int)jj * d.sw + coff;
+        const bool gok = ok && (unsigned)gi < (unsigned)d.HG && (unsigned)gj < (unsigned)d.WG;
+        goff = gok ? (b * d.g_bstride + (unsigned)gi * d.g_rstride + (unsigned)gj * (unsigned)d.ldg) * 4u : OOB;
+    };
+    f32x4 ra[A_PT], rb[B_PT];
+    auto load_chunk = [&](int kc) {
+        const unsigned pbase = (unsigned)kc * BK;
+        if constexpr (BM == BN) {
+#pragma unroll
+            for (int t = 0; t < A_PT; ++t) {
+                unsigned go, dof;
+                pixel(pbase + (unsigned)(a_kp + t * A_RPP), go, dof);
+                ra[t] = bload16(g_rsrc, (go + a_cb * 4u) | a_cbad);
+                rb[t] = bload16(d_rsrc, (dof + b_cb * 4u) | b_cbad);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < A_PT; ++t) {
+                unsigned go, dof;
+                pixel(pbase + (unsigned)(a_kp + t * A_RPP), go, dof);
+                ra[t] = bload16(g_rsrc, (go + a_cb * 4u) | a_cbad);
+            }
+#pragma unroll
+            for (int t = 0; t < B_PT; ++t) {
+                unsigned go, dof;
+                pixel(pbase + (unsigned)(b_kp + t * B_RPP), go, dof);
+                rb[t] = bload16(d_rsrc, (dof + b_cb * 4u) | b_cbad);
+            }
+        }
+    };
+    auto split_store = [&](f32x4 v, char* dst, int plane_bytes) {
+        float a = v[0], b = v[1], c = v[2], e = v[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            u32x2 w;
+            w[0] = split_pair(a, b);
+            w[1] = split_pair(c, e);
+            *reinterpret_cast<u32x2*>(dst + pl * plane_bytes) = w;
+        }
+    };
+    auto store_chunk = [&](int stage) {
+        char* st = smem + stage * ST;
+#pragma unroll
+        for (int t = 0; t < A_PT; ++t) split_store(ra[t], st + a_wofs + t * A_RPP * RSA, PLA);
+#pragma unroll
+        for (int t = 0; t < B_PT; ++t) split_store(rb[t], st + b_wofs + t * B_RPP * RSB, PLB);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addressing: lane group (lane>>4) = 2*g + h; source lane q = lane & 15 hands in row q/4, columns 4*(q%4)..+3
+    const int q = lane & 15, gk = lane >> 5, hh = (lane >> 4) & 1;
+    const int a_foff = (8 * gk + (q >> 2)) * RSA + (wm * WM + 16 * hh + 4 * (q & 3)) * 2;
+    const int b_foff = 3 * PLA + (8 * gk + (q >> 2)) * RSB + (wn * WN + 16 * hh + 4 * (q & 3)) * 2;
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // hh, hm, mh, hl, lh, mm
+
+    const int ntiles = kc1 - kc0;
+    if (ntiles > 0) {
+        load_chunk(kc0);
+        store_chunk(0);
+        if (ntiles > 1) load_chunk(kc0 + 1);
+    }
+    lds_barrier();
+    int stage = 0;
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const char* st = smem + stage * ST;
+        bf16x8 fa[3][MT], fb[3][NT];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[pl][i] = tr_frag(st + a_foff + pl * PLA + i * 64, RSA);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[pl][j] = tr_frag(st + b_foff + pl * PLB + j * 64, RSB);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[tt]][i], fb[TB[tt]][j], acc[i][j], 0, 0, 0);
+        if (kc + 1 < kc1) {
+            store_chunk(stage ^ 1);                    // chunk kc+1: its loads were issued one iteration ago
+            if (kc + 2 < kc1) load_chunk(kc + 2);
+        }
+        lds_barrier();
+        stage ^= 1;
+    }
+
+    // epilogue.  C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int li = lane & 31, kk = lane >> 5;
+    float* out = d.splitk > 1 ? d.ws + (size_t)z * ntaps * d.Cg * d.Cd : d.out;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int g = g0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (g >= d.Cg) continue;
+            float* orow = out + ((size_t)tap * d.Cg + g) * d.Cd;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int dd = d0 + wn * WN + j * 32 + li;
+                if (dd < d.Cd) orow[dd] = acc[i][j][e];
+            }
+        }
+}
+
 // plain reference of the same contraction (one thread per output element, fp64 accumulation): SAGEN_WGRAD_REF=1 routes every
 // weight gradient through it - a debugging aid that isolates the MFMA kernel from the rest of the backward pass
 __global__ __launch_bounds__(256) void wgrad_ref_kernel(const WgradDesc d) {
@@ -223,16 +420,26 @@ __global__ __launch_bounds__(256) void wgrad_ref_kernel(const WgradDesc d) {
     double acc = 0.0;
     for (int b = 0; b < d.B; ++b)
         for (int i = 0; i < d.Hd; ++i) {
-            const int gi = i * d.sh + th + d.h0;
+            const int gi = i * d.sh + th * d.tsh + d.h0;
             if ((unsigned)gi >= (unsigned)d.HG) continue;
             for (int j = 0; j < d.Wd; ++j) {
-                const int gj = j * d.sw + tw + d.w0;
+                const int gj = j * d.sw + tw * d.tsw + d.w0;
                 if ((unsigned)gj >= (unsigned)d.WG) continue;
                 acc += (double)d.g[(size_t)b * d.g_bstride + (size_t)gi * d.g_rstride + (size_t)gj * d.ldg + g] *
                        (double)d.d[(size_t)b * d.d_bstride + (size_t)i * d.d_rstride + (size_t)j * d.ldd + dd];
             }
         }
     d.out[idx] = (float)acc;
+}
+
+// SAGEN_FP32_ONLY / SAGEN_WGRAD_F32: the exact fp32 MFMA kernel; default: the bf16x3 kernel (fp32-equivalent, finite inputs)
+static bool wgrad_exact() {
+    static const bool exact = getenv("SAGEN_FP32_ONLY") != nullptr || getenv("SAGEN_WGRAD_F32") != nullptr;
+    return exact;
+}
+const char* wgrad_kernel_name() {
+    static const bool ref = getenv("SAGEN_WGRAD_REF") != nullptr;
+    return ref ? "wgrad_ref_kernel" : (wgrad_exact() ? "wgrad_kernel" : "wgrad3_kernel");
 }
 
 static unsigned magic_of(int dv) { return dv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1ull); }
@@ -244,7 +451,8 @@ int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats) {
     const long ntile = (long)d.TH * d.TW * cdiv(d.Cg, bm) * cdiv(d.Cd, bn);
     const long P = (long)d.B * d.Hd * d.Wd;
     const long nchunks = (P + 15) / 16;
-    long sk = std::max<long>(1, std::min<long>((1024 + ntile - 1) / ntile, nchunks / 8));
+    // ~1024 workgroups (two rounds of the 2-per-CU slots for the 128x128 tile, never a thin third one), >= 8 chunks per range
+    long sk = std::max<long>(1, std::min<long>(1024 / ntile, nchunks / 8));
     const size_t per = (size_t)d.TH * d.TW * d.Cg * d.Cd;
     while (sk > 1 && sk * per > ws_capacity_floats) --sk;
     return (int)std::min<long>(sk, 256);
@@ -278,10 +486,17 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
     const long blocks = (long)d.TH * d.TW * cdiv(d.Cg, bm) * cdiv(d.Cd, bn) * d.splitk;
     if (blocks >= (1L << 30)) return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: grid too large");
     const dim3 grid((unsigned)blocks);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, d);
-    else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, s, d);
-    else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, d);
+    if (wgrad_exact()) {
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, d);
+        else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, s, d);
+        else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, d);
+    } else {
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad3_kernel<128, 128>), grid, dim3(256), 0, s, d);
+        else if (bm == 128) hipLaunchKernelGGL((wgrad3_kernel<128, 64>), grid, dim3(256), 0, s, d);
+        else if (bn == 128) hipLaunchKernelGGL((wgrad3_kernel<64, 128>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((wgrad3_kernel<64, 64>), grid, dim3(256), 0, s, d);
+    }
     SAGEN_LAUNCH_CHECK();
     if (d.splitk > 1)
         return splitk_reduce_launch(d.ws, d.splitk, d.TH * d.TW * d.Cg, d.Cd, nullptr, 0, d.out, d.Cd, 1, nullptr, s);

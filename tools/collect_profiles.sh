@@ -2,11 +2,12 @@
 # GPU box: rocprofv3 evidence for bench.py (kernel trace + separate PMC passes; never combined with
 # sys/hip traces).  Outputs under gpurun_out/prof_<tag>/ ; tools/summarize_profiles.py digests them.
 TAG=${1:-r01}
+CFG=${2:-av}          # bench configuration: av (headline) | train | ...
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 # tune once OUTSIDE the profiler, then replay the saved plan so the traces hold steady-state launches only
-python $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 --plan-file $O/plan.json > $O/tune.log 2>&1
-BENCH="python $R/bench.py --no-cpu-baseline --plan-file $O/plan.json"
+python $R/bench.py --no-cpu-baseline --config $CFG --steps 2 --warmup 1 --plan-file $O/plan.json > $O/tune.log 2>&1
+BENCH="python $R/bench.py --no-cpu-baseline --config $CFG --plan-file $O/plan.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH --steps 20 --warmup 5 > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $BENCH --steps 2 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $BENCH --steps 2 --warmup 1 > $O/write.log 2>&1

@@ -19,7 +19,7 @@ with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns'])
     rows = [r for r in rows if not r['Name'].startswith('Cijk_')]      # the host's stream-concurrency probe (torch.mm), not the path
-    for r in rows[:30]:
+    for r in rows[:45]:
         w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], '%.1f' % float(r['AverageNs']), r['Percentage'], r['MinNs'], r['MaxNs']])
 
 # 2. PMC passes: per-kernel mean of each counter
@@ -63,11 +63,21 @@ for k, v in traffic.items():
         wsum[base][1] += n
 for base, (tot, n) in wsum.items():
     label[base] = round(tot / n)
-json.dump(label, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
+# the training step labels all weight-gradient instantiations "wgrad3_kernel" / "wgrad_kernel": launch-weighted mean
+for pfx in ('wgrad3_kernel', 'wgrad_kernel'):
+    tot = n = 0.0
+    for k, v in traffic.items():
+        if k.startswith(pfx + '<'):
+            m = keep[k].get('launches_fetch', 1)
+            tot += v['hbm_bytes_fetch_x2'] * m; n += m
+    if n:
+        label[pfx] = round(tot / n)
+is_train = any(k.startswith('wgrad') for k in traffic)
+json.dump(label, open(os.path.join(dst, 'pmc_traffic_train.json' if is_train else 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 b = os.path.join(src, 'bench_under_trace.json')
 if os.path.exists(b):
     open(os.path.join(dst, tag + '_bench_under_rocprof.json'), 'w').write(open(b).read())
 print(open(os.path.join(dst, tag + '_kernel_stats.csv')).read())
 for k, v in sorted(keep.items()):
-    if 'igemm' in k or 'conv3p' in k or 'p3_' in k:
+    if 'igemm' in k or 'conv3p' in k or 'p3_' in k or 'wgrad' in k or 'bwd' in k:
         print(k, {c: ('%.4g' % x) for c, x in v.items() if not c.startswith('launches')})
