@@ -142,6 +142,10 @@ int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, i
                         hipStream_t s);
 // uint8 frames -> normalised (x/255 - 0.5) zero-bordered 4-channel fp32
 int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s);
+// ResNet stem + max-pool fused for inference (stempool.hip): 7x7/2 conv over the zero-bordered 4-channel frame, batch statistics
+// of the raw output, and the 3x3/2 pool of the RAW output taken as max or min per channel by the sign of gamma; the elementwise
+// BN + ReLU then runs on the pooled tensor.  wp = the stem's packed filter + planes; pooled [B,56,112,64]; stats fp64 [2][64].
+int stempool_launch(const float* xpad, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);

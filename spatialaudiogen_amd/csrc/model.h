@@ -92,6 +92,7 @@ struct sagen_ctx {
     // gradient activations, data-gradient filter packs, fp64 accumulators.  `train_mode` makes the forward retain.
     bool train_mode = false;
     bool train_ready = false;
+    bool stem_fused = true;                // inference: 7x7/2 stem + max-pool as one kernel (stempool.hip); SAGEN_NO_STEMPOOL=1 disables
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
     size_t tws_floats = 0;
     float* tws = nullptr;
@@ -458,6 +459,18 @@ struct Fwd {
         }
         {
             const std::string name = scope + "/conv1/conv";
+            const bool fused = c->stem_fused && !c->tuning && !c->fp32_only && !(c->use_p3 && c->p3_from_stage <= 2);
+            if (fused) {
+                // conv + statistics + pool of the RAW output in one kernel (max or min per channel by the sign of gamma), then BN + ReLU on
+                // the pooled tensor in place: relu(bn(.)) is monotone per channel, so this IS maxpool(relu(bn(conv))) (stempool.hip)
+                H = 112; W = 224;
+                layer = name + "+pool";
+                timed("stempool_kernel", 2.0 * B * H * W * 64 * 224, [&] {
+                    return stempool_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });
+                const BnRef bnf = bn_ref(li, name, (long)B * H * W);
+                layer = name + "/bn-relu";
+                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, c->p("rx0" + sfx), (long)B * 56 * 112, 64, s); });
+            } else {
             IgemmDesc d = conv_desc(c->p("xpad" + sfx), 229, 454, 4, 4, c->p("pk:" + name + "/weights"), 7, 8, 2, 2, false, 64,
                                     c->p("y0" + sfx), 64, H, W);
             d.stats = bn_acc(li);
@@ -468,6 +481,7 @@ struct Fwd {
                 timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s); });
             else
                 timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
+            }
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
         }

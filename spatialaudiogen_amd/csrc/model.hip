@@ -33,6 +33,9 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
     c->use_p3 = !c->fp32_only && getenv("SAGEN_NO_P3") == nullptr;
     if (const char* e = getenv("SAGEN_P3_FROM_STAGE")) c->p3_from_stage = atoi(e);
+    // fused stem + pool (stempool.hip): +0.8 % for a host that runs one forward at a time; with several batches in flight
+    // (SAGEN_ONE_STREAM=1 hosts, bench.py) its one-workgroup-per-CU LDS footprint blocks co-residency and it is a wash (-0.3 %)
+    c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;

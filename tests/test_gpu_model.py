@@ -247,3 +247,39 @@ def test_uint8_video_entry_point_is_bit_identical(T):
     b = net.inference_ops(inp['audio'], u8).cpu().numpy()
     c = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
     assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_fused_stem_pool_with_negative_gammas(T):
+    """stempool_kernel pools the RAW stem output with max or min per channel by the sign of gamma (relu(bn(.)) is monotone per
+    channel).  Half of the stem's gammas negative, one exactly zero: same bar against the oracle, and the same result as the unfused
+    stem + pool kernels (SAGEN_NO_STEMPOOL=1, in a subprocess) to rounding."""
+    import os, subprocess, sys, tempfile
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=6, mode='test')
+    g = P['video_encoder/conv1/conv/bn/gamma'].copy()
+    g[::2] *= -1.0
+    g[5] = 0.0
+    P['video_encoder/conv1/conv/bn/gamma'] = g
+    inp = synth_inputs(3, enc, seed=55)
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+    check_out(got, ref)
+    t = net.intermediate(3, 'video_encoder/conv5_2').cpu().numpy()
+    assert rel_rms_err(t, orc.ends['video_encoder/conv5_2']) < 1e-4
+    fn = tempfile.mktemp(suffix='.npz')
+    np.savez(fn, **{k.replace('/', '|'): v for k, v in P.items()})
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from spatialaudiogen_amd.model import SptAudioGen\n"
+            "from spatialaudiogen_amd.weights import synth_inputs\n"
+            "P = {k.replace('|', '/'): v for k, v in np.load(%r).items()}\n"
+            "inp = synth_inputs(3, ['audio', 'video'], seed=55)\n"
+            "net = SptAudioGen(1, encoders=['audio', 'video'], separation='unet_mask'); net.load_variables(P)\n"
+            "np.save(%r, net.inference_ops(inp['audio'], inp['video']).cpu().numpy())\n") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), fn, fn + '.out.npy')
+    subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, SAGEN_NO_STEMPOOL='1'), timeout=600)
+    unfused = np.load(fn + '.out.npy')
+    assert rms(got - unfused) <= 2e-5 * max(rms(unfused), 1e-9) + 1e-6
