@@ -304,7 +304,9 @@ def main():
     is_eval = args.config == 'eval'
     # eval: a pool of distinct synthetic windows stands in for the 9216 windows of the clip set (window w of the global order
     # uses pool entry w % pool); the other configurations: each rank owns one batch of its own windows
-    POOL = 4 * BATCH if is_eval else BATCH
+    # (the other configurations cycle over three distinct batches of this rank's own windows: no step re-reads the inputs of the one before)
+    NPOOL = 4 if is_eval else 3
+    POOL = NPOOL * BATCH
     inp = synth_inputs(POOL, ENCODERS, seed=1234 + (0 if is_eval else rank))
     # Steps are independent batches, so NF of them are kept in flight: step i runs on native context i % NF and stream
     # i % NF (each context has its own workspace and its own second stream).  Every step is still one full forward of
@@ -335,7 +337,7 @@ def main():
         my_batches = list(range(lo_b, hi_b))
         steps = min(args.steps, len(my_batches)) if args.steps > 0 else len(my_batches)
     else:
-        my_batches, steps = [rank], args.steps
+        my_batches, steps = list(range(NPOOL)), args.steps
 
     def run_step(j, b, ctx_nets, ctx_outs):
         """one forward (+ metrics in eval mode) of global batch b on context j (current stream)"""
@@ -538,7 +540,8 @@ def main():
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None,
         'dtype': 'f32 (products on the bf16 matrix cores as a 3-way bf16 operand split, 6 products per multiply, fp32 accumulate '
                  '- fp32-equivalent, parity bar 1e-4 RMS unchanged; SAGEN_FP32_ONLY=1 selects the exact fp32 MFMA kernels)',
-        'data': 'synthetic' + (' (pool of %d distinct windows cycled over the %d x %d window set)' % (POOL, EVAL_CLIPS, EVAL_WINDOWS_PER_CLIP) if is_eval else ''),
+        'data': 'synthetic' + (' (pool of %d distinct windows cycled over the %d x %d window set)' % (POOL, EVAL_CLIPS, EVAL_WINDOWS_PER_CLIP) if is_eval else
+                               ' (%d distinct resident batches per GPU, cycled)' % NPOOL),
         'config': {'workload': cfg['workload'], 'name': args.config,
                    'windows_per_gpu_per_step': BATCH, 'windows_per_s': round(windows / elapsed, 1),
                    'sharding': ('whole batches of the global window order over ranks (%d batches in total, %d timed on this rank); '

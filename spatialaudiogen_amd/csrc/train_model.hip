@@ -64,6 +64,7 @@ static void train_carve(sagen_ctx* c) {
     c->talloc("t:cacc", (size_t)CACC_SLOTS * CACC_SLOT * 2);
     c->talloc("t:wgws", WGWS_FLOATS);
     c->talloc("t:redws", reduce_scratch_floats(1024));
+    c->talloc("t:redws2", reduce_scratch_floats(1024));       // ... of the launcher on the second stream
     c->talloc("t:ddmask", (size_t)B * 31 * 1024 * nsep);
     c->talloc("t:mbw", mask_istft_bwd_scratch_floats(B, nsep));
     c->talloc("t:dcoeffs", (size_t)B * 3 * ldc);
@@ -140,6 +141,7 @@ static int repack_dgrad(sagen_ctx* c, hipStream_t s) {
 
 struct Bwd : Fwd {
     int cslot = 0;
+    std::string redws = "t:redws";                                // scratch of this launcher's channel reductions
     bool split_ok = getenv("SAGEN_BWD_NOSPLIT") == nullptr;      // debugging: no split-K in the data-gradient contractions
     Bwd(sagen_ctx* ctx, hipStream_t st) { c = ctx; s = st; }
 
@@ -156,7 +158,7 @@ struct Bwd : Fwd {
         layer = label;
         double* acc = bias_var.empty() ? nullptr : cacc_next();
         if (rc) return;
-        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p("t:redws"), s); });
+        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p(redws), s); });
         if (acc) timed("acc_to_f32_kernel", 0.0, [&] { return acc_to_f32_launch(acc, grad(bias_var), C, s); });
     }
 
@@ -256,7 +258,7 @@ struct Bwd : Fwd {
         const BnRef bn = bn_ref(li, bn_name, npix);
         double* acc = bnb_acc(li);
         layer = "bnbwd:" + bn_name;
-        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, act, y, bn, npix, C, acc, c->p("t:redws"), s); });
+        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, act, y, bn, npix, C, acc, c->p(redws), s); });
         timed("bn_bwd_apply_kernel", 0.0, [&] {
             return bn_bwd_apply_launch(ga, gb, act, y, bn, acc, npix, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s); });
     }
@@ -409,26 +411,36 @@ struct Bwd : Fwd {
             wgrad("wgrad:bottleneck/audio-fc", w, grad("bottleneck/audio-fc/weights"));
             dgrad_fc("bottleneck/audio-fc", dy, 1024, B * 3, 1024, 3072, c->p("t:g:conv5_fc"), 3072);
         }
-        // audio encoder (model.py:161-187), conv5 .. conv1
-        for (int l = 5; l >= 1 && !rc; --l) {
-            const std::string name = "audio_encoder/conv" + std::to_string(l);
-            const int C = c->enc_c[l], H = c->enc_h[l], W = c->enc_w[l];
-            const int off = l == 5 ? 0 : C;
-            const float* ga = c->p("t:dcat" + std::to_string(l)) + off;
-            const float* gb2 = l == 5 ? c->p("t:g:conv5_fc") : c->p("t:g:conv" + std::to_string(l));
-            float* dy = c->p("t:dy:conv" + std::to_string(l));
-            relu_bwd("relu:" + name, ga, 2 * C, gb2, C, c->p("cat" + std::to_string(l)) + off, 2 * C, dy, C, (long)B * H * W, C, name + "/biases");
-            const int kh = AENC_K[l - 1][0], kw = AENC_K[l - 1][1], sh = AENC_S[l - 1][0], sw = AENC_S[l - 1][1];
-            if (l == 1) {
-                // Cin = 1: the 16 taps along frequency are 16 contiguous floats of the magnitude row (pixel stride 1 float)
-                WgradDesc w = wdesc(c->p("mag"), 127, 1024, 1, kw, dy, H, W, C, C, kh, 1, sh, sw, 0, 0);
-                wgrad("wgrad:" + name, w, grad(name + "/weights"));
-            } else {
-                const int Cp = c->enc_c[l - 1], Hp = c->enc_h[l - 1], Wp = c->enc_w[l - 1];
-                const float* x = c->p("cat" + std::to_string(l - 1)) + Cp;            // encoder half of cat_{l-1}
-                wgrad("wgrad:" + name, wdesc(x, Hp, Wp, 2 * Cp, Cp, dy, H, W, C, C, kh, kw, sh, sw, 0, 0), grad(name + "/weights"));
-                dgrad_strided(name, dy, H, W, C, kh, kw, sh, sw, Hp, Wp, Cp, c->p("t:g:conv" + std::to_string(l - 1)), Cp);
+        // audio encoder (model.py:161-187), conv5 .. conv1.  Nothing on the way to the visual trunk depends on it: with a second
+        // stream the whole chain (ReLU / bias passes, weight gradients, strided data gradients - small launches that fill a fraction of
+        // the chip) runs there, under the trunk's backward on the main stream.
+        {
+            Bwd& a = wg ? *wg : *this;
+            if (wg) {
+                hipEvent_t e = next_event();
+                if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(wg->s, e, 0) != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "stream fork failed"); return; }
             }
+            for (int l = 5; l >= 1 && !rc && !a.rc; --l) {
+                const std::string name = "audio_encoder/conv" + std::to_string(l);
+                const int C = c->enc_c[l], H = c->enc_h[l], W = c->enc_w[l];
+                const int off = l == 5 ? 0 : C;
+                const float* ga = c->p("t:dcat" + std::to_string(l)) + off;
+                const float* gb2 = l == 5 ? c->p("t:g:conv5_fc") : c->p("t:g:conv" + std::to_string(l));
+                float* dy = c->p("t:dy:conv" + std::to_string(l));
+                a.relu_bwd("relu:" + name, ga, 2 * C, gb2, C, c->p("cat" + std::to_string(l)) + off, 2 * C, dy, C, (long)B * H * W, C, name + "/biases");
+                const int kh = AENC_K[l - 1][0], kw = AENC_K[l - 1][1], sh = AENC_S[l - 1][0], sw = AENC_S[l - 1][1];
+                if (l == 1) {
+                    // Cin = 1: the 16 taps along frequency are 16 contiguous floats of the magnitude row (pixel stride 1 float)
+                    WgradDesc w = wdesc(c->p("mag"), 127, 1024, 1, kw, dy, H, W, C, C, kh, 1, sh, sw, 0, 0);
+                    a.wgrad_here("wgrad:" + name, w, grad(name + "/weights"));
+                } else {
+                    const int Cp = c->enc_c[l - 1], Hp = c->enc_h[l - 1], Wp = c->enc_w[l - 1];
+                    const float* x = c->p("cat" + std::to_string(l - 1)) + Cp;            // encoder half of cat_{l-1}
+                    a.wgrad_here("wgrad:" + name, wdesc(x, Hp, Wp, 2 * Cp, Cp, dy, H, W, C, C, kh, kw, sh, sw, 0, 0), grad(name + "/weights"));
+                    a.dgrad_strided(name, dy, H, W, C, kh, kw, sh, sw, Hp, Wp, Cp, c->p("t:g:conv" + std::to_string(l - 1)), Cp);
+                }
+            }
+            if (a.rc) rc = a.rc;
         }
         // visual encoders: bottleneck FCs (video-fc tiled over the 3 steps), then the trunk
         int choff = 1024;
@@ -522,6 +534,7 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     if (loss_out) SAGEN_HIP_CHECK(hipMemcpyAsync(loss_out, loss, sizeof(double), hipMemcpyDeviceToDevice, s));
     static const bool one_stream = getenv("SAGEN_BWD_ONE_STREAM") != nullptr;
     Bwd w(c, c->aux);
+    w.redws = "t:redws2"; w.cslot = CACC_SLOTS / 2; w.wsname = "splitk_aux";      // its own scratch: it runs concurrently with `b`
     if (c->aux && !one_stream && !c->tuning) b.wg = &w;
     b.run();
     if (b.wg) b.aux_wait(b.aux_mark());          // join: the gradients are complete when the caller's stream gets here

@@ -26,6 +26,11 @@
 //    the block index is remapped so that the tiles of one pixel range share an XCD (L2).
 #include "igemm3_common.h"
 #include <algorithm>
+#ifdef SAGEN_WGRAD_MUL32          // dev builds: 32-bit index multiplies (A/B of the 24-bit ones)
+#define WG_MUL(a, b) ((a) * (b))
+#else
+#define WG_MUL(a, b) __umul24((a), (b))
+#endif
 #include <cstdlib>
 
 namespace sagen {
@@ -88,15 +93,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradDesc d) {
 
     // pixel p -> byte offsets of its D row and of its (tap-displaced) G row; OOB when outside
     auto pixel = [&](unsigned p, unsigned& goff, unsigned& doff) {
+        // every factor is < 2^24 (wgrad_launch checks): 24-bit multiplies are full rate, 32-bit ones quarter rate - 20 of them per
+        // K step were a third of this kernel's VALU time
         const unsigned r = d.Wd == 1 ? p : __umulhi(p, d.magic_w);
-        const unsigned jj = p - r * (unsigned)d.Wd;
+        const unsigned jj = p - WG_MUL(r, (unsigned)d.Wd);
         const unsigned b = d.Hd == 1 ? r : __umulhi(r, d.magic_h);
-        const unsigned ii = r - b * (unsigned)d.Hd;
+        const unsigned ii = r - WG_MUL(b, (unsigned)d.Hd);
         const bool ok = p < (unsigned)d.P;
-        doff = ok ? (b * d.d_bstride + ii * d.d_rstride + jj * (unsigned)d.ldd) * 4u : OOB;
-        const int gi = (int)ii * d.sh + roff, gj = (int)jj * d.sw + coff;
+        doff = ok ? (WG_MUL(b, d.d_bstride) + WG_MUL(ii, d.d_rstride) + WG_MUL(jj, (unsigned)d.ldd)) * 4u : OOB;
+        const int gi = (int)WG_MUL(ii, (unsigned)d.sh) + roff, gj = (int)WG_MUL(jj, (unsigned)d.sw) + coff;
         const bool gok = ok && (unsigned)gi < (unsigned)d.HG && (unsigned)gj < (unsigned)d.WG;
-        goff = gok ? (b * d.g_bstride + (unsigned)gi * d.g_rstride + (unsigned)gj * (unsigned)d.ldg) * 4u : OOB;
+        goff = gok ? (WG_MUL(b, d.g_bstride) + WG_MUL((unsigned)gi, d.g_rstride) + WG_MUL((unsigned)gj, (unsigned)d.ldg)) * 4u : OOB;
     };
     auto begin_issue = [&](int kc, int stage) {
         i_stage = stage;
@@ -229,9 +236,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p, int row_bytes) {
     typedef __attribute__((address_space(3))) s16x4* lds_p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * row_bytes));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    // (a plain concatenation: element-wise construction of the 8 x 16-bit vector cost 120 v_mov per K step)
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #else
     return bf16x8{};
 #endif
@@ -287,15 +293,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradDesc d) {
     const int a_wofs = a_kp * RSA + (tid % A_CPR) * 8, b_wofs = 3 * PLA + b_kp * RSB + (tid % B_CPR) * 8;
 
     auto pixel = [&](unsigned p, unsigned& goff, unsigned& doff) {
+        // every factor is < 2^24 (wgrad_launch checks): 24-bit multiplies are full rate, 32-bit ones quarter rate - 20 of them per
+        // K step were a third of this kernel's VALU time
         const unsigned r = d.Wd == 1 ? p : __umulhi(p, d.magic_w);
-        const unsigned jj = p - r * (unsigned)d.Wd;
+        const unsigned jj = p - WG_MUL(r, (unsigned)d.Wd);
         const unsigned b = d.Hd == 1 ? r : __umulhi(r, d.magic_h);
-        const unsigned ii = r - b * (unsigned)d.Hd;
+        const unsigned ii = r - WG_MUL(b, (unsigned)d.Hd);
         const bool ok = p < (unsigned)d.P;
-        doff = ok ? (b * d.d_bstride + ii * d.d_rstride + jj * (unsigned)d.ldd) * 4u : OOB;
-        const int gi = (int)ii * d.sh + roff, gj = (int)jj * d.sw + coff;
+        doff = ok ? (WG_MUL(b, d.d_bstride) + WG_MUL(ii, d.d_rstride) + WG_MUL(jj, (unsigned)d.ldd)) * 4u : OOB;
+        const int gi = (int)WG_MUL(ii, (unsigned)d.sh) + roff, gj = (int)WG_MUL(jj, (unsigned)d.sw) + coff;
         const bool gok = ok && (unsigned)gi < (unsigned)d.HG && (unsigned)gj < (unsigned)d.WG;
-        goff = gok ? (b * d.g_bstride + (unsigned)gi * d.g_rstride + (unsigned)gj * (unsigned)d.ldg) * 4u : OOB;
+        goff = gok ? (WG_MUL(b, d.g_bstride) + WG_MUL((unsigned)gi, d.g_rstride) + WG_MUL((unsigned)gj, (unsigned)d.ldg)) * 4u : OOB;
     };
     f32x4 ra[A_PT], rb[B_PT];
     auto load_chunk = [&](int kc) {
@@ -470,6 +478,10 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
     const long gb = ((long)(d.B - 1) * d.g_bstride + (long)d.HG * d.g_rstride) * 4 + 64, db = ((long)(d.B - 1) * d.d_bstride + (long)d.Hd * d.d_rstride) * 4 + 64;
     if (gb >= (1L << 31) || db >= (1L << 31) || P >= (1L << 24) || (long)P * d.Wd >= (1L << 32))
         return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: operand exceeds 2 GiB buffer addressing / 2^24 pixels (use a smaller batch)");
+    const unsigned lim = 1u << 24;
+    if (d.g_bstride >= lim || d.g_rstride >= lim || d.d_bstride >= lim || d.d_rstride >= lim || (unsigned)d.ldg >= lim || (unsigned)d.ldd >= lim ||
+        (unsigned)d.HG >= lim || (unsigned)d.WG >= lim)
+        return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: a stride / extent exceeds 2^24 (24-bit index multiplies)");
     d.P = (int)P;
     d.g_bytes = (unsigned)gb; d.d_bytes = (unsigned)db;
     d.magic_w = magic_of(d.Wd); d.magic_h = magic_of(d.Hd);
