@@ -27,7 +27,7 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 // per-channel partials, part[block][NV][C]; partials_finish_kernel then adds the rows in a fixed order in fp64 (deterministic,
 // and no same-address atomic chains: 4096 workgroups x 128 fp64 atomics on 128 addresses took 300 us per batch-norm layer).
 // Requires 256 % C4 == 0 (thread t owns channels 4*(t % C4)).
-constexpr int RED_MAX_BLOCKS = 2048;
+constexpr int RED_MAX_BLOCKS = 512;
 template <int NV>
 __device__ __forceinline__ void channel_partials(const float4 (&v)[NV], int C4, float* part) {
     __shared__ float4 red[NV][256];
@@ -45,26 +45,35 @@ __device__ __forceinline__ void channel_partials(const float4 (&v)[NV], int C4, 
     }
 }
 
-// acc[i] = sum_b part[b][i] (fp64), i < n: 32 columns x 8 row slices per workgroup
-__global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ part, int nblocks, int n, double* __restrict__ acc) {
-    __shared__ double red[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + cl;
+// acc[i] = sum_b part[b][i] (fp64), i < n: 8 columns x 32 row slices per workgroup, four rows in flight per thread (a first
+// version with 8 slices and one load in flight walked 256 rows per thread: 60-100 us of pure latency per batch-norm layer)
+__global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ part, int nblocks, int n, double* __restrict__ acc,
+                                                              float* __restrict__ out_f32) {
+    __shared__ double red[32][8];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + cl;
     double s = 0.0;
-    if (i < n)
-        for (int b = sl; b < nblocks; b += 8) s += (double)part[(size_t)b * n + i];
+    if (i < n) {
+        int b = sl;
+        for (; b + 96 < nblocks; b += 128) {
+            const float v0 = part[(size_t)b * n + i], v1 = part[(size_t)(b + 32) * n + i], v2 = part[(size_t)(b + 64) * n + i], v3 = part[(size_t)(b + 96) * n + i];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nblocks; b += 32) s += (double)part[(size_t)b * n + i];
+    }
     red[sl][cl] = s;
     __syncthreads();
     if (sl == 0 && i < n) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        for (int k = 0; k < 32; ++k) t += red[k][cl];
         acc[i] = t;
+        if (out_f32) out_f32[i] = (float)t;
     }
 }
 
 static int reduce_grid(long n4, int C4) {
-    long g = std::min<long>(cdiv(n4, 256 * 4), RED_MAX_BLOCKS);
+    long g = std::min<long>(cdiv(n4, 256 * 8), RED_MAX_BLOCKS);
     g = std::max<long>(g, 1);
     if ((g * 256) % C4) {
         long a = 256, b = C4;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 }
 
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
-                    int C, double* colsum, float* scratch, hipStream_t s) {
+                    int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32) {
     if (!ga || (!dy && !colsum)) return fail(SAGEN_ERR_NULL, "relu_bwd: null argument");
     const int Cp = (C + 3) / 4 * 4;
     if (lda % 4 || (gb && ldb % 4) || (act && ldact % 4) || (dy && lddy % 4) || lda < Cp)
@@ -119,8 +128,10 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, n4, C4, colsum, C, fast ? scratch : nullptr);
     SAGEN_LAUNCH_CHECK();
     if (fast) {
-        hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(Cp, 32)), dim3(256), 0, s, scratch, grid, Cp, colsum);
+        hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(Cp, 8)), dim3(256), 0, s, scratch, grid, Cp, colsum, colsum_f32);
         SAGEN_LAUNCH_CHECK();
+    } else if (colsum && colsum_f32) {
+        return acc_to_f32_launch(colsum, colsum_f32, C, s);
     }
     return SAGEN_OK;
 }
@@ -196,7 +207,7 @@ int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, con
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
                        (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch);
     SAGEN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, s, scratch, grid, 2 * C, acc);
+    hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, s, scratch, grid, 2 * C, acc, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -225,8 +225,9 @@ const char* wgrad_kernel_name();      // "wgrad3_kernel" (bf16x3, default) | "wg
 size_t reduce_scratch_floats(int C);
 // dy[r][c] = (ga[r][c] + gb[r][c]) * (act[r][c] > 0); gb / act / dy nullable; colsum (fp64 [C]) nullable: sum_r dy (overwritten);
 // scratch >= reduce_scratch_floats(C) floats (without it, or for widths that do not divide 256 lanes: fp64 atomics)
+// colsum_f32 (nullable): the sums also as fp32 (the bias gradient at its place in the gradient bucket)
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
-                    int C, double* colsum, float* scratch, hipStream_t s);
+                    int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32 = nullptr);
 // training-mode batch-norm backward (core.py:6,209-210 under tf.gradients).  dz = (ga + gb) * (act > 0) (act nullable);
 // xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat) (overwritten);
 // scratch >= reduce_scratch_floats(C) floats

@@ -158,8 +158,7 @@ struct Bwd : Fwd {
         layer = label;
         double* acc = bias_var.empty() ? nullptr : cacc_next();
         if (rc) return;
-        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p(redws), s); });
-        if (acc) timed("acc_to_f32_kernel", 0.0, [&] { return acc_to_f32_launch(acc, grad(bias_var), C, s); });
+        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p(redws), s, acc ? grad(bias_var) : nullptr); });
     }
 
     WgradDesc wdesc(const float* g, int HG, int WG, int ldg, int Cg, const float* dd, int Hd, int Wd, int ldd, int Cd, int kh, int kw,
