@@ -653,4 +653,85 @@ int pack_deconv_launch(const float* w_hwoi, int kh, int kw, int cout, int cin, i
     return SAGEN_OK;
 }
 
+// -----------------------------------------------------------------------------------------
+// all filter packs of a context in ONE launch (the training step re-packs every filter every step: 110 small launches, 0.9 ms)
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ float pack_source(const PackJob& j, int n, int k) {
+    const float* w = j.src;
+    switch (j.kind) {
+        case PACK_CONV: {          // Wp[n][(tap, c)] = W_hwio[tap][c][n]
+            const int ntaps = j.p[0], cin_src = j.p[1], cin_pad = j.p[2], cout = j.p[3], tw_src = j.p[4], tw_pad = j.p[5];
+            if (n >= cout || k >= ntaps * cin_pad) return 0.f;
+            int tap = k / cin_pad;
+            const int c = k - tap * cin_pad;
+            bool ok = c < cin_src;
+            if (tw_pad > 0) {
+                const int th = tap / tw_pad, tw = tap - th * tw_pad;
+                ok = ok && tw < tw_src;
+                tap = th * tw_src + tw;
+            }
+            return ok ? w[((long)tap * cin_src + c) * cout + n] : 0.f;
+        }
+        case PACK_DECONV: {        // n = (ry, rx, o), k = (dp, dq, c): W[ry + sh*dp][rx + sw*dq][o][c]
+            const int kh = j.p[0], kw = j.p[1], cout = j.p[2], cin = j.p[3], sh = j.p[4], sw = j.p[5], ntw = j.p[6];
+            const int nth = (kh + sh - 1) / sh;
+            if (n >= sh * sw * cout || k >= nth * ntw * cin) return 0.f;
+            const int ry = n / (sw * cout), rx = (n / cout) % sw, o = n % cout;
+            const int tap = k / cin, c = k - tap * cin;
+            const int dp = tap / ntw, dq = tap - dp * ntw;
+            const int pp = ry + sh * dp, q = rx + sw * dq;
+            return (pp < kh && q < kw) ? w[(((long)pp * kw + q) * cout + o) * cin + c] : 0.f;
+        }
+        case PACK_FLIPT: {         // Wp[n = ci][(tap', co)] = W_hwio[ntaps-1-tap'][ci][co]
+            const int ntaps = j.p[0], cin = j.p[1], cout = j.p[2];
+            if (n >= cin || k >= ntaps * cout) return 0.f;
+            const int tap = k / cout, co = k - tap * cout;
+            return w[((long)(ntaps - 1 - tap) * cin + n) * cout + co];
+        }
+        default: {                 // PACK_ROWS: row-major [rows][cols] -> [rows][Kpad]
+            const int rows = j.p[0], cols = j.p[1];
+            return (n < rows && k < cols) ? w[(long)n * cols + k] : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    // job of this block: the last one whose first_block <= blockIdx.x (wave-uniform binary search)
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const long idx = ((long)(blockIdx.x - j.first_block) * 256 + threadIdx.x) * 4;
+    if (idx >= (long)j.N * j.Kpad) return;
+    const int n = (int)(idx / j.Kpad), k = (int)(idx - (long)n * j.Kpad);      // Kpad % 16 == 0: the four elements share the row
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = pack_source(j, n, k + e);
+    *reinterpret_cast<float4*>(j.dst + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    // the three bf16 planes, tiled [Kpad/16][plane][N][16] (same arithmetic as pack_split_kernel, igemm3.hip)
+    __bf16* w3 = reinterpret_cast<__bf16*>(j.dst + (long)j.N * j.Kpad);
+    __bf16 h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        const float r1 = v[e] - (float)h[e];
+        m[e] = (__bf16)r1;
+        l[e] = (__bf16)(r1 - (float)m[e]);
+    }
+    const long o = ((long)(k >> 4) * 3 * j.N + n) * 16 + (k & 15);
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<bf16x4_t*>(w3 + o) = bf16x4_t{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<bf16x4_t*>(w3 + o + (long)j.N * 16) = bf16x4_t{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<bf16x4_t*>(w3 + o + (long)j.N * 32) = bf16x4_t{l[0], l[1], l[2], l[3]};
+}
+
+int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s) {
+    if (!jobs_dev || njobs <= 0 || nblocks <= 0) return fail(SAGEN_ERR_NULL, "pack_multi: no jobs");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 }  // namespace sagen

@@ -90,6 +90,9 @@ struct sagen_ctx {
     std::map<std::string, Named> named;
     // training (train_model.hip): a second caller-provided workspace holds what the backward pass needs - retained activations,
     // gradient activations, data-gradient filter packs, fp64 accumulators.  `train_mode` makes the forward retain.
+    // batched filter packs: job tables (host copies; the device copies live in the workspaces)
+    std::vector<PackJob> pack_jobs, pack_jobs_bwd;
+    int pack_blocks = 0, pack_blocks_bwd = 0;
     bool train_mode = false;
     bool train_ready = false;
     bool stem_fused = true;                // inference: 7x7/2 stem + max-pool as one kernel (stempool.hip); SAGEN_NO_STEMPOOL=1 disables
@@ -186,6 +189,7 @@ static inline int auto_splitk(const IgemmDesc& d, IgemmTile tile) {
 
 
 int sagen_repack_impl(sagen_ctx* c, hipStream_t s);
+int sagen_upload_pack_jobs(std::vector<PackJob>& jobs, void* dev, hipStream_t s);
 int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
 
 namespace sagen {

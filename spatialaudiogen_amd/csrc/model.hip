@@ -120,6 +120,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         }
         c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
     }
+    c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
     // activations
     c->alloc("mag", (size_t)B * 127 * 1024);
     c->alloc("spec", (size_t)B * 28 * 513 * 2);
@@ -204,6 +205,7 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
         if (!ptr[i] && !moving) return fail(SAGEN_ERR_WEIGHTS, "variable %s was not provided", nm.c_str());
     }
     c->var_ptr = ptr;
+    c->pack_jobs.clear();                 // (the table holds the variables' addresses)
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     rc = sagen_repack_impl(c, s);
@@ -214,37 +216,57 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
 
 // repack every filter from the bound variables into the kernels' layouts (bind; and once per training step, after the optimiser
 // has updated the variables in place)
-int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
-    int rc = SAGEN_OK;
-    for (const auto& vs : c->vars) {
-        if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
-        const float* src = c->v(vs.name);
-        float* dst = c->p("pk:" + vs.name);
-        if (vs.name.find("/deconv") != std::string::npos) {
-            const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
-            const int sh = AENC_S[l][0], sw = AENC_S[l][1];
-            const int taps = cdiv(vs.shape[0], sh) * cdiv(vs.shape[1], sw);
-            const int N = sh * sw * (int)vs.shape[2], K = taps * (int)vs.shape[3];
-            rc = pack_deconv_launch(src, (int)vs.shape[0], (int)vs.shape[1], (int)vs.shape[2], (int)vs.shape[3], sh, sw, dst,
-                                    N, (K + 15) / 16 * 16, s);
-            if (!rc) rc = pack_split_launch(dst, N, (K + 15) / 16 * 16, s);
-        } else if (vs.ndim == 4) {
-            int cin = (int)vs.shape[2], cinp = cin == 3 ? 4 : cin, taps = (int)(vs.shape[0] * vs.shape[1]);
-            if (cin == 1) { cin = cinp = (int)vs.shape[1]; taps = (int)vs.shape[0]; }
-            const bool stem = cin == 3;                   // tap rows padded 7 -> 8, K = (dh, dw8, c4)
-            if (stem) taps = (int)(vs.shape[0] * (vs.shape[1] + 1));
-            const int K = taps * cinp;
-            rc = pack_conv_launch(src, taps, cin, cinp, (int)vs.shape[3], dst, (int)vs.shape[3], (K + 15) / 16 * 16, s,
-                                  stem ? (int)vs.shape[1] : 0, stem ? (int)vs.shape[1] + 1 : 0);
-            if (!rc) rc = pack_split_launch(dst, (int)vs.shape[3], (K + 15) / 16 * 16, s);
-        } else {
-            const int K = (int)vs.shape[0], N = (int)vs.shape[1];
-            rc = pack_conv_launch(src, 1, K, K, N, dst, N, (K + 15) / 16 * 16, s);
-            if (!rc) rc = pack_split_launch(dst, N, (K + 15) / 16 * 16, s);
-        }
-        if (rc) return rc;
+// The pack of one "/weights" variable as a job of the batched launch (same layouts as the single-variable launchers of igemm.hip)
+static PackJob forward_pack_job(const sagen_ctx* c, const VarSpec& vs) {
+    PackJob j;
+    j.src = c->v(vs.name);
+    j.dst = c->p("pk:" + vs.name);
+    if (vs.name.find("/deconv") != std::string::npos) {
+        const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
+        const int sh = AENC_S[l][0], sw = AENC_S[l][1];
+        const int nth = cdiv(vs.shape[0], sh), ntw = cdiv(vs.shape[1], sw);
+        j.kind = PACK_DECONV;
+        j.N = sh * sw * (int)vs.shape[2];
+        j.Kpad = (nth * ntw * (int)vs.shape[3] + 15) / 16 * 16;
+        j.p[0] = (int)vs.shape[0]; j.p[1] = (int)vs.shape[1]; j.p[2] = (int)vs.shape[2]; j.p[3] = (int)vs.shape[3]; j.p[4] = sh; j.p[5] = sw; j.p[6] = ntw;
+    } else if (vs.ndim == 4) {
+        int cin = (int)vs.shape[2], cinp = cin == 3 ? 4 : cin, taps = (int)(vs.shape[0] * vs.shape[1]);
+        if (cin == 1) { cin = cinp = (int)vs.shape[1]; taps = (int)vs.shape[0]; }
+        const bool stem = cin == 3;                   // tap rows padded 7 -> 8, K = (dh, dw8, c4)
+        if (stem) taps = (int)(vs.shape[0] * (vs.shape[1] + 1));
+        j.kind = PACK_CONV;
+        j.N = (int)vs.shape[3];
+        j.Kpad = (taps * cinp + 15) / 16 * 16;
+        j.p[0] = taps; j.p[1] = cin; j.p[2] = cinp; j.p[3] = (int)vs.shape[3];
+        j.p[4] = stem ? (int)vs.shape[1] : 0; j.p[5] = stem ? (int)vs.shape[1] + 1 : 0;
+    } else {
+        const int K = (int)vs.shape[0], N = (int)vs.shape[1];
+        j.kind = PACK_CONV;
+        j.N = N; j.Kpad = (K + 15) / 16 * 16;
+        j.p[0] = 1; j.p[1] = K; j.p[2] = K; j.p[3] = N;
     }
-    return SAGEN_OK;
+    return j;
+}
+
+// uploads a job table into `dev` (capacity checked by the caller) and returns the number of blocks of the launch
+int sagen_upload_pack_jobs(std::vector<PackJob>& jobs, void* dev, hipStream_t s) {
+    int nb = 0;
+    for (auto& j : jobs) { j.first_block = nb; nb += pack_job_blocks(j.N, j.Kpad); }
+    if (!jobs.empty() && hipMemcpyAsync(dev, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    return nb;
+}
+
+int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
+    if (c->pack_jobs.empty()) {          // first call after bind: build the table from the bound variables and ship it
+        for (const auto& vs : c->vars) {
+            if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
+            c->pack_jobs.push_back(forward_pack_job(c, vs));
+        }
+        if (c->pack_jobs.size() * sizeof(PackJob) > c->bufs.at("pk:jobs").n * sizeof(float)) return fail(SAGEN_ERR_WORKSPACE, "pack job table too small");
+        c->pack_blocks = sagen_upload_pack_jobs(c->pack_jobs, c->p("pk:jobs"), s);
+        if (c->pack_blocks < 0) return fail(SAGEN_ERR_HIP, "pack job upload failed");
+    }
+    return pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pk:jobs")), (int)c->pack_jobs.size(), c->pack_blocks, s);
 }
 
 // ------------------------------------------------------------------------------------------------

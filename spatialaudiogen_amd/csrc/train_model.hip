@@ -114,29 +114,35 @@ static void train_carve(sagen_ctx* c) {
         if (p.kind == PKD_NONE) continue;
         c->talloc("pkd:" + vs.name, packed_split_floats((size_t)p.N * ceil16(p.K)));
     }
+    c->talloc("pkd:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);
 }
 
-// data-gradient filter packs, once per step (the optimiser rewrote the variables)
+// data-gradient filter packs, once per step (the optimiser rewrote the variables): one batched launch (igemm.hip: pack_multi_kernel)
 static int repack_dgrad(sagen_ctx* c, hipStream_t s) {
-    for (const auto& vs : c->vars) {
-        if (!is_weights(vs.name)) continue;
-        const PkdSpec p = pkd_spec(vs);
-        if (p.kind == PKD_NONE) continue;
-        const float* src = c->v(vs.name);
-        float* dst = c->p("pkd:" + vs.name);
-        const int Kpad = ceil16(p.K);
-        int rc = SAGEN_OK;
-        switch (p.kind) {
-            case PKD_FLIPT: rc = pack_conv_flipT_launch(src, p.kh * p.kw, p.a, p.b, dst, Kpad, s); break;
-            case PKD_STRIDED: rc = pack_deconv_launch(src, p.kh, p.kw, p.a, p.b, p.sh, p.sw, dst, p.N, Kpad, s); break;   // HWIO = [kh,kw,"Cout"=Cin,"Cin"=Cout]
-            case PKD_DECONV: rc = pack_conv_launch(src, p.kh * p.kw, p.a, p.a, p.b, dst, p.N, Kpad, s); break;          // [kh,kw,Cout,Cin] read as HWIO
-            case PKD_ROWS: rc = pack_rows_launch(src, p.a, p.b, dst, Kpad, s); break;
-            default: break;
+    if (c->pack_jobs_bwd.empty()) {
+        for (const auto& vs : c->vars) {
+            if (!is_weights(vs.name)) continue;
+            const PkdSpec p = pkd_spec(vs);
+            if (p.kind == PKD_NONE) continue;
+            PackJob j;
+            j.src = c->v(vs.name);
+            j.dst = c->p("pkd:" + vs.name);
+            j.N = p.N; j.Kpad = ceil16(p.K);
+            switch (p.kind) {
+                case PKD_FLIPT: j.kind = PACK_FLIPT; j.p[0] = p.kh * p.kw; j.p[1] = p.a; j.p[2] = p.b; break;
+                case PKD_STRIDED:                                   // HWIO read as [kh,kw,"Cout"=Cin,"Cin"=Cout]
+                    j.kind = PACK_DECONV; j.p[0] = p.kh; j.p[1] = p.kw; j.p[2] = p.a; j.p[3] = p.b; j.p[4] = p.sh; j.p[5] = p.sw; j.p[6] = cdiv(p.kw, p.sw); break;
+                case PKD_DECONV:                                    // [kh,kw,Cout,Cin] read as HWIO
+                    j.kind = PACK_CONV; j.p[0] = p.kh * p.kw; j.p[1] = p.a; j.p[2] = p.a; j.p[3] = p.b; break;
+                default: j.kind = PACK_ROWS; j.p[0] = p.a; j.p[1] = p.b; break;
+            }
+            c->pack_jobs_bwd.push_back(j);
         }
-        if (!rc) rc = pack_split_launch(dst, p.N, Kpad, s);
-        if (rc) return rc;
+        if (c->pack_jobs_bwd.size() * sizeof(PackJob) > c->tbufs.at("pkd:jobs").n * sizeof(float)) return fail(SAGEN_ERR_WORKSPACE, "pack job table too small");
+        c->pack_blocks_bwd = sagen_upload_pack_jobs(c->pack_jobs_bwd, c->p("pkd:jobs"), s);
+        if (c->pack_blocks_bwd < 0) return fail(SAGEN_ERR_HIP, "pack job upload failed");
     }
-    return SAGEN_OK;
+    return pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pkd:jobs")), (int)c->pack_jobs_bwd.size(), c->pack_blocks_bwd, s);
 }
 
 struct Bwd : Fwd {
@@ -482,6 +488,7 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
         return fail(SAGEN_ERR_WORKSPACE, "train workspace has %zu bytes, need %zu", tws_bytes, c->tws_floats * sizeof(float));
     if (((uintptr_t)tws) % 256) return fail(SAGEN_ERR_WORKSPACE, "train workspace must be 256-byte aligned");
     c->tws = (float*)tws;
+    c->pack_jobs_bwd.clear();
     std::vector<float*> gp(c->vars.size(), nullptr), mp(c->vars.size(), nullptr);
     for (int pass = 0; pass < 2; ++pass) {
         const sagen_tensor* ts = pass ? moving : grads;
