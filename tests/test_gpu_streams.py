@@ -39,6 +39,7 @@ def T():
 def _forward(enc, one_stream, path):
     env = dict(os.environ)
     env.pop('SAGEN_ONE_STREAM', None)
+    env['SAGEN_STEMPOOL'] = '1'          # same kernel set in both modes (a one-stream host would otherwise run the unfused stem + pool)
     if one_stream:
         env['SAGEN_ONE_STREAM'] = '1'
     subprocess.run([sys.executable, '-c', CHILD, ','.join(enc), path], check=True, env=env, timeout=600)
