@@ -525,13 +525,26 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     if (!c || !audio || !target) return fail(SAGEN_ERR_NULL, "sagen_train_step: null argument");
     if (!c->train_ready) return fail(SAGEN_ERR_WORKSPACE, "sagen_train_step: call sagen_train_bind first");
     int rc = sagen_repack_impl(c, s);                  // the optimiser updated the variables in place
-    if (!rc) rc = repack_dgrad(c, s);
+    // the data-gradient packs are first needed after the forward: on the second stream, under it
+    static const bool one_stream_pack = getenv("SAGEN_BWD_ONE_STREAM") != nullptr;
+    const bool pack_aux = c->aux && c->ev_fork && !one_stream_pack && !c->tuning && !c->profiling;
+    if (!rc && pack_aux) {
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        rc = repack_dgrad(c, c->aux);
+    } else if (!rc) {
+        rc = repack_dgrad(c, s);
+    }
     if (rc) return rc;
     float* pred = pred_out ? pred_out : c->p("t:pred");
     c->train_mode = true;
     rc = sagen_forward_impl(c, audio, video, flow, pred, s);
     c->train_mode = false;
     if (rc) return rc;
+    if (pack_aux) {                                    // (the forward joins the second stream only when it forked)
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
     double* loss = reinterpret_cast<double*>(c->p("t:loss"));
     Bwd b(c, s);
     b.layer = "loss";
@@ -541,7 +554,8 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     static const bool one_stream = getenv("SAGEN_BWD_ONE_STREAM") != nullptr;
     Bwd w(c, c->aux);
     w.redws = "t:redws2"; w.cslot = CACC_SLOTS / 2; w.wsname = "splitk_aux";      // its own scratch: it runs concurrently with `b`
-    if (c->aux && !one_stream && !c->tuning) b.wg = &w;
+    // (with the per-launch profiler on, everything stays on one stream: the events then time unoverlapped launches)
+    if (c->aux && !one_stream && !c->tuning && !c->profiling) b.wg = &w;
     b.run();
     if (b.wg) b.aux_wait(b.aux_mark());          // join: the gradients are complete when the caller's stream gets here
     if (b.rc) return b.rc;
