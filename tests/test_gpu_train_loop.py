@@ -58,6 +58,22 @@ def test_loss_decreases_and_resume_is_bit_identical(T, tmp_path):
     assert np.abs(mm).max() > 0 and int(full['step']) == 6
 
 
+def test_training_converges_on_the_synthetic_task(T):
+    """150 Adam steps at the reference's learning rate on the learnable synthetic task (target = fixed per-channel scaling of the
+    mono crop, 4 distinct batches cycled): the loss of the audio-only network must fall by more than 100x and stay finite
+    (profiles/r03_train_convergence_*.txt hold 400-step curves of both configurations at B = 32)."""
+    from spatialaudiogen_amd.train import synthetic_batches
+    enc, B = ['audio'], 8
+    tr, _ = _trainer(T, enc, B, lr=1e-4)
+    it = synthetic_batches(enc, B, seed=5, pool=4)
+    losses = []
+    for _ in range(150):
+        a, v, f, t, m = next(it)
+        losses.append(float(tr.step(a, v, f, t, m)[0]))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < 1e-2 * np.mean(losses[:10]), (losses[:10], losses[-10:])
+
+
 def test_nan_guard_stops_the_loop_and_still_saves(T, tmp_path):
     from spatialaudiogen_amd.train import synthetic_batches, train_loop
 
