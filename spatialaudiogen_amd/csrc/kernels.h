@@ -224,7 +224,7 @@ struct WgradDesc {
     int tsh = 1, tsw = 1;             // tap strides: tap (th, tw) reads G at (i*sh + th*tsh + h0, j*sw + tw*tsw + w0)
     int splitk = 1;
     // filled by wgrad_launch
-    int P = 0;
+    int P = 0, fold = 1;
     unsigned g_bytes = 0, d_bytes = 0, magic_w = 0, magic_h = 0;
 };
 int wgrad_launch(const WgradDesc& d, hipStream_t s);

@@ -261,8 +261,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradDesc d) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int ntaps = d.TH * d.TW;
-    const int tiles_g = (d.Cg + BM - 1) / BM, tiles_d = (d.Cd + BN - 1) / BN;
+    // d.fold > 1 (the stem: 32 gathered channels, 7 filter rows): a tile's rows are `fold` consecutive filter rows x Cg channels,
+    // so the D operand (205 MB for the stem) is read once per `fold` filter rows and no MFMA rows are padding
+    const int fold = d.fold;
+    const int ntaps = fold > 1 ? (d.TH + fold - 1) / fold : d.TH * d.TW;
+    const int tiles_g = fold > 1 ? 1 : (d.Cg + BM - 1) / BM, tiles_d = (d.Cd + BN - 1) / BN;
     const int ntile = ntaps * tiles_g * tiles_d;
     int n;
     {
@@ -275,8 +278,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradDesc d) {
     const int tap = rem / (tiles_g * tiles_d);
     rem -= tap * (tiles_g * tiles_d);
     const int tg = rem / tiles_d, td = rem - tg * tiles_d;
-    const int th = tap / d.TW, tw = tap - th * d.TW;
     const int g0 = tg * BM, d0 = td * BN;
+    int th = tap / d.TW;
+    const int tw = tap - th * d.TW;
+    unsigned a_cb = (unsigned)(g0 + 4 * (tid % (BM / 4)));
+    unsigned a_cbad = a_cb < (unsigned)d.Cg ? 0u : OOB;
+    if (fold > 1) {                                            // this thread's filter row and channel inside it
+        const int gl = 4 * (tid % (BM / 4));
+        const int tl = gl / d.Cg;
+        th = tap * fold + tl;
+        a_cb = (unsigned)(gl - tl * d.Cg);
+        a_cbad = (tl < fold && th < d.TH) ? 0u : OOB;
+    }
     const int roff = th * d.tsh + d.h0, coff = tw * d.tsw + d.w0;
 
     const int nchunks = (d.P + BK - 1) / BK;
@@ -287,8 +300,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradDesc d) {
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.g, 0, d.g_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.d, 0, d.d_bytes, 0x00020000);
 
-    const unsigned a_cb = (unsigned)(g0 + 4 * (tid % A_CPR)), b_cb = (unsigned)(d0 + 4 * (tid % B_CPR));
-    const unsigned a_cbad = a_cb < (unsigned)d.Cg ? 0u : OOB, b_cbad = b_cb < (unsigned)d.Cd ? 0u : OOB;
+    const unsigned b_cb = (unsigned)(d0 + 4 * (tid % B_CPR));
+    const unsigned b_cbad = b_cb < (unsigned)d.Cd ? 0u : OOB;
     const int a_kp = tid / A_CPR, b_kp = tid / B_CPR;          // pixel row of pass 0
     const int a_wofs = a_kp * RSA + (tid % A_CPR) * 8, b_wofs = 3 * PLA + b_kp * RSB + (tid % B_CPR) * 8;
 
@@ -398,20 +411,240 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradDesc d) {
 
     // epilogue.  C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int li = lane & 31, kk = lane >> 5;
-    float* out = d.splitk > 1 ? d.ws + (size_t)z * ntaps * d.Cg * d.Cd : d.out;
+    float* out = d.splitk > 1 ? d.ws + (size_t)z * d.TH * d.TW * d.Cg * d.Cd : d.out;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int g = g0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-            if (g >= d.Cg) continue;
-            float* orow = out + ((size_t)tap * d.Cg + g) * d.Cd;
+            int g = g0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            int otap = tap;
+            if (fold > 1) {
+                const int tl = g / d.Cg;
+                g -= tl * d.Cg;
+                otap = tap * fold + tl;
+                if (tl >= fold || otap >= d.TH) continue;
+            } else if (g >= d.Cg) continue;
+            float* orow = out + ((size_t)otap * d.Cg + g) * d.Cd;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int dd = d0 + wn * WN + j * 32 + li;
                 if (dd < d.Cd) orow[dd] = acc[i][j][e];
             }
         }
+}
+
+// wgrad3r_kernel: wgrad3_kernel for the dense 3x3 stride-1 SAME convolutions (13 of the 20 ResNet convs, half of all weight-gradient
+// time), one workgroup per FILTER ROW instead of per tap.  wgrad3_kernel is bound by its VALU work, not by the matrix pipe: every
+// workgroup splits its own copy of both operand tiles (about 8 VALU per element) and derives every pixel's address by two divisions,
+// for each of the nine taps.  Here the three horizontal taps of a filter row share ONE staged G tile (18 pixel rows instead of
+// 3 x 16: tap tw reads its fragments tw rows further down) and ONE D tile, so a K step splits (18*BM + 16*BN) elements for
+// 3*6*MT*NT MFMAs - 2.8x fewer per MFMA - and the chunk's base pixel is decomposed once on the scalar unit, the rows of a thread
+// following by compare-and-wrap.
+// The contraction index runs over the PADDED pixel grid [B][Hd][Wd + 1] (one zero pixel closing every image row, the idea of
+// conv3p.hip): the horizontal neighbours of a pixel are then its neighbours in the flat index - the pad pixel is the right-hand
+// padding of its own row and the left-hand padding of the next - and a chunk may straddle image rows freely.  Pad pixels and
+// rows outside the image are buffer-range-check zeros on both operands (1/Wd more K steps).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad3r_kernel(const WgradDesc d) {
+    constexpr int BK = 16, NTW = 3, AR = BK + NTW - 1;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;
+    constexpr int A_CPR = BM / 4, B_CPR = BN / 4;
+    constexpr int A_RPP = 256 / A_CPR, B_RPP = 256 / B_CPR;
+    constexpr int A_PT = (AR + A_RPP - 1) / A_RPP, B_PT = BK / B_RPP;
+    static_assert(B_PT >= 1 && BK % B_RPP == 0, "D tile: whole passes");
+    // the last G pass only has the two extra rows left: wave 0 alone runs it (a scalar branch); its 64 lanes cover 64 / A_CPR rows
+    static_assert((A_PT - 1) * A_RPP == BK && 64 / A_CPR >= NTW - 1, "G tile: whole passes + one wave for the tap overlap");
+    constexpr int AROWS = BK + 64 / A_CPR;
+    constexpr int PLA = AROWS * RSA, PLB = BK * RSB;
+    constexpr int ST = 3 * (PLA + PLB);
+    __shared__ __attribute__((aligned(16))) char smem[2 * ST];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_g = (d.Cg + BM - 1) / BM, tiles_d = (d.Cd + BN - 1) / BN;
+    const int ntile = d.TH * tiles_g * tiles_d;
+    int n;
+    {
+        const int gm = gridDim.x, bid = blockIdx.x;
+        const int q = gm >> 3, r = gm & 7, xcd = bid & 7, j = bid >> 3;
+        n = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int z = n / ntile;
+    int rem = n - z * ntile;
+    const int th = rem / (tiles_g * tiles_d);
+    rem -= th * (tiles_g * tiles_d);
+    const int tg = rem / tiles_d, td = rem - tg * tiles_d;
+    const int g0 = tg * BM, d0 = td * BN;
+    const int roff = th * d.tsh + d.h0;
+    const int Wp = d.Wd + 1;
+
+    const int nchunks = (d.P + BK - 1) / BK;                   // d.P: PADDED pixels (wgrad_launch)
+    const int per_z = (nchunks + d.splitk - 1) / d.splitk;
+    const int kc0 = z * per_z;
+    const int kc1 = min(nchunks, kc0 + per_z);
+
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.g, 0, d.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.d, 0, d.d_bytes, 0x00020000);
+
+    const unsigned a_cb = (unsigned)(g0 + 4 * (tid % A_CPR)), b_cb = (unsigned)(d0 + 4 * (tid % B_CPR));
+    const unsigned a_cbad = a_cb < (unsigned)d.Cg ? 0u : OOB, b_cbad = b_cb < (unsigned)d.Cd ? 0u : OOB;
+    const int a_kp = tid / A_CPR, b_kp = tid / B_CPR;
+    const int a_wofs = a_kp * RSA + (tid % A_CPR) * 8, b_wofs = 3 * PLA + b_kp * RSB + (tid % B_CPR) * 8;
+
+    // pixel `delta` places after (b, i, j) of the padded grid; delta < 2 * Wp (wgrad_launch: Wd >= 12, delta <= 23)
+    auto advance = [&](int& b, int& i, int& j, int delta) {
+        j += delta;
+        if (j >= Wp) { j -= Wp; ++i; }
+        if (j >= Wp) { j -= Wp; ++i; }
+        if (i >= d.Hd) { i -= d.Hd; ++b; }
+        if (i >= d.Hd) { i -= d.Hd; ++b; }
+    };
+    f32x4 ra[A_PT], rb[B_PT];
+    int cb0 = 0, ci0 = 0, cj0 = 0;                             // (b, i, j) of the first pixel of the chunk being loaded: wave-uniform
+    auto chunk_base = [&](int kc) {
+        const unsigned q0 = (unsigned)kc * BK;
+        const unsigned r0 = __umulhi(q0, d.magic_w);           // / Wp: two scalar divisions per chunk
+        cj0 = (int)(q0 - r0 * (unsigned)Wp);
+        const unsigned bb = d.Hd == 1 ? r0 : __umulhi(r0, d.magic_h);
+        ci0 = (int)(r0 - bb * (unsigned)d.Hd);
+        cb0 = (int)bb;
+    };
+    auto load_a = [&](int t) {
+        const int row = a_kp + t * A_RPP;                      // slot `row` of the G tile holds padded pixel q0 - 1 + row
+        int b = cb0, i = ci0, j = cj0 - 1;
+        advance(b, i, j, row);                                 // (-1 only at a row start: that neighbour is the previous row's pad pixel - zero)
+        const int gi = (int)WG_MUL((unsigned)i, (unsigned)d.sh) + roff;
+        const bool ok = j >= 0 && j < d.Wd && b < d.B && (unsigned)gi < (unsigned)d.HG;
+        const unsigned off = ok ? ((WG_MUL((unsigned)b, d.g_bstride) + WG_MUL((unsigned)gi, d.g_rstride) + WG_MUL((unsigned)j, (unsigned)d.ldg) + a_cb) * 4u) | a_cbad : OOB;
+        ra[t] = bload16(g_rsrc, off);
+    };
+    auto load_b = [&](int t) {
+        int b = cb0, i = ci0, j = cj0;
+        advance(b, i, j, b_kp + t * B_RPP);
+        const bool ok = j < d.Wd && b < d.B;
+        const unsigned off = ok ? ((WG_MUL((unsigned)b, d.d_bstride) + WG_MUL((unsigned)i, d.d_rstride) + WG_MUL((unsigned)j, (unsigned)d.ldd) + b_cb) * 4u) | b_cbad : OOB;
+        rb[t] = bload16(d_rsrc, off);
+    };
+    // one plane of one staged row: the bf16 pair planes are peeled off in place (v keeps the residual for the next plane)
+    auto split_plane = [&](f32x4& v, char* dst) {
+        float a = v[0], b = v[1], c = v[2], e = v[3];
+        u32x2 w;
+        w[0] = split_pair(a, b);
+        w[1] = split_pair(c, e);
+        v = f32x4{a, b, c, e};
+        *reinterpret_cast<u32x2*>(dst) = w;
+    };
+    // The staging work of one K step as UNITS that the K loop places between its MFMAs (left in one block after them, the wave
+    // runs matrix phase and VALU phase back to back - 9 VALU per MFMA, measured - and the matrix pipe idles through the second):
+    // per staged row: plane 0, 1, 2 of chunk kc+1 into the other stage, then the load of the same row of chunk kc+2.  No
+    // per-lane predicates (rows past the range load range-check zeros; the last K steps stage chunks nobody reads).
+    constexpr int NUNIT = 4 * (A_PT + B_PT);
+    auto unit = [&](int u, char* st_next) {
+        const int r = u >> 2, k = u & 3;                       // row slot (A rows first), piece
+        if (r < A_PT) {
+            if (r == A_PT - 1 && wave != 0) return;
+            if (k < 3) split_plane(ra[r], st_next + a_wofs + r * A_RPP * RSA + k * PLA);
+            else load_a(r);
+        } else {
+            const int t = r - A_PT;
+            if (k < 3) split_plane(rb[t], st_next + b_wofs + t * B_RPP * RSB + k * PLB);
+            else load_b(t);
+        }
+    };
+
+    f32x16 acc[NTW][MT][NT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][i][j][e] = 0.f;
+
+    const int q = lane & 15, gk = lane >> 5, hh = (lane >> 4) & 1;
+    const int a_foff = (8 * gk + (q >> 2)) * RSA + (wm * WM + 16 * hh + 4 * (q & 3)) * 2;
+    const int b_foff = 3 * PLA + (8 * gk + (q >> 2)) * RSB + (wn * WN + 16 * hh + 4 * (q & 3)) * 2;
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // hh, hm, mh, hl, lh, mm
+
+    if (kc1 > kc0) {
+        chunk_base(kc0);
+#pragma unroll
+        for (int u = 3; u < NUNIT; u += 4) unit(u, smem);
+#pragma unroll
+        for (int u = 0; u < NUNIT; ++u) if ((u & 3) != 3) unit(u, smem);
+        chunk_base(kc0 + 1);
+#pragma unroll
+        for (int u = 3; u < NUNIT; u += 4) unit(u, smem);
+    }
+    lds_barrier();
+    int stage = 0;
+    constexpr int NM1 = 6 * MT * NT, NMG = NTW * NM1;          // MFMAs per tap / per K step
+    constexpr int USTRIDE = NMG / NUNIT > 0 ? NMG / NUNIT : 1;
+    constexpr int NFA = 3 * MT;
+    static_assert(NFA <= NM1, "a tap has enough MFMA slots for the next tap's fragment reads");
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const char* st = smem + stage * ST;
+        char* st_next = smem + (stage ^ 1) * ST;
+        chunk_base(kc + 2);
+        bf16x8 fb[3][NT], fa[2][3][MT];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[pl][j] = tr_frag(st + b_foff + pl * PLB + j * 64, RSB);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[0][pl][i] = tr_frag(st + a_foff + pl * PLA + i * 64, RSA);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int cb = t & 1;
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int k = (tt * MT + i) * NT + j, idx = t * NM1 + k;
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][TA[tt]][i], fb[TB[tt]][j], acc[t][i][j], 0, 0, 0);
+                        // side jobs of this slot: the next tap's G fragments, one staging unit
+                        if (t + 1 < NTW && k < NFA) {
+                            const int pl = k / MT, fi = k - pl * MT;
+                            fa[cb ^ 1][pl][fi] = tr_frag(st + a_foff + (t + 1) * RSA + pl * PLA + fi * 64, RSA);
+                        }
+                        if (idx % USTRIDE == 0 && idx / USTRIDE < NUNIT) unit(idx / USTRIDE, st_next);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = (NMG + USTRIDE - 1) / USTRIDE; u < NUNIT; ++u) unit(u, st_next);      // (units that found no slot)
+        lds_barrier();
+        stage ^= 1;
+    }
+
+    const int li = lane & 31, kk = lane >> 5;
+    float* out = d.splitk > 1 ? d.ws + (size_t)z * d.TH * NTW * d.Cg * d.Cd : d.out;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int g = g0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (g >= d.Cg) continue;
+                float* orow = out + ((size_t)(th * NTW + t) * d.Cg + g) * d.Cd;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int dd = d0 + wn * WN + j * 32 + li;
+                    if (dd < d.Cd) orow[dd] = acc[t][i][j][e];
+                }
+            }
 }
 
 // plain reference of the same contraction (one thread per output element, fp64 accumulation): SAGEN_WGRAD_REF=1 routes every
@@ -454,14 +687,39 @@ static unsigned magic_of(int dv) { return dv <= 1 ? 0u : (unsigned)((1ull << 32)
 
 size_t wgrad_ws_floats(const WgradDesc& d, int splitk) { return splitk > 1 ? (size_t)splitk * d.TH * d.TW * d.Cg * d.Cd : 0; }
 
+// the filter-row kernel runs dense 3-wide stride-1 rows with SAME padding (one pad pixel either side), rows of >= 12 pixels
+static bool wgrad_rowtap(const WgradDesc& d) {
+    static const bool off = getenv("SAGEN_WGRAD_NOROW") != nullptr;
+    return !off && !wgrad_exact() && d.TW == 3 && d.tsw == 1 && d.sw == 1 && d.w0 == -1 && d.WG == d.Wd && d.Wd >= 12;
+}
+struct WgradShape { int bm, bn, fold; long ntile, nchunks; bool row; };
+static WgradShape wgrad_shape(const WgradDesc& d) {
+    WgradShape w;
+    w.row = wgrad_rowtap(d);
+    w.bm = d.Cg > 64 ? 128 : 64;
+    w.bn = (d.Cd > 64 && !w.row) ? 128 : 64;                      // (three accumulator sets: the row kernel keeps BN = 64)
+    const long P = w.row ? (long)d.B * d.Hd * (d.Wd + 1) : (long)d.B * d.Hd * d.Wd;
+    // 32 gathered channels, a column of filter rows (the stem after its horizontal taps were folded into the channels): four rows per tile
+    static const bool nofold = getenv("SAGEN_WGRAD_NOFOLD") != nullptr;
+    w.fold = (!nofold && !wgrad_exact() && !w.row && d.TW == 1 && d.TH >= 2 && d.Cg == 32) ? 4 : 1;
+    if (w.fold > 1) w.bm = 128;
+    w.ntile = w.fold > 1 ? (long)cdiv(d.TH, w.fold) * cdiv(d.Cd, w.bn)
+                         : (long)d.TH * (w.row ? 1 : d.TW) * cdiv(d.Cg, w.bm) * cdiv(d.Cd, w.bn);
+    w.nchunks = (P + 15) / 16;
+    return w;
+}
+
 int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats) {
-    const int bm = d.Cg > 64 ? 128 : 64, bn = d.Cd > 64 ? 128 : 64;
-    const long ntile = (long)d.TH * d.TW * cdiv(d.Cg, bm) * cdiv(d.Cd, bn);
-    const long P = (long)d.B * d.Hd * d.Wd;
-    const long nchunks = (P + 15) / 16;
+    const WgradShape w = wgrad_shape(d);
     // ~1024 workgroups (two rounds of the 2-per-CU slots for the 128x128 tile, never a thin third one), >= 8 chunks per range
-    long sk = std::max<long>(1, std::min<long>(1024 / ntile, nchunks / 8));
+    // Workgroups: two rounds of the 2-per-CU slots (1024) hide prologues and tails best - unless the partial sums become the cost:
+    // every workgroup writes its whole tile and the reducer reads it back, 2 x (workgroups x tile bytes) of traffic.  Measured
+    // on the 3x3 layers of stages 3-5 (2.4-9.4 MB of gradient, 64-98 KB per tile): 110 us with 1024 workgroups, of which 60 us is
+    // partial-sum traffic, 94 us with 512; the stem (57 KB of gradient) 344 us with 1024, 467 us with 512.
+    static const long forced = getenv("SAGEN_WGRAD_WGS") ? std::max(64, atoi(getenv("SAGEN_WGRAD_WGS"))) : 0;
     const size_t per = (size_t)d.TH * d.TW * d.Cg * d.Cd;
+    const long target = forced ? forced : ((1024 / w.ntile) * per * 4 > (32u << 20) ? 512 : 1024);
+    long sk = std::max<long>(1, std::min<long>(target / w.ntile, w.nchunks / 8));
     while (sk > 1 && sk * per > ws_capacity_floats) --sk;
     return (int)std::min<long>(sk, 256);
 }
@@ -474,9 +732,10 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
     if (d.Cg % 4 || d.ldg <= 0 || d.ldd % 4 || (d.Cd % 4 && d.ldd < (d.Cd + 3) / 4 * 4))
         return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: Cg=%d must be a multiple of 4, D rows must be padded to a multiple of 4 floats (Cd=%d ldd=%d)", d.Cg, d.Cd, d.ldd);
     if (((uintptr_t)d.g | (uintptr_t)d.d) % 16) return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: operands must be 16-byte aligned");
-    const long P = (long)d.B * d.Hd * d.Wd;
+    const WgradShape shp = wgrad_shape(d);
+    const long P = shp.row ? (long)d.B * d.Hd * (d.Wd + 1) : (long)d.B * d.Hd * d.Wd;      // (the row kernel contracts over the padded grid)
     const long gb = ((long)(d.B - 1) * d.g_bstride + (long)d.HG * d.g_rstride) * 4 + 64, db = ((long)(d.B - 1) * d.d_bstride + (long)d.Hd * d.d_rstride) * 4 + 64;
-    if (gb >= (1L << 31) || db >= (1L << 31) || P >= (1L << 24) || (long)P * d.Wd >= (1L << 32))
+    if (gb >= (1L << 31) || db >= (1L << 31) || P >= (1L << 24) || (long)P * (d.Wd + 1) >= (1L << 32))
         return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: operand exceeds 2 GiB buffer addressing / 2^24 pixels (use a smaller batch)");
     const unsigned lim = 1u << 24;
     if (d.g_bstride >= lim || d.g_rstride >= lim || d.d_bstride >= lim || d.d_rstride >= lim || (unsigned)d.ldg >= lim || (unsigned)d.ldd >= lim ||
@@ -484,7 +743,8 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
         return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: a stride / extent exceeds 2^24 (24-bit index multiplies)");
     d.P = (int)P;
     d.g_bytes = (unsigned)gb; d.d_bytes = (unsigned)db;
-    d.magic_w = magic_of(d.Wd); d.magic_h = magic_of(d.Hd);
+    d.magic_w = magic_of(shp.row ? d.Wd + 1 : d.Wd); d.magic_h = magic_of(d.Hd);
+    d.fold = shp.fold;
     static const bool use_ref = getenv("SAGEN_WGRAD_REF") != nullptr;
     const long total = (long)d.TH * d.TW * d.Cg * d.Cd;
     if (use_ref) {
@@ -494,8 +754,8 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
     }
     if (d.splitk < 1) d.splitk = 1;
     if (d.splitk > 1 && !d.ws) return fail(SAGEN_ERR_WORKSPACE, "wgrad: split-K needs a workspace");
-    const int bm = d.Cg > 64 ? 128 : 64, bn = d.Cd > 64 ? 128 : 64;
-    const long blocks = (long)d.TH * d.TW * cdiv(d.Cg, bm) * cdiv(d.Cd, bn) * d.splitk;
+    const int bm = shp.bm, bn = shp.bn;
+    const long blocks = shp.ntile * d.splitk;
     if (blocks >= (1L << 30)) return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: grid too large");
     const dim3 grid((unsigned)blocks);
     if (wgrad_exact()) {
@@ -503,6 +763,9 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
         else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, s, d);
         else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, d);
         else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, d);
+    } else if (shp.row) {
+        if (bm == 128) hipLaunchKernelGGL((wgrad3r_kernel<128, 64>), grid, dim3(256), 0, s, d);
+        else hipLaunchKernelGGL((wgrad3r_kernel<64, 64>), grid, dim3(256), 0, s, d);
     } else {
         if (bm == 128 && bn == 128) hipLaunchKernelGGL((wgrad3_kernel<128, 128>), grid, dim3(256), 0, s, d);
         else if (bm == 128) hipLaunchKernelGGL((wgrad3_kernel<128, 64>), grid, dim3(256), 0, s, d);

@@ -39,10 +39,15 @@ CONV_CASES = [
     (2, 10, 18, 64, 128, 1, 1, 2, 2, 'SAME'),       # shortcut
     (2, 7, 14, 128, 256, 3, 3, 1, 1, 'SAME'),       # 128x128 tile, small image (edge handling dominates)
     (2, 9, 13, 256, 128, 3, 3, 1, 1, 'SAME'),       # odd sizes, Cg > Cd
+    (1, 28, 56, 128, 128, 3, 3, 1, 1, 'SAME'),      # stage-3 image: filter-row kernel, chunks straddling image rows (57 % 16 != 0)
+    (5, 5, 12, 64, 96, 3, 3, 1, 1, 'SAME'),         # narrowest image of the filter-row kernel, Cd tail (96 of 128), 5 images
+    (2, 6, 11, 64, 64, 3, 3, 1, 1, 'SAME'),         # one pixel narrower: the per-tap kernel
     (2, 15, 31, 32, 64, 3, 7, 2, 4, 'VALID'),       # audio conv2
     (2, 15, 31, 64, 128, 3, 5, 2, 2, 'VALID'),      # audio conv3
     (3, 7, 14, 128, 256, 3, 5, 1, 1, 'VALID'),      # audio conv4
     (2, 16, 16, 16, 32, 5, 3, 3, 2, 'VALID'),       # ragged: rows / columns the strided conv never reads
+    (2, 21, 9, 32, 64, 7, 1, 2, 1, 'VALID'),        # 32 gathered channels, a column of 7 filter rows: four rows folded into one tile (the stem's form)
+    (3, 12, 10, 32, 96, 5, 1, 1, 1, 'SAME'),        # the same with padding rows and a second, partly empty row group
 ]
 
 
