@@ -26,6 +26,7 @@
 //    the block index is remapped so that the tiles of one pixel range share an XCD (L2).
 #include "igemm3_common.h"
 #include <algorithm>
+#include <type_traits>
 #ifdef SAGEN_WGRAD_MUL32          // dev builds: 32-bit index multiplies (A/B of the 24-bit ones)
 #define WG_MUL(a, b) ((a) * (b))
 #else
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3r_kernel(const WgradDesc d) {
         if (i >= d.Hd) { i -= d.Hd; ++b; }
         if (i >= d.Hd) { i -= d.Hd; ++b; }
     };
-    f32x4 ra[A_PT], rb[B_PT];
+    f32x4 ra[2][A_PT], rb[2][B_PT];                          // two register sets: the loads run TWO K steps ahead of their split
     int cb0 = 0, ci0 = 0, cj0 = 0;                             // (b, i, j) of the first pixel of the chunk being loaded: wave-uniform
     auto chunk_base = [&](int kc) {
         const unsigned q0 = (unsigned)kc * BK;
@@ -515,21 +516,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3r_kernel(const WgradDesc d) {
         ci0 = (int)(r0 - bb * (unsigned)d.Hd);
         cb0 = (int)bb;
     };
-    auto load_a = [&](int t) {
+    auto load_a = [&](int set, int t) {
         const int row = a_kp + t * A_RPP;                      // slot `row` of the G tile holds padded pixel q0 - 1 + row
         int b = cb0, i = ci0, j = cj0 - 1;
         advance(b, i, j, row);                                 // (-1 only at a row start: that neighbour is the previous row's pad pixel - zero)
         const int gi = (int)WG_MUL((unsigned)i, (unsigned)d.sh) + roff;
         const bool ok = j >= 0 && j < d.Wd && b < d.B && (unsigned)gi < (unsigned)d.HG;
         const unsigned off = ok ? ((WG_MUL((unsigned)b, d.g_bstride) + WG_MUL((unsigned)gi, d.g_rstride) + WG_MUL((unsigned)j, (unsigned)d.ldg) + a_cb) * 4u) | a_cbad : OOB;
-        ra[t] = bload16(g_rsrc, off);
+        ra[set][t] = bload16(g_rsrc, off);
     };
-    auto load_b = [&](int t) {
+    auto load_b = [&](int set, int t) {
         int b = cb0, i = ci0, j = cj0;
         advance(b, i, j, b_kp + t * B_RPP);
         const bool ok = j < d.Wd && b < d.B;
         const unsigned off = ok ? ((WG_MUL((unsigned)b, d.d_bstride) + WG_MUL((unsigned)i, d.d_rstride) + WG_MUL((unsigned)j, (unsigned)d.ldd) + b_cb) * 4u) | b_cbad : OOB;
-        rb[t] = bload16(d_rsrc, off);
+        rb[set][t] = bload16(d_rsrc, off);
     };
     // one plane of one staged row: the bf16 pair planes are peeled off in place (v keeps the residual for the next plane)
     auto split_plane = [&](f32x4& v, char* dst) {
@@ -545,16 +546,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3r_kernel(const WgradDesc d) {
     // per staged row: plane 0, 1, 2 of chunk kc+1 into the other stage, then the load of the same row of chunk kc+2.  No
     // per-lane predicates (rows past the range load range-check zeros; the last K steps stage chunks nobody reads).
     constexpr int NUNIT = 4 * (A_PT + B_PT);
-    auto unit = [&](int u, char* st_next) {
+    auto unit = [&](int set, int u, char* st_next) {
         const int r = u >> 2, k = u & 3;                       // row slot (A rows first), piece
         if (r < A_PT) {
             if (r == A_PT - 1 && wave != 0) return;
-            if (k < 3) split_plane(ra[r], st_next + a_wofs + r * A_RPP * RSA + k * PLA);
-            else load_a(r);
+            if (k < 3) split_plane(ra[set][r], st_next + a_wofs + r * A_RPP * RSA + k * PLA);
+            else load_a(set, r);
         } else {
             const int t = r - A_PT;
-            if (k < 3) split_plane(rb[t], st_next + b_wofs + t * B_RPP * RSB + k * PLB);
-            else load_b(t);
+            if (k < 3) split_plane(rb[set][t], st_next + b_wofs + t * B_RPP * RSB + k * PLB);
+            else load_b(set, t);
         }
     };
 
@@ -573,15 +574,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3r_kernel(const WgradDesc d) {
     const int b_foff = 3 * PLA + (8 * gk + (q >> 2)) * RSB + (wn * WN + 16 * hh + 4 * (q & 3)) * 2;
     constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // hh, hm, mh, hl, lh, mm
 
+    // chunk c lives in register set (c - kc0) & 1: loaded two K steps before it is contracted, split one step before
     if (kc1 > kc0) {
         chunk_base(kc0);
 #pragma unroll
-        for (int u = 3; u < NUNIT; u += 4) unit(u, smem);
+        for (int u = 3; u < NUNIT; u += 4) unit(0, u, smem);
 #pragma unroll
-        for (int u = 0; u < NUNIT; ++u) if ((u & 3) != 3) unit(u, smem);
+        for (int u = 0; u < NUNIT; ++u) if ((u & 3) != 3) unit(0, u, smem);
         chunk_base(kc0 + 1);
 #pragma unroll
-        for (int u = 3; u < NUNIT; u += 4) unit(u, smem);
+        for (int u = 3; u < NUNIT; u += 4) unit(1, u, smem);
+        chunk_base(kc0 + 2);
+#pragma unroll
+        for (int u = 3; u < NUNIT; u += 4) unit(0, u, smem);
     }
     lds_barrier();
     int stage = 0;
@@ -589,44 +594,55 @@ __global__ __launch_bounds__(256, 2) void wgrad3r_kernel(const WgradDesc d) {
     constexpr int USTRIDE = NMG / NUNIT > 0 ? NMG / NUNIT : 1;
     constexpr int NFA = 3 * MT;
     static_assert(NFA <= NM1, "a tap has enough MFMA slots for the next tap's fragment reads");
-    for (int kc = kc0; kc < kc1; ++kc) {
+    auto step = [&](int kc, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;          // register set of chunk kc + 1 (split now) = of chunk kc + 3 (loaded now)
         const char* st = smem + stage * ST;
         char* st_next = smem + (stage ^ 1) * ST;
-        chunk_base(kc + 2);
-        bf16x8 fb[3][NT], fa[2][3][MT];
+        chunk_base(kc + 3);
+        bf16x8 fb[3][NT];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[pl][j] = tr_frag(st + b_foff + pl * PLB + j * 64, RSB);
+        {
+            bf16x8 fa[2][3][MT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[0][pl][i] = tr_frag(st + a_foff + pl * PLA + i * 64, RSA);
-        }
+            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int cb = t & 1;
+                for (int i = 0; i < MT; ++i) fa[0][pl][i] = tr_frag(st + a_foff + pl * PLA + i * 64, RSA);
 #pragma unroll
-            for (int tt = 0; tt < 6; ++tt)
+            for (int t = 0; t < NTW; ++t) {
+                const int cb = t & 1;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int tt = 0; tt < 6; ++tt)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int k = (tt * MT + i) * NT + j, idx = t * NM1 + k;
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][TA[tt]][i], fb[TB[tt]][j], acc[t][i][j], 0, 0, 0);
-                        // side jobs of this slot: the next tap's G fragments, one staging unit
-                        if (t + 1 < NTW && k < NFA) {
-                            const int pl = k / MT, fi = k - pl * MT;
-                            fa[cb ^ 1][pl][fi] = tr_frag(st + a_foff + (t + 1) * RSA + pl * PLA + fi * 64, RSA);
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int k = (tt * MT + i) * NT + j, idx = t * NM1 + k;
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][TA[tt]][i], fb[TB[tt]][j], acc[t][i][j], 0, 0, 0);
+                            // side jobs of this slot: the next tap's G fragments, one staging unit
+                            if (t + 1 < NTW && k < NFA) {
+                                const int pl = k / MT, fi = k - pl * MT;
+                                fa[cb ^ 1][pl][fi] = tr_frag(st + a_foff + (t + 1) * RSA + pl * PLA + fi * 64, RSA);
+                            }
+                            if (idx % USTRIDE == 0 && idx / USTRIDE < NUNIT) unit(SET, idx / USTRIDE, st_next);
                         }
-                        if (idx % USTRIDE == 0 && idx / USTRIDE < NUNIT) unit(idx / USTRIDE, st_next);
-                    }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = (NMG + USTRIDE - 1) / USTRIDE; u < NUNIT; ++u) unit(u, st_next);      // (units that found no slot)
+        for (int u = (NMG + USTRIDE - 1) / USTRIDE; u < NUNIT; ++u) unit(SET, u, st_next);      // (units that found no slot)
         lds_barrier();
         stage ^= 1;
+    };
+    int kc = kc0;
+    for (; kc + 1 < kc1; kc += 2) {
+        step(kc, std::integral_constant<int, 1>{});
+        step(kc + 1, std::integral_constant<int, 0>{});
     }
+    if (kc < kc1) step(kc, std::integral_constant<int, 1>{});
 
     const int li = lane & 31, kk = lane >> 5;
     float* out = d.splitk > 1 ? d.ws + (size_t)z * d.TH * NTW * d.Cg * d.Cd : d.out;
