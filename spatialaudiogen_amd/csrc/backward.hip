@@ -156,6 +156,29 @@ __device__ __forceinline__ void bn_moments4(const BnRef& bn, int C, int c4, floa
     invstd = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// the forward's scale / shift of this layer, bit for bit (bn_coeffs4 of elementwise.hip, p3.hip): with them relu(bn(y)) > 0 can be
+// re-derived from the raw conv output y that the backward reads anyway, and the retained activation need not be read for its sign
+__device__ __forceinline__ void bn_forward_coeffs4(const BnRef& bn, int C, int c4, float4& sc, float4& sh) {
+    float s4[4], h4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * c4 + k;
+        const double mean = bn.acc[c] * bn.inv_count;
+        double var = bn.acc[C + c] * bn.inv_count - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double a = (double)bn.gamma[c] / sqrt(var + (double)bn.eps);
+        s4[k] = (float)a;
+        h4[k] = (float)((double)bn.beta[c] - mean * a);
+    }
+    sc = make_float4(s4[0], s4[1], s4[2], s4[3]);
+    sh = make_float4(h4[0], h4[1], h4[2], h4[3]);
+}
+__device__ __forceinline__ float4 self_masked(float4 g, const float4& v, const float4& sc, const float4& sh) {
+    g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+    g.z = fmaf(v.z, sc.z, sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+    return g;
+}
+
 __device__ __forceinline__ float4 masked_sum(const float4* ga, const float4* gb, const float4* act, long i) {
     float4 v = ga[i];
     if (gb) v = add4(v, gb[i]);
@@ -168,10 +191,12 @@ __device__ __forceinline__ float4 masked_sum(const float4* ga, const float4* gb,
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb,
                                                             const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
-                                                            long n4, int C4, float* __restrict__ part) {
+                                                            long n4, int C4, float* __restrict__ part, int self_mask) {
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 mean, invstd;
     bn_moments4(bn, 4 * C4, c4, mean, invstd);
+    float4 fsc = make_float4(0.f, 0.f, 0.f, 0.f), fsh = fsc;
+    if (self_mask) bn_forward_coeffs4(bn, 4 * C4, c4, fsc, fsh);
     float4 sum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     // two elements per trip: eight 16-byte loads in flight per lane (one element per trip ran at 2.9 TB/s)
     const long stride = (long)gridDim.x * 256;
@@ -191,21 +216,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
             dz0.x = a0.x > 0.f ? dz0.x : 0.f; dz0.y = a0.y > 0.f ? dz0.y : 0.f; dz0.z = a0.z > 0.f ? dz0.z : 0.f; dz0.w = a0.w > 0.f ? dz0.w : 0.f;
             dz1.x = a1.x > 0.f ? dz1.x : 0.f; dz1.y = a1.y > 0.f ? dz1.y : 0.f; dz1.z = a1.z > 0.f ? dz1.z : 0.f; dz1.w = a1.w > 0.f ? dz1.w : 0.f;
         }
+        if (self_mask) { dz0 = self_masked(dz0, v0, fsc, fsh); dz1 = self_masked(dz1, v1, fsc, fsh); }
         accumulate(dz0, v0);
         accumulate(dz1, v1);
     }
-    if (i < n4) accumulate(masked_sum(ga, gb, act, i), y[i]);
+    if (i < n4) {
+        const float4 v = y[i];
+        float4 dz = masked_sum(ga, gb, act, i);
+        if (self_mask) dz = self_masked(dz, v, fsc, fsh);
+        accumulate(dz, v);
+    }
     channel_partials<2>(sum, C4, part);
 }
 
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, float* scratch, hipStream_t s) {
+                         double* acc, float* scratch, hipStream_t s, int self_mask) {
+    if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_reduce: self_mask replaces the activation operand");
     if (!ga || !y || !bn.acc || !acc || !scratch) return fail(SAGEN_ERR_NULL, "bn_bwd_reduce: null argument");
     if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_reduce: C=%d must be 4 * a divisor of 256", C);
     const long n4 = n_pixels * (C / 4);
     const int grid = reduce_grid(n4, C / 4);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
-                       (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch);
+                       (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask);
     SAGEN_LAUNCH_CHECK();
     hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, s, scratch, grid, 2 * C, acc, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
@@ -216,11 +248,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
                                                            const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
                                                            const double* __restrict__ acc, long n4, int C4, float4* __restrict__ dy,
                                                            float4* __restrict__ dz_out, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, int self_mask) {
     const int C = 4 * C4;
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 mean, invstd;
     bn_moments4(bn, C, c4, mean, invstd);
+    float4 fsc = make_float4(0.f, 0.f, 0.f, 0.f), fsh = fsc;
+    if (self_mask) bn_forward_coeffs4(bn, C, c4, fsc, fsh);
     float k0[4], k1[4], gs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -238,8 +272,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
         }
     }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const float4 dz = masked_sum(ga, gb, act, i);
         const float4 v = y[i];
+        float4 dz = masked_sum(ga, gb, act, i);
+        if (self_mask) dz = self_masked(dz, v, fsc, fsh);
         float4 o;
         o.x = gs[0] * (dz.x - k0[0] - (v.x - mean.x) * invstd.x * k1[0]);
         o.y = gs[1] * (dz.y - k0[1] - (v.y - mean.y) * invstd.y * k1[1]);
@@ -251,12 +286,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
 }
 
 int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
-                        long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s) {
+                        long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask) {
+    if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_apply: self_mask replaces the activation operand");
     if (!ga || !y || !bn.acc || !acc || !dy) return fail(SAGEN_ERR_NULL, "bn_bwd_apply: null argument");
     if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_apply: C=%d must be 4 * a divisor of 256", C);
     const long n4 = n_pixels * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(aligned_grid(n4, C / 4)), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
-                       (const float4*)act, (const float4*)y, bn, acc, n4, C / 4, (float4*)dy, (float4*)dz_out, dgamma, dbeta);
+                       (const float4*)act, (const float4*)y, bn, acc, n4, C / 4, (float4*)dy, (float4*)dz_out, dgamma, dbeta, self_mask);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -268,36 +304,50 @@ int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, cons
 // maximum is 0 (all inputs <= 0) routes nowhere that survives the ReLU mask, in TF as here.  Exact float ties between two
 // positive activations of one window would be credited twice (TF: first in scan order); not observed, measure-zero.
 // -----------------------------------------------------------------------------------------
+// MODE 0 writes the gradient at z0 = bn(y0) (after the ReLU mask); MODES 1 and 2 are the two passes of the batch-norm backward of
+// the stem with that gradient RECOMPUTED on the fly (1: per-channel sums of dz and dz*xhat; 2: dy0), so dz0 - 205 MB at batch 32 -
+// is never written nor read back: 0.93 GB of traffic for pool + batch-norm backward instead of 1.59 GB.
+template <int MODE>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restrict__ y0, const BnRef bn, const float4* __restrict__ pooled,
                                                           const float4* __restrict__ ga, const float4* __restrict__ gb,
-                                                          float4* __restrict__ dz, int B, int H, int W, int C4, int Ho, int Wo, int pt, int pl) {
+                                                          float4* __restrict__ out, int B, int H, int W, int C4, int Ho, int Wo, int pt, int pl,
+                                                          float* __restrict__ part, const double* __restrict__ acc, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
     const int C = 4 * C4;
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 sc, sh;
-    {
-        float s4[4], h4[4];
+    bn_forward_coeffs4(bn, C, c4, sc, sh);              // identical to bn_coeffs4 of the forward pool (elementwise.hip)
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), invstd = mean;
+    float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE != 0) bn_moments4(bn, C, c4, mean, invstd);
+    if (MODE == 2) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {       // identical to bn_coeffs4 of the forward pool (elementwise.hip)
+        for (int k = 0; k < 4; ++k) {
             const int c = 4 * c4 + k;
-            const double mean = bn.acc[c] * bn.inv_count;
-            double var = bn.acc[C + c] * bn.inv_count - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            const double a = (double)bn.gamma[c] / sqrt(var + (double)bn.eps);
-            s4[k] = (float)a;
-            h4[k] = (float)((double)bn.beta[c] - mean * a);
+            k0[k] = (float)(acc[c] * bn.inv_count);
+            k1[k] = (float)(acc[C + c] * bn.inv_count);
+            gs[k] = bn.gamma[c] * (&invstd.x)[k];
         }
-        sc = make_float4(s4[0], s4[1], s4[2], s4[3]);
-        sh = make_float4(h4[0], h4[1], h4[2], h4[3]);
+        if (blockIdx.x == 0 && threadIdx.x < C4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * c4 + k;
+                if (dbeta) dbeta[c] = (float)acc[c];
+                if (dgamma) dgamma[c] = (float)acc[C + c];
+            }
+        }
     }
+    float4 sum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     const long total = (long)B * H * W * C4;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         long p = idx / C4;
         const int j = (int)(p % W); p /= W;
         const int i = (int)(p % H);
         const int b = (int)(p / H);
-        float4 a = y0[idx];
-        a.x = fmaxf(fmaf(a.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(a.y, sc.y, sh.y), 0.f);
-        a.z = fmaxf(fmaf(a.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(a.w, sc.w, sh.w), 0.f);
+        const float4 v = y0[idx];
+        float4 a;
+        a.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); a.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        a.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); a.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         const int oi0 = max((i + pt - 1) >> 1, 0), oi1 = min((i + pt) >> 1, Ho - 1);      // windows rows 2*oi - pt .. 2*oi - pt + 2
         const int oj0 = max((j + pl - 1) >> 1, 0), oj1 = min((j + pl) >> 1, Wo - 1);
@@ -311,20 +361,62 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
                 g.z += (a.z == pv.z) ? gv.z : 0.f; g.w += (a.w == pv.w) ? gv.w : 0.f;
             }
         g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
-        dz[idx] = g;
+        if (MODE == 0) out[idx] = g;
+        else if (MODE == 1) {
+            sum[0] = add4(sum[0], g);
+            sum[1].x = fmaf(g.x, (v.x - mean.x) * invstd.x, sum[1].x); sum[1].y = fmaf(g.y, (v.y - mean.y) * invstd.y, sum[1].y);
+            sum[1].z = fmaf(g.z, (v.z - mean.z) * invstd.z, sum[1].z); sum[1].w = fmaf(g.w, (v.w - mean.w) * invstd.w, sum[1].w);
+        } else {
+            float4 o;
+            o.x = gs[0] * (g.x - k0[0] - (v.x - mean.x) * invstd.x * k1[0]);
+            o.y = gs[1] * (g.y - k0[1] - (v.y - mean.y) * invstd.y * k1[1]);
+            o.z = gs[2] * (g.z - k0[2] - (v.z - mean.z) * invstd.z * k1[2]);
+            o.w = gs[3] * (g.w - k0[3] - (v.w - mean.w) * invstd.w * k1[3]);
+            out[idx] = o;
+        }
     }
+    if (MODE == 1) channel_partials<2>(sum, C4, part);
+}
+
+static int maxpool_bwd_check(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* out, int C) {
+    if (!y0 || !bn.acc || !pooled || !ga || !out) return fail(SAGEN_ERR_NULL, "maxpool_bwd: null argument");
+    if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bwd: C=%d must be a multiple of 4", C);
+    return SAGEN_OK;
 }
 
 int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dz, int B,
                        int H, int W, int C, hipStream_t s) {
-    if (!y0 || !bn.acc || !pooled || !ga || !dz) return fail(SAGEN_ERR_NULL, "maxpool_bwd: null argument");
-    if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bwd: C=%d must be a multiple of 4", C);
+    if (int rc = maxpool_bwd_check(y0, bn, pooled, ga, dz, C)) return rc;
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
     const long total = (long)B * H * W * (C / 4);
     // (i + pt - 1) >> 1 must be ceil((i + pt - 2) / 2): true for i + pt >= 1; i + pt == 0 gives -1 >> 1 = -1 -> clamped to 0
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(aligned_grid(total, C / 4)), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled,
-                       (const float4*)ga, (const float4*)gb, (float4*)dz, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<0>, dim3(aligned_grid(total, C / 4)), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled,
+                       (const float4*)ga, (const float4*)gb, (float4*)dz, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, (float*)nullptr,
+                       (const double*)nullptr, (float*)nullptr, (float*)nullptr);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// x0 = maxpool(relu(bn0(y0))): gradient at y0 and at gamma / beta from the gradient at x0 (ga + gb), dz0 never materialised
+int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dy0, int B,
+                          int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s) {
+    if (int rc = maxpool_bwd_check(y0, bn, pooled, ga, dy0, C)) return rc;
+    if (!acc || !scratch) return fail(SAGEN_ERR_NULL, "maxpool_bn_bwd: null accumulator / scratch");
+    if (256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bn_bwd: C=%d must be 4 * a divisor of 256", C);
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
+    const long total = (long)B * H * W * (C / 4);
+    const int grid = reduce_grid(total, C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled, (const float4*)ga,
+                       (const float4*)gb, (float4*)nullptr, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, scratch, (const double*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
+    SAGEN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, s, scratch, grid, 2 * C, acc, (float*)nullptr);
+    SAGEN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3(aligned_grid(total, C / 4)), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled,
+                       (const float4*)ga, (const float4*)gb, (float4*)dy0, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, (float*)nullptr,
+                       (const double*)acc, dgamma, dbeta);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

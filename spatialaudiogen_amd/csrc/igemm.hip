@@ -695,22 +695,11 @@ __device__ __forceinline__ float pack_source(const PackJob& j, int n, int k) {
     }
 }
 
-__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    // job of this block: the last one whose first_block <= blockIdx.x (wave-uniform binary search)
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const PackJob j = jobs[lo];
-    const long idx = ((long)(blockIdx.x - j.first_block) * 256 + threadIdx.x) * 4;
-    if (idx >= (long)j.N * j.Kpad) return;
-    const int n = (int)(idx / j.Kpad), k = (int)(idx - (long)n * j.Kpad);      // Kpad % 16 == 0: the four elements share the row
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = pack_source(j, n, k + e);
+// writes elements (n, k .. k+3) of job j: the fp32 pack and the three bf16 planes, tiled [Kpad/16][plane][N][16] (same arithmetic as
+// pack_split_kernel, igemm3.hip)
+__device__ __forceinline__ void pack_store4(const PackJob& j, int n, int k, const float v[4]) {
+    const long idx = (long)n * j.Kpad + k;
     *reinterpret_cast<float4*>(j.dst + idx) = make_float4(v[0], v[1], v[2], v[3]);
-    // the three bf16 planes, tiled [Kpad/16][plane][N][16] (same arithmetic as pack_split_kernel, igemm3.hip)
     __bf16* w3 = reinterpret_cast<__bf16*>(j.dst + (long)j.N * j.Kpad);
     __bf16 h[4], m[4], l[4];
 #pragma unroll
@@ -725,6 +714,43 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     *reinterpret_cast<bf16x4_t*>(w3 + o) = bf16x4_t{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<bf16x4_t*>(w3 + o + (long)j.N * 16) = bf16x4_t{m[0], m[1], m[2], m[3]};
     *reinterpret_cast<bf16x4_t*>(w3 + o + (long)j.N * 32) = bf16x4_t{l[0], l[1], l[2], l[3]};
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    // job of this block: the last one whose first_block <= blockIdx.x (wave-uniform binary search)
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int blk = (int)blockIdx.x - j.first_block;
+    if (j.kind == PACK_CONV) {
+        // HWIO -> [N][K] is a transpose: a 32 (k) x 32 (n) tile per block, read along n (the source's fast index: 128-byte runs;
+        // thread-per-destination-element reads fetched 335 MB for 123 MB of variables), written along k
+        __shared__ float tile[32][33];
+        const int tiles_k = (j.Kpad + 31) >> 5;
+        const int tn = blk / tiles_k, tk = blk - tn * tiles_k;
+        const int n0 = tn * 32, k0 = tk * 32;
+        const int nl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[kl + 8 * r][nl] = pack_source(j, n0 + nl, k0 + kl + 8 * r);
+        __syncthreads();
+        const int n = n0 + (threadIdx.x >> 3), k = k0 + 4 * (threadIdx.x & 7);
+        if (n >= j.N || k >= j.Kpad) return;            // (Kpad % 16 == 0: a group of four is inside or outside as a whole)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[4 * (threadIdx.x & 7) + e][threadIdx.x >> 3];
+        pack_store4(j, n, k, v);
+        return;
+    }
+    const long idx = ((long)blk * 256 + threadIdx.x) * 4;
+    if (idx >= (long)j.N * j.Kpad) return;
+    const int n = (int)(idx / j.Kpad), k = (int)(idx - (long)n * j.Kpad);      // Kpad % 16 == 0: the four elements share the row
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = pack_source(j, n, k + e);
+    pack_store4(j, n, k, v);
 }
 
 int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s) {

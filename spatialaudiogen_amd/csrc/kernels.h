@@ -132,7 +132,10 @@ struct PackJob {
     int p[7] = {0, 0, 0, 0, 0, 0, 0};
     int first_block = 0;             // of this job inside the launch (1024 elements per block)
 };
-inline int pack_job_blocks(long N, long Kpad) { return (int)((N * Kpad + 1023) / 1024); }
+// conv jobs (a [K][N] -> [N][K] transpose) run as 32 x 32 tiles through LDS, the others as flat runs of 1024 elements
+inline int pack_job_blocks(int kind, long N, long Kpad) {
+    return kind == PACK_CONV ? (int)(((N + 31) / 32) * ((Kpad + 31) / 32)) : (int)((N * Kpad + 1023) / 1024);
+}
 int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s);
 // deconv as depth-to-space conv: n = (ry, rx, o), k = (dp, dq, c);
 // Wp[n][k] = W[ry + sh*dp][rx + sw*dq][o][c] (0 when outside the kh x kw kernel)
@@ -245,14 +248,20 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
 // xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat) (overwritten);
 // scratch >= reduce_scratch_floats(C) floats
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, float* scratch, hipStream_t s);
+                         double* acc, float* scratch, hipStream_t s, int self_mask = 0);
 // dy = gamma*invstd*(dz - acc0/N - xhat*acc1/N) (+ dz to `dz_out`, nullable); writes dgamma = acc1, dbeta = acc0 (nullable)
 int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
-                        long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s);
+                        long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask = 0);
+// self_mask = 1 (act must be null): the ReLU mask is relu(bn(y)) > 0, re-derived from y with the forward's own scale / shift - for a
+// layer whose activation IS relu(bn(y)) (no residual), e.g. conv_1 of a residual block: one tensor less to read in both passes
 // backward of maxpool3x3s2(relu(bn(y0))) (resnet.py:134-135): dz0[b,i,j,c] = (a > 0) * sum over the windows containing (i,j) of
 // [a == pooled] * (ga + gb), a = relu(bn(y0)); pooled = the forward's pool output [B,Ho,Wo,C]
 int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dz,
                        int B, int H, int W, int C, hipStream_t s);
+// the same followed by the stem's batch-norm backward, fused: dy0 = d/dy0 of maxpool(relu(bn0(y0))), gamma / beta gradients;
+// acc: fp64 [2][C] (overwritten), scratch >= reduce_scratch_floats(C)
+int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dy0, int B,
+                          int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s);
 // out[m][c] = sum_{r < rep} (ina[(m*rep + r)*lda + c] + inb[(m*rep + r)*ldb + c]); inb nullable (backward of tf.tile / concat fan-in)
 int sum_rows_launch(const float* ina, int lda, const float* inb, int ldb, int rep, long M, int C, float* out, int ldo, hipStream_t s);
 int acc_to_f32_launch(const double* acc, float* dst, int n, hipStream_t s);

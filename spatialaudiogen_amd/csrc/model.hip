@@ -251,7 +251,7 @@ static PackJob forward_pack_job(const sagen_ctx* c, const VarSpec& vs) {
 // uploads a job table into `dev` (capacity checked by the caller) and returns the number of blocks of the launch
 int sagen_upload_pack_jobs(std::vector<PackJob>& jobs, void* dev, hipStream_t s) {
     int nb = 0;
-    for (auto& j : jobs) { j.first_block = nb; nb += pack_job_blocks(j.N, j.Kpad); }
+    for (auto& j : jobs) { j.first_block = nb; nb += pack_job_blocks(j.kind, j.N, j.Kpad); }
     if (!jobs.empty() && hipMemcpyAsync(dev, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     return nb;
 }

@@ -258,14 +258,17 @@ struct Bwd : Fwd {
     double* bnb_acc(int li) { return reinterpret_cast<double*>(c->p("t:bnbacc" + sfx)) + (size_t)li * 2 * 512; }
     // training-mode BN of layer `li` backward: dz = (ga + gb) * (act > 0) -> dy (and dz), dgamma, dbeta
     void bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
-                float* dy, float* dz) {
+                float* dy, float* dz, bool self_mask = false) {
         if (rc) return;
         const BnRef bn = bn_ref(li, bn_name, npix);
         double* acc = bnb_acc(li);
         layer = "bnbwd:" + bn_name;
-        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, act, y, bn, npix, C, acc, c->p(redws), s); });
+        static const bool no_self = getenv("SAGEN_BN_READ_ACT") != nullptr;     // (A/B: read the retained activation for its sign)
+        const int sm = self_mask && !no_self;
+        const float* a = sm ? nullptr : act;
+        timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, a, y, bn, npix, C, acc, c->p(redws), s, sm); });
         timed("bn_bwd_apply_kernel", 0.0, [&] {
-            return bn_bwd_apply_launch(ga, gb, act, y, bn, acc, npix, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s); });
+            return bn_bwd_apply_launch(ga, gb, a, y, bn, acc, npix, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s, sm); });
     }
 
     void resnet_bwd(const std::string& scope, const float* gfeat) {
@@ -296,7 +299,7 @@ struct Bwd : Fwd {
             wgrad("wgrad:" + pfx + "/conv_2", wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_2/weights"));
             dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA);
             // a1 = relu(bn1(y1))
-            bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr);
+            bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr, true);      // a1 > 0 <=> bn1(y1) > 0: a1 is not read
             if (first) {
                 wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
                 wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));
@@ -317,8 +320,15 @@ struct Bwd : Fwd {
         float* dz0 = c->p("t:dz0" + sfx);
         const BnRef bn0 = bn_ref(0, name, (long)B * 112 * 224);
         layer = "poolbwd:" + scope;
-        timed("maxpool_bwd_kernel", 0.0, [&] { return maxpool_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, s); });
-        bn_bwd(name, 0, dz0, nullptr, nullptr, c->p("y0" + sfx), (long)B * 112 * 224, 64, dz0, nullptr);       // (in place: elementwise)
+        static const bool unfused = getenv("SAGEN_STEM_BWD_UNFUSED") != nullptr;
+        if (unfused) {
+            timed("maxpool_bwd_kernel", 0.0, [&] { return maxpool_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, s); });
+            bn_bwd(name, 0, dz0, nullptr, nullptr, c->p("y0" + sfx), (long)B * 112 * 224, 64, dz0, nullptr);       // (in place: elementwise)
+        } else {
+            timed("maxpool_bn_bwd_kernels", 0.0, [&] {
+                return maxpool_bn_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, bnb_acc(0), c->p(redws),
+                                             grad(name + "/bn/gamma"), grad(name + "/bn/beta"), s); });
+        }
         // 7x7/2 over the zero-bordered 4-channel frame: the 7 (+1 zero) horizontal taps x 4 channels are 32 contiguous floats
         WgradDesc w = wdesc(c->p("xpad" + sfx), 229, 454, 4, 32, dz0, 112, 224, 64, 64, 7, 1, 2, 2, 0, 0);
         wgrad("wgrad:" + name, w, c->p("t:stemtmp" + sfx));
