@@ -5,6 +5,7 @@
 // (channels innermost, C % 4 == 0); per-channel sums are accumulated in registers, reduced through LDS and added to fp64
 // accumulators with one atomic per channel and workgroup (same scheme as the forward BN statistics, igemm_common.h).
 #include "kernels.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace sagen {
@@ -404,10 +405,13 @@ int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled,
     if (int rc = maxpool_bwd_check(y0, bn, pooled, ga, dy0, C)) return rc;
     if (!acc || !scratch) return fail(SAGEN_ERR_NULL, "maxpool_bn_bwd: null accumulator / scratch");
     if (256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bn_bwd: C=%d must be 4 * a divisor of 256", C);
+    if (C > 128) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bn_bwd: C=%d > 128 (scratch rows)", C);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
     const long total = (long)B * H * W * (C / 4);
-    const int grid = reduce_grid(total, C / 4);
+    // (gather-heavy: more, shorter workgroups than the streaming reductions; rows of 2C floats)
+    static const int gmax = getenv("SAGEN_POOLBWD_GRID") ? atoi(getenv("SAGEN_POOLBWD_GRID")) : 2048;
+    const int grid = (int)std::max<long>(1, std::min<long>(cdiv(total, 256 * 4), gmax));
     hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled, (const float4*)ga,
                        (const float4*)gb, (float4*)nullptr, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, scratch, (const double*)nullptr,
                        (float*)nullptr, (float*)nullptr);

@@ -259,7 +259,7 @@ int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, cons
 int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dz,
                        int B, int H, int W, int C, hipStream_t s);
 // the same followed by the stem's batch-norm backward, fused: dy0 = d/dy0 of maxpool(relu(bn0(y0))), gamma / beta gradients;
-// acc: fp64 [2][C] (overwritten), scratch >= reduce_scratch_floats(C)
+// acc: fp64 [2][C] (overwritten), scratch >= reduce_scratch_floats(1024) floats (4096 partial rows of 2C, C <= 128)
 int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dy0, int B,
                           int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s);
 // out[m][c] = sum_{r < rep} (ina[(m*rep + r)*lda + c] + inb[(m*rep + r)*ldb + c]); inb nullable (backward of tf.tile / concat fan-in)
