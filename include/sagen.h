@@ -138,6 +138,10 @@ const char* sagen_tile_name(int tile);
  * writes one line per launch, "kernel\tlayer\tmicroseconds\tflops\n"; returns the number of lines
  * (>= 0) or a negative sagen_status. */
 int    sagen_profile_enable(sagen_ctx* ctx, int on);
+/* Per-context switches.  "materialize_mask" (default 0): 1 keeps the mask decoder's last layer (model.py:320-337) and the mask
+ * application as two kernels so that the logits exist in the workspace ("separation/deconv1" of sagen_get_intermediate); 0 lets the
+ * forward fold sigmoid + track mix into the deconvolution's epilogue (same result, 94 MB less HBM traffic per batch of 32). */
+int    sagen_set_option(sagen_ctx* ctx, const char* name, int value);
 int    sagen_profile_report(sagen_ctx* ctx, char* buf, size_t buflen);
 
 /* ---- op-level (unit-testable; same conventions) ----------------------------------------- */

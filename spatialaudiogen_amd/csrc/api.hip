@@ -21,6 +21,7 @@ int sagen_plan_set_impl(sagen_ctx* c, const char* layer, int tile, int splitk);
 int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen);
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride);
+int sagen_set_option_impl(sagen_ctx* c, const char* name, int value);
 size_t sagen_train_workspace_bytes_impl(sagen_ctx* c);
 int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving, void* tws,
                           size_t tws_bytes, hipStream_t s);
@@ -98,6 +99,11 @@ int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float**
                            int64_t* pixel_stride) {
     if (!ctx || !name || !data || !ndim || !shape || !pixel_stride) return fail(SAGEN_ERR_NULL, "sagen_get_intermediate: null argument");
     return guarded([&] { return sagen_get_intermediate_impl(ctx, name, data, ndim, shape, pixel_stride); });
+}
+
+int sagen_set_option(sagen_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return fail(SAGEN_ERR_NULL, "sagen_set_option: null argument");
+    return guarded([&] { return sagen_set_option_impl(ctx, name, value); });
 }
 
 int sagen_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {

@@ -149,7 +149,7 @@ constexpr int OUT_SHIFT = 1216;   // 768 + 448
 template <int NTR>
 __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ dmask, long dmask_bstride, int dmask_f0,
                                                          const float2* __restrict__ spec, const float* __restrict__ coeffs,
-                                                         float* __restrict__ frames) {
+                                                         float* __restrict__ frames, const float* __restrict__ ebuf) {
     __shared__ __attribute__((aligned(16))) float2 fftbuf[2048];      // FFT ping-pong; before that: staging of the mask rows
     float2* const bufA = fftbuf;
     float2* const bufB = fftbuf + 1024;
@@ -174,6 +174,16 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
     // XOR-swizzled by the row so the row-wise reads below spread over the banks) and consumed by NTR/16 lanes per bin; the next
     // pass's loads are in flight while the current one is reduced.  (The first version let every lane walk its own 128-byte row:
     // 64 cache lines per load instruction, 1.07 TB/s.)
+    if (ebuf != nullptr) {
+        // the sums were formed in the epilogue of the deconvolution that produced the logits (igemm_epilogue_maskmix): 32 bytes per bin
+        const float4* src = reinterpret_cast<const float4*>(ebuf + ((long)b * MASK_NF + fi) * 1024 * 8);
+        __syncthreads();                         // X visible
+        for (int k = tid; k < 1024; k += 256) {
+            const float4 lo = src[2 * k], hi = src[2 * k + 1];
+            E[0][k] = lo.x; E[1][k] = lo.y; E[2][k] = lo.z; E[3][k] = lo.w; E[4][k] = hi.x; E[5][k] = hi.y;
+        }
+        __syncthreads();
+    } else {
     constexpr int NC = NTR / 4;                  // 16-byte chunks per mask row
     constexpr int RPP = 4096 / NTR;              // rows per pass (16 KiB of staging)
     constexpr int TPRW = 256 / RPP;              // lanes per row: each takes 16 tracks
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
             if (part == 0) E[c][ps * RPP + row] = e[c];
         }
         __syncthreads();                         // the staging area is rewritten by the next pass (and then by the FFT)
+    }
     }
 
     float* fout = frames + ((long)b * MASK_NF + fi) * 3 * 1024;
@@ -279,17 +290,17 @@ __global__ __launch_bounds__(256) void ola_mix_kernel(const float* __restrict__ 
 size_t mask_istft_scratch_bytes(int B) { return (size_t)B * MASK_NF * 3 * 1024 * sizeof(float); }
 
 int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, const float* spec, const float* coeffs,
-                          int B, int ntracks, float* out, float* scratch, hipStream_t s) {
+                          int B, int ntracks, float* out, float* scratch, hipStream_t s, const float* ebuf) {
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     if (dmask_f0 > MASK_F_LO) return fail(SAGEN_ERR_SHAPE, "mask_istft: dmask must start at frame <= %d", MASK_F_LO);
     dim3 grid(MASK_NF, B);
     if (ntracks == 32)
-        hipLaunchKernelGGL(mask_istft_kernel<32>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch);
+        hipLaunchKernelGGL(mask_istft_kernel<32>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf);
     else if (ntracks == 64)
-        hipLaunchKernelGGL(mask_istft_kernel<64>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch);
+        hipLaunchKernelGGL(mask_istft_kernel<64>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf);
     else if (ntracks == 16)
-        hipLaunchKernelGGL(mask_istft_kernel<16>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch);
+        hipLaunchKernelGGL(mask_istft_kernel<16>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf);
     else
         return fail(SAGEN_ERR_UNSUPPORTED, "mask_istft: num_sep_tracks=%d (supported: 16, 32, 64)", ntracks);
     SAGEN_LAUNCH_CHECK();

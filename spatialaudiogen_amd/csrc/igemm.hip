@@ -354,6 +354,12 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     const int bk = kTiles[t].bk;
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
+    if (d.mm_out != nullptr) {              // fused decoder tail: igemm3_kernel tiles holding one mask frame of one window
+        const bool b3 = kTiles[t].split && !kTiles[t].dw3 && !kTiles[t].s2 && !kTiles[t].p3;
+        if (!b3 || kTiles[t].bm > 128 || kTiles[t].bn > 128 || d.Cout != 32 || d.dsh * d.dsw <= 1 || d.Wg % kTiles[t].bm ||
+            (d.dsw * d.Cout) % kTiles[t].bn || d.splitk != 1 || d.in_scale || d.bn_in.acc || !d.mm_coeffs)
+            return false;
+    }
     if (kTiles[t].dw3 && !dw3_ok(d)) return false;
     if (kTiles[t].p3 && (d.xp3 == nullptr || d.splitk != 1)) return false;
     if (!kTiles[t].p3 && d.xp3 != nullptr && d.x == nullptr) return false;      // only the planes were provided
@@ -367,6 +373,7 @@ IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: IgemmTile index
     if (force && d.M > 128 && d.N >= 64 && igemm_tile_ok(d, (IgemmTile)atoi(force))) return (IgemmTile)atoi(force);
     static const bool fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
+    if (d.mm_out != nullptr) return TILE_B3_64x128;
     auto blocks = [&](IgemmTile t) { return (long)cdiv(d.M, tile_bm(t)) * cdiv(d.N, tile_bn(t)) * d.splitk; };
     const long want = 2 * 256;                 // >= 2 workgroups per CU
     if (d.w_split && !fp32_only) {             // the bf16x3 kernels are the faster family wherever their planes exist

@@ -327,6 +327,11 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
         if (t + 1 < nsteps) step(std::integral_constant<int, 1>{}, t + 1);
     }
 
+    if (d.mm_out != nullptr) {           // fused decoder tail (igemm_tile_ok admits only the tiles compiled here)
+        if constexpr (BM <= 128 && BN <= 128 && WM * BN + 7 * 32 <= 2 * STAGE_F && !PRO)
+            igemm_epilogue_maskmix<BM, BN, WM, WN, 2 * STAGE_F>(d, acc, smem, m0, n0, tid);
+        return;
+    }
     if (!igemm_epilogue_rows<BM, BN, WM, WN, 2 * STAGE_F>(d, acc, s_row, smem, n0, tid))
         igemm_epilogue<BM, BN, WM, WN>(d, acc, s_row, smem, m0, n0, z, tid);
 }

@@ -272,4 +272,86 @@ __device__ __forceinline__ bool igemm_epilogue_rows(const IgemmDesc& d, f32x16 (
     }
 }
 
+// ---- fused decoder tail (IgemmDesc::mm_*): the depth-to-space tile of deconv1 goes through LDS one wave-row at a time; a tile
+// holds ONE mask frame of ONE window (BM divides the grid row, BN divides dsw*Cout: igemm_tile_ok), so the six weight rows
+// (2 localisation steps x 3 outputs x 32 tracks) are loaded once per workgroup.  Two lanes per output pixel, 16 tracks each.
+// Frame <-> sample geometry as in fft.hip (mask_istft_kernel): output sample n = 256 f + p - 1216, localisation step n / 1600.
+template <int BM, int BN, int WM, int WN, int CAP>
+__device__ __forceinline__ void igemm_epilogue_maskmix(const IgemmDesc& d, f32x16 (&acc)[WM / 32][WN / 32], float* red, int m0, int n0,
+                                                       int tid) {
+    constexpr int NTR = 32;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+    constexpr int SUBS = BN / NTR, ITEMS = WM * SUBS * 2;
+    static_assert(WM * BN + 7 * NTR <= CAP, "mask-mix staging must fit the tile ring");
+    static_assert(ITEMS % 2 == 0 && BN % NTR == 0, "whole output pixels per tile");
+    float* const tile = red;                        // [WM][BN]
+    float* const wl = red + WM * BN;                // [6][NTR]
+    float* const bs = wl + 6 * NTR;                 // [NTR]
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, kk = lane >> 5;
+    const int HgWg = d.Hg * d.Wg;
+    const int b = m0 / HgWg;
+    const int rem = m0 - b * HgWg;
+    const int ia = rem / d.Wg;
+    const int q0 = d.g_w0 + rem - ia * d.Wg;
+    const int dswC = d.dsw * NTR;
+    const int ry = n0 / dswC, rx0 = (n0 - ry * dswC) / NTR;
+    const int y = (d.g_h0 + ia) * d.dsh + ry, fi = y - d.mm_row0;
+    if (m0 >= d.M || y >= d.Hlim || fi < 0 || fi >= d.mm_nf) return;          // (uniform over the workgroup)
+    const int f = d.mm_f_lo + fi;
+    const int n_lo = max(256 * f - 1216, 0), n_hi = min(256 * f - 1216 + 1023, 4799);
+    const int s_lo = n_lo / 1600, s_hi = n_hi / 1600;
+    const bool two = s_hi != s_lo;
+    for (int i = tid; i < 6 * NTR; i += 256) {
+        const int j = i % NTR, o = (i / NTR) % 3, si = i / (3 * NTR);
+        wl[i] = d.mm_coeffs[(((long)b * 3 + (si ? s_hi : s_lo)) * 3 + o) * (NTR + 1) + j];
+    }
+    if (tid < NTR) bs[tid] = d.bias ? d.bias[tid] : 0.f;
+#pragma unroll
+    for (int part = 0; part < WAVES_M; ++part) {
+        if (wm == part) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)      // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+                        tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int item = tid; item < ITEMS; item += 256) {
+            const int half = item & 1, sub = (item >> 1) % SUBS, r = (item >> 1) / SUBS;
+            float e[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(tile + r * BN + sub * NTR + half * 16 + 4 * q4);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = half * 16 + 4 * q4 + u;
+                    const float sg = 1.f / (1.f + expf(-(vv[u] + bs[j])));
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        e[o] = fmaf(wl[o * NTR + j], sg, e[o]);
+                        if (two) e[3 + o] = fmaf(wl[(3 + o) * NTR + j], sg, e[3 + o]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) e[c] += __shfl_xor(e[c], 1);
+            const int row = part * WM + r;
+            const int x = (q0 + row) * d.dsw + rx0 + sub;
+            if (half == 0 && m0 + row < d.M && x < d.Wlim) {
+                float4* dst = reinterpret_cast<float4*>(d.mm_out + (((long)b * d.mm_nf + fi) * d.Wlim + x) * 8);
+                dst[0] = make_float4(e[0], e[1], e[2], e[3]);
+                dst[1] = make_float4(e[4], e[5], 0.f, 0.f);
+            }
+        }
+        if (part + 1 < WAVES_M) __syncthreads();
+    }
+}
+
 }  // namespace sagen

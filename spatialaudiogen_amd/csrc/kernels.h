@@ -62,6 +62,13 @@ struct IgemmDesc {
     unsigned xp3_bytes = 0, xp3_cstride = 0;
     int p3_np = 0;
     unsigned p3_magic_wp = 0, p3_magic_h = 0;   // filled by conv3p_dispatch: floor(2^32 / d) + 1 for d = Win + 1, Hin (exact quotients by mul-hi)
+    // Fused decoder tail (deconv1 of the mask decoder at inference, model.py:326-337 + 421-434): instead of the 32 mask logits of an
+    // output pixel the epilogue writes E[c] = sum_j w[step_c][out_c][j] * sigmoid(logit_j + bias_j), c = (step lo/hi, output) -
+    // what mask_istft_kernel would compute from them; the logits (94 MB at batch 32) never reach HBM.  igemm3_kernel tiles only.
+    const float* mm_coeffs = nullptr; // localisation coefficients [B][3 steps][3 outputs][Cout + 1]
+    float* mm_out = nullptr;          // [B][mm_nf][Wlim][8] (6 used)
+    int mm_row0 = 0, mm_nf = 0;       // output row y holds mask frame mm_f_lo + (y - mm_row0); rows outside [0, mm_nf) are not produced
+    int mm_f_lo = 1;
     // debug builds (-DSAGEN_TRACE): phase timeline of workgroup `trace_block`
     void* trace = nullptr;
     int trace_block = 0;
@@ -193,7 +200,8 @@ int stft_launch(const float* audio, int B, int n_samples, int f0, int f1, float*
 size_t mask_istft_scratch_bytes(int B);
 int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, const float* spec,
                           const float* coeffs, int B, int ntracks, float* out, float* scratch,
-                          hipStream_t s);
+                          hipStream_t s, const float* ebuf = nullptr);
+// ebuf (then dmask may be null): the weighted sigmoid sums E[B][23][1024][8] written by the fused deconv1 epilogue (IgemmDesc::mm_out)
 
 // -----------------------------------------------------------------------------------------
 // evaluation metrics (eval.hip)

@@ -96,6 +96,8 @@ struct sagen_ctx {
     bool train_mode = false;
     bool train_ready = false;
     bool stem_fused = true;                // inference: 7x7/2 stem + max-pool as one kernel (stempool.hip); SAGEN_NO_STEMPOOL=1 disables
+    bool materialize_mask = false;         // sagen_set_option("materialize_mask"): keep deconv1 -> mask as two kernels so that the logits exist
+    bool mask_fused_last = false;          // the last forward ran the fused decoder tail: "separation/deconv1" holds no logits
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
     size_t tws_floats = 0;
     float* tws = nullptr;
@@ -390,7 +392,7 @@ struct Fwd {
 
     // tfw.deconv_2d (core.py:96-153) as a stride-1 conv with a depth-to-space epilogue
     void deconv(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int a0, int a1, int Ylim,
-                long y_bstride, long y_row0) {
+                long y_bstride, long y_row0, const float* mm_coeffs = nullptr, float* mm_out = nullptr, int mm_nf = 0) {
         const std::string name = "separation/deconv" + std::to_string(l + 1);
         layer = name;
         const int kh = AENC_K[l][0], kw = AENC_K[l][1], sh = AENC_S[l][0], sw = AENC_S[l][1];
@@ -409,6 +411,7 @@ struct Fwd {
         d.y_bstride = y_bstride > 0 ? y_bstride : (long)Hout * Wout * ldy;
         d.y = y - y_row0 * d.y_rstride;
         d.relu_out = relu;
+        if (mm_out) { d.mm_coeffs = mm_coeffs; d.mm_out = mm_out; d.mm_row0 = (int)y_row0; d.mm_nf = mm_nf; d.mm_f_lo = 1; }
         gemm(d);
     }
 

@@ -408,16 +408,26 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         f.deconv(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
                  2 * c->enc_c[l], true, 0, 0, 0, 0, 0);
     }
-    // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16
-    f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44);
-    if (fork2) {                                         // the mix needs the localisation coefficients
+    // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16.
+    // Inference: sigmoid and the track-weighted sums run in its epilogue (igemm_epilogue_maskmix) and the 94 MB of logits are never
+    // written; the training step keeps them (the adjoint reads them), and so does sagen_set_option("materialize_mask", 1).
+    static const bool no_maskfuse = getenv("SAGEN_NO_MASKFUSE") != nullptr;
+    const bool fused_tail = !no_maskfuse && !c->train_mode && !c->materialize_mask && !c->fp32_only && c->nsep == 32;
+    c->mask_fused_last = fused_tail;
+    if (fork2 && fused_tail) {                           // the epilogue needs the localisation coefficients (three small FCs, long done)
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
+        SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
+    float* const ebuf = fused_tail ? c->p("dmask") : nullptr;       // (32 bytes per bin in the buffer of the 128-byte logits)
+    f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44, c->p("coeffs"), ebuf, 23);
+    if (fork2 && !fused_tail) {                          // the mix needs the localisation coefficients
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
         SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
     f.layer = "separation/mask-istft-mix";
     f.timed("mask_istft_kernel+ola_mix_kernel", 0.0, [&] {
         return mask_istft_mix_launch(c->p("dmask"), 23L * 1024 * c->nsep, 1, c->p("spec"), c->p("coeffs"), B, c->nsep, out,
-                                     c->p("frames"), s); });
+                                     c->p("frames"), s, ebuf); });
     return f.rc;
 }
 int sagen_forward_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video_u8, const float* flow, float* out, hipStream_t s) {
@@ -523,12 +533,21 @@ int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32
     for (int k = 0; k < 4; ++k) shape[k] = c->vars[i].shape[k];
     return SAGEN_OK;
 }
+int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
+    const std::string n = name;
+    if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
+    return fail(SAGEN_ERR_UNSUPPORTED, "sagen_set_option: unknown option %s", name);
+}
+
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride) {
     if (!c->ws) return fail(SAGEN_ERR_WORKSPACE, "no workspace bound");
     auto it = c->named.find(name);
     if (it == c->named.end()) return fail(SAGEN_ERR_SHAPE, "unknown intermediate %s", name);
     const Named& nm = it->second;
+    if (c->mask_fused_last && std::string(name) == "separation/deconv1")
+        return fail(SAGEN_ERR_UNSUPPORTED, "separation/deconv1: the last forward fused the mask into the deconvolution's epilogue - "
+                    "sagen_set_option(ctx, \"materialize_mask\", 1) keeps the logits");
     *data = c->ws + nm.buf.off + nm.extra_off;
     *ndim = nm.ndim;
     for (int k = 0; k < 4; ++k) shape[k] = nm.shape[k];

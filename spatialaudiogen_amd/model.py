@@ -70,6 +70,10 @@ class _Ctx(object):
                                    self.workspace.numel() * 4, stream))
         self._keep = keep
 
+    def set_option(self, name, value):
+        """Per-context switch of the native library (sagen_set_option), e.g. 'materialize_mask'."""
+        check(_lib.lib().sagen_set_option(self.handle, name.encode(), int(value)))
+
     def intermediate(self, name):
         l = _lib.lib()
         data, ndim, shape, ps = C.c_void_p(), C.c_int32(), (C.c_int64 * 4)(), C.c_int64()
@@ -254,6 +258,11 @@ class SptAudioGen(object):
 
     def intermediate(self, batch, name):
         return self.context_for(batch).intermediate(name)
+
+    def set_option(self, batch, name, value):
+        """'materialize_mask' = 1: the next forwards keep the mask logits ('separation/deconv1') instead of folding the mask into the
+        last deconvolution's epilogue."""
+        self.context_for(batch).set_option(name, value)
 
     # ---- per-layer launch plan -------------------------------------------------------------------
     def autotune(self, audio, video=None, flow=None):

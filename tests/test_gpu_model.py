@@ -53,9 +53,21 @@ def test_audio_only_intermediates_and_output(T):
         r = r.reshape(g.shape)
         e = rel_rms_err(g, r)
         assert e < 5e-5, (n, e)
+    # the default forward folds sigmoid + track mix into deconv1's epilogue: the logits are not materialised, and asking says so
+    with pytest.raises(Exception, match='materialize_mask'):
+        net.intermediate(B, 'separation/deconv1')
+    check_out(got, ref)
+    # with the logits kept (two kernels): the logits against the oracle, and the same output to rounding
+    net.set_option(B, 'materialize_mask', 1)
+    inp = synth_inputs(B, ['audio'], seed=1234)
+    got2 = net.inference_ops(inp['audio']).cpu().numpy()
     d1 = net.intermediate(B, 'separation/deconv1').cpu().numpy()          # rows 44..66 only
     assert rel_rms_err(d1, orc.ends['separation/deconv1'][:, 44:67]) < 5e-5
-    check_out(got, ref)
+    check_out(got2, ref)
+    assert rel_rms_err(got, got2) < 2e-6, rel_rms_err(got, got2)
+    net.set_option(B, 'materialize_mask', 0)
+    got3 = net.inference_ops(inp['audio']).cpu().numpy()
+    assert np.array_equal(got3, got)
 
 
 def test_audio_video(T):
