@@ -245,8 +245,8 @@ def main_train(args, cfg):
         'metric': 'ambisonic seconds trained/sec (0.1 s windows, 224x448 video; one Adam step per batch)',
         'value': round(value, 2), 'unit': 'ambisonic-s/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (forward / data gradients: products on the bf16 matrix cores as a 3-way operand split, fp32-equivalent; weight '
-                 'gradients: exact fp32 MFMA; fp32 Adam state)',
+        'dtype': 'f32 (forward, data and weight gradients: products on the bf16 matrix cores as a 3-way operand split with fp32 '
+                 'accumulation, fp32-equivalent - tests/test_gpu_backward.py; fp32 Adam state)',
         'data': 'synthetic',
         'config': {'workload': cfg['workload'], 'name': 'train', 'windows_per_gpu_per_step': BATCH,
                    'windows_per_s': round(BATCH * world * steps / elapsed, 1), 'optimizer': 'Adam (lr 1e-4), fused over %d flat buckets' % len(tr.opt.params),

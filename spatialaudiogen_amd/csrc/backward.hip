@@ -2,8 +2,8 @@
 // myutils.py:220-221): ReLU / bias gradients, training-mode batch-norm backward (core.py:6,209-210), max-pool backward
 // (resnet.py:135), fan-in sums of tf.tile / tf.concat (model.py:230-236, 291-297), the BN moving averages (UPDATE_OPS,
 // train.py:147-148) and the filter packs of the data-gradient contractions.  All are 16-byte-per-lane coalesced NHWC streams
-// (channels innermost, C % 4 == 0); per-channel sums are accumulated in registers, reduced through LDS and added to fp64
-// accumulators with one atomic per channel and workgroup (same scheme as the forward BN statistics, igemm_common.h).
+// (channels innermost, C % 4 == 0); per-channel sums are accumulated in registers, reduced through LDS into one row of partials
+// per workgroup, and the rows are added in a fixed order in fp64 by partials_finish_kernel (deterministic; no atomics).
 #include "kernels.h"
 #include <cstdlib>
 #include <algorithm>

@@ -234,13 +234,17 @@ struct WgradDesc {
     int sh = 1, sw = 1, TH = 1, TW = 1, h0 = 0, w0 = 0;
     int tsh = 1, tsw = 1;             // tap strides: tap (th, tw) reads G at (i*sh + th*tsh + h0, j*sw + tw*tsw + w0)
     int splitk = 1;
+    int defer_reduce = 0;             // 1: wgrad_launch leaves the partials in ws; the caller runs wgrad_reduce_launch (timed separately)
     // filled by wgrad_launch
     int P = 0, fold = 1;
     unsigned g_bytes = 0, d_bytes = 0, magic_w = 0, magic_h = 0;
 };
 int wgrad_launch(const WgradDesc& d, hipStream_t s);
 int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats);
-const char* wgrad_kernel_name();      // "wgrad3_kernel" (bf16x3, default) | "wgrad_kernel" (exact fp32 MFMA) | "wgrad_ref_kernel"
+int wgrad_reduce_launch(const WgradDesc& d, hipStream_t s);
+// "wgrad3r_kernel" (bf16x3, one filter row per workgroup: dense 3x3 stride-1) | "wgrad3_kernel" (bf16x3, one tap) |
+// "wgrad_kernel" (exact fp32 MFMA) | "wgrad_ref_kernel"
+const char* wgrad_kernel_name(const WgradDesc& d);
 
 // -----------------------------------------------------------------------------------------
 // backward elementwise / reductions (backward.hip)

@@ -188,7 +188,9 @@ struct Bwd : Fwd {
         d.ws = c->p("t:wgws");
         d.splitk = wgrad_pick_splitk(d, c->cap("t:wgws"));
         const double flops = 2.0 * d.B * d.Hd * d.Wd * d.TH * d.TW * d.Cg * d.Cd;
-        timed(wgrad_kernel_name(), flops, [&] { return wgrad_launch(d, s); });
+        d.defer_reduce = 1;
+        timed(wgrad_kernel_name(d), flops, [&] { return wgrad_launch(d, s); });
+        if (d.splitk > 1) timed("splitk_reduce_kernel", 0.0, [&] { return wgrad_reduce_launch(d, s); });
     }
     void wgrad(const std::string& label, const WgradDesc& d, float* out) {
         if (rc) return;

@@ -694,9 +694,10 @@ static bool wgrad_exact() {
     static const bool exact = getenv("SAGEN_FP32_ONLY") != nullptr || getenv("SAGEN_WGRAD_F32") != nullptr;
     return exact;
 }
-const char* wgrad_kernel_name() {
+static bool wgrad_rowtap(const WgradDesc& d);
+const char* wgrad_kernel_name(const WgradDesc& d) {
     static const bool ref = getenv("SAGEN_WGRAD_REF") != nullptr;
-    return ref ? "wgrad_ref_kernel" : (wgrad_exact() ? "wgrad_kernel" : "wgrad3_kernel");
+    return ref ? "wgrad_ref_kernel" : (wgrad_exact() ? "wgrad_kernel" : (wgrad_rowtap(d) ? "wgrad3r_kernel" : "wgrad3_kernel"));
 }
 
 static unsigned magic_of(int dv) { return dv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1ull); }
@@ -789,9 +790,15 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
         else hipLaunchKernelGGL((wgrad3_kernel<64, 64>), grid, dim3(256), 0, s, d);
     }
     SAGEN_LAUNCH_CHECK();
-    if (d.splitk > 1)
-        return splitk_reduce_launch(d.ws, d.splitk, d.TH * d.TW * d.Cg, d.Cd, nullptr, 0, d.out, d.Cd, 1, nullptr, s);
+    if (d.splitk > 1 && !d.defer_reduce) return wgrad_reduce_launch(d, s);
     return SAGEN_OK;
+}
+
+// the fixed-order sum of the pixel-range partials (wgrad_launch runs it itself unless d.defer_reduce)
+int wgrad_reduce_launch(const WgradDesc& d, hipStream_t s) {
+    static const bool use_ref = getenv("SAGEN_WGRAD_REF") != nullptr;
+    if (d.splitk <= 1 || use_ref) return SAGEN_OK;
+    return splitk_reduce_launch(d.ws, d.splitk, d.TH * d.TW * d.Cg, d.Cd, nullptr, 0, d.out, d.Cd, 1, nullptr, s);
 }
 
 }  // namespace sagen

@@ -9,6 +9,9 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 python $R/bench.py --no-cpu-baseline --config $CFG --steps 2 --warmup 1 --plan-file $O/plan.json > $O/tune.log 2>&1
 BENCH="python $R/bench.py --no-cpu-baseline --config $CFG --plan-file $O/plan.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH --steps 20 --warmup 5 > $O/trace.log 2>&1
+if [ "$CFG" = train ]; then
+  SAGEN_BWD_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- $BENCH --steps 20 --warmup 5 > $O/trace1.log 2>&1
+fi
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $BENCH --steps 2 --warmup 1 > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $BENCH --steps 2 --warmup 1 > $O/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- $BENCH --steps 2 --warmup 1 > $O/sq.log 2>&1

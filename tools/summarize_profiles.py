@@ -22,6 +22,17 @@ with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w') as f:
     for r in rows[:45]:
         w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], '%.1f' % float(r['AverageNs']), r['Percentage'], r['MinNs'], r['MaxNs']])
 
+# 1b. (training) the same trace with the backward on ONE stream: the launch durations bench.py's roofline object is computed from
+#     (with two streams a weight gradient shares the chip with the data-gradient chain and its duration is not its own)
+one = glob.glob(os.path.join(src, 'trace1', '*', '*_kernel_stats.csv'))
+if one:
+    rows1 = [r for r in csv.DictReader(open(one[0])) if not r['Name'].startswith('Cijk_')]
+    with open(os.path.join(dst, tag + '_kernel_stats_one_stream.csv'), 'w') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns'])
+        for r in rows1[:45]:
+            w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], '%.1f' % float(r['AverageNs']), r['Percentage'], r['MinNs'], r['MaxNs']])
+
 # 2. PMC passes: per-kernel mean of each counter
 pmc = collections.defaultdict(dict)
 for sub in ('fetch', 'write', 'sq', 'sq2'):
@@ -63,8 +74,8 @@ for k, v in traffic.items():
         wsum[base][1] += n
 for base, (tot, n) in wsum.items():
     label[base] = round(tot / n)
-# the training step labels all weight-gradient instantiations "wgrad3_kernel" / "wgrad_kernel": launch-weighted mean
-for pfx in ('wgrad3_kernel', 'wgrad_kernel'):
+# the training step labels the weight-gradient instantiations by family ("wgrad3r_kernel" / "wgrad3_kernel" / "wgrad_kernel"): launch-weighted mean
+for pfx in ('wgrad3r_kernel', 'wgrad3_kernel', 'wgrad_kernel'):
     tot = n = 0.0
     for k, v in traffic.items():
         if k.startswith(pfx + '<'):
