@@ -265,6 +265,41 @@ def test_every_variable_gradient_matches_fp64_autograd(T, encoders, B, seed):
                                                                              max(rows, key=lambda t: t[1])[0]))
 
 
+def test_full_size_gradients_are_affine_in_the_target(T):
+    """BASELINE configs[4] at its real size (B = 32, audio+video: the tiles, split-K factors and workgroup counts the bench runs),
+    where fp64 autograd on the CPU would take minutes: a size-independent property instead.  With the inputs and weights fixed the
+    forward is fixed, dL/dpred is affine in the target and every variable's gradient is linear in dL/dpred, so for all 88 variables
+    g(t1 + t2) = g(t1) + g(t2) - g(0).  Any launch-geometry fault of the backward (a tile dropped, a pixel range counted twice,
+    a race between the streams) breaks it; the bar is fp32 rounding of a three-term sum."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    from spatialaudiogen_amd.train import Trainer
+    from spatialaudiogen_amd.weights import init_weights, synth_inputs
+    enc, B = ['audio', 'video'], 32
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(init_weights(net.variable_specs(), seed=4, mode='bench', fc3_std=0.05))
+    inp = synth_inputs(B, enc, seed=77)
+    r = rng(5)
+    t1 = (0.3 * r.normal(size=(B, 4800, 3))).astype(np.float32)
+    t2 = (0.3 * r.normal(size=(B, 4800, 3))).astype(np.float32)
+    tr = Trainer(net, batch=B)
+    a, v = T.as_tensor(inp['audio']).cuda(), T.as_tensor(inp['video']).cuda()
+
+    def grads(t):
+        tr.forward_backward(a, v, None, T.as_tensor(t).cuda(), update_moving=False)
+        return {k: tr.grad(k).double().clone() for k in tr.opt.layout}
+    g0, g1, g2, g12 = grads(np.zeros_like(t1)), grads(t1), grads(t2), grads(t1 + t2)
+    again = grads(t1 + t2)
+    worst = 0.0
+    for k in g0:
+        assert T.equal(again[k], g12[k]), 'the backward is not bit-reproducible for ' + k
+        lhs, rhs = g12[k], g1[k] + g2[k] - g0[k]
+        scale = max(float(lhs.norm()), float(g1[k].norm()), float(g0[k].norm()), 1e-30)
+        err = float((lhs - rhs).norm()) / scale
+        worst = max(worst, err)
+        assert err < 2e-5, (k, err)
+    assert worst > 0.0                                     # (three different launches really were added)
+
+
 def test_weight_gradients_do_not_depend_on_the_mfma_kernel(T):
     """SAGEN_WGRAD_REF=1 routes every weight gradient through the plain one-thread-per-element kernel: same gradients."""
     import os
