@@ -258,6 +258,13 @@ int sagen_train_step(sagen_ctx* ctx, const float* audio, const float* video, con
  * its launch candidates; the plan is stored in the ctx.  The gradients it leaves behind are not meaningful.  Synchronises. */
 int sagen_train_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
                          const float* mask, void* stream);
+/* Data-parallel training (train.py runs one device; here one process per GPU, gradients summed over the ranks): overlap the
+ * exchange with the backward pass.  The caller partitions the trainable variables into n_buckets flat buckets (names[i] belongs to
+ * bucket[i]) and hands in one event per bucket (hipEvent_t, e.g. torch.cuda.Event.cuda_event); every following sagen_train_step
+ * records events[b] as soon as the last kernel writing a gradient of bucket b has been enqueued - behind both of the step's streams -
+ * so a communication stream that waits for events[b] can all-reduce bucket b under the rest of the backward.  Every event is
+ * recorded by every step (buckets that never complete early are recorded at the end).  n = 0 switches it off. */
+int sagen_train_set_grad_events(sagen_ctx* ctx, const char* const* names, const int32_t* bucket, int n, void* const* events, int n_buckets);
 /* named buffer of the train workspace (parity tests): e.g. "t:dcoeffs" [B*3][100], "t:ddmask" [B,31,1024,ntracks] (deconv1 output
  * rows 40..70), "t:dpred", "t:g:feat" (dL/d conv5_2) */
 int sagen_train_get_buffer(const sagen_ctx* ctx, const char* name, const float** data, size_t* n_floats);

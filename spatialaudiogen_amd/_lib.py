@@ -77,6 +77,7 @@ SIGNATURES = {
     'sagen_train_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'sagen_train_autotune': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'sagen_train_get_buffer': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_SZ)]),
+    'sagen_train_set_grad_events': (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _I, C.POINTER(_P), _I]),
     'sagen_wgrad_scratch_bytes': (_SZ, [_I] * 4),
     'sagen_wgrad': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _SZ, _P]),
     'sagen_conv2d_bwd_data_scratch_bytes': (_SZ, [_I] * 6),

@@ -28,6 +28,7 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
 int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
                           const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s);
 int sagen_train_get_buffer_impl(const sagen_ctx* c, const char* name, const float** data, size_t* n);
+int sagen_train_set_grad_events_impl(sagen_ctx* c, const char* const* names, const int32_t* bucket, int n, void* const* events, int n_buckets);
 int sagen_train_autotune_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
                               const float* mask, hipStream_t s);
 
@@ -407,6 +408,11 @@ int sagen_train_autotune(sagen_ctx* ctx, const float* audio, const float* video,
                          const float* mask, void* stream) {
     return guarded([&] { return sagen_train_autotune_impl(ctx, audio, video, flow, target_yzx, mask, (hipStream_t)stream); });
 }
+int sagen_train_set_grad_events(sagen_ctx* ctx, const char* const* names, const int32_t* bucket, int n, void* const* events, int n_buckets) {
+    if (!ctx) return fail(SAGEN_ERR_NULL, "sagen_train_set_grad_events: null ctx");
+    return guarded([&] { return sagen_train_set_grad_events_impl(ctx, names, bucket, n, events, n_buckets); });
+}
+
 int sagen_train_get_buffer(const sagen_ctx* ctx, const char* name, const float** data, size_t* n_floats) {
     if (!ctx || !name || !data || !n_floats) return fail(SAGEN_ERR_NULL, "sagen_train_get_buffer: null argument");
     return guarded([&] { return sagen_train_get_buffer_impl(ctx, name, data, n_floats); });

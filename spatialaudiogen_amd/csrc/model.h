@@ -103,6 +103,14 @@ struct sagen_ctx {
     float* tws = nullptr;
     std::map<std::string, Buf> tbufs;
     std::vector<float*> grad_ptr;          // per variable: where its gradient is written (caller's gradient buckets)
+    // gradient-bucket milestones (sagen_train_set_grad_events): event b is recorded as soon as the last kernel writing into bucket b
+    // has been enqueued (after both streams) - the host starts that bucket's all-reduce under the rest of the backward pass
+    std::vector<int> ms_bucket;            // per variable: its bucket, -1 = none
+    std::vector<int> ms_count, ms_left;    // per bucket: variables in it / not yet written in this step
+    std::vector<hipEvent_t> ms_event;
+    std::vector<char> ms_done;             // per variable, this step
+    std::vector<int> ms_touched;           // variables whose producer was enqueued since the last flush
+    hipEvent_t ms_tmp = nullptr;
     std::vector<float*> mov_ptr;           // per variable: writable pointer of a BN moving average (or null)
     Buf talloc(const std::string& name, size_t n) {
         Buf b;

@@ -151,7 +151,32 @@ struct Bwd : Fwd {
     bool split_ok = getenv("SAGEN_BWD_NOSPLIT") == nullptr;      // debugging: no split-K in the data-gradient contractions
     Bwd(sagen_ctx* ctx, hipStream_t st) { c = ctx; s = st; }
 
-    float* grad(const std::string& v) { return c->grad_ptr[c->var_index.at(v)]; }
+    // where variable v's gradient goes; the caller is about to enqueue the kernel that writes it (bucket milestones: ms_flush)
+    float* grad(const std::string& v) {
+        const int i = c->var_index.at(v);
+        if (!c->ms_bucket.empty() && c->ms_bucket[i] >= 0 && !c->ms_done[i]) { c->ms_done[i] = 1; c->ms_touched.push_back(i); }
+        return c->grad_ptr[i];
+    }
+    // every gradient requested so far has its producer enqueued (on this stream or on the second one): buckets that are now complete
+    // get their event - on the second stream, behind everything the main stream has enqueued (one more wait for a stream that runs
+    // behind the main one anyway)
+    void ms_flush() {
+        if (rc || c->ms_touched.empty()) return;
+        for (int i : c->ms_touched) {
+            const int b = c->ms_bucket[i];
+            if (--c->ms_left[b] != 0) continue;
+            hipError_t e = hipSuccess;
+            if (wg) {
+                e = hipEventRecord(c->ms_tmp, s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(wg->s, c->ms_tmp, 0);
+                if (e == hipSuccess) e = hipEventRecord(c->ms_event[b], wg->s);
+            } else {
+                e = hipEventRecord(c->ms_event[b], s);
+            }
+            if (e != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "bucket milestone: %s", hipGetErrorString(e)); break; }
+        }
+        c->ms_touched.clear();
+    }
     double* cacc_next() {
         if (cslot >= CACC_SLOTS) { if (!rc) rc = fail(SAGEN_ERR_WORKSPACE, "bias accumulator slots exhausted"); return nullptr; }
         return reinterpret_cast<double*>(c->p("t:cacc")) + (size_t)(cslot++) * CACC_SLOT;
@@ -315,6 +340,7 @@ struct Bwd : Fwd {
             }
             done[k] = aux_mark();
             ga = A;
+            ms_flush();
         }
         if (rc) return;
         // pool + stem: x0 = maxpool(relu(bn0(y0)))  (resnet.py:133-135)
@@ -338,6 +364,7 @@ struct Bwd : Fwd {
         u.layer = "wgrad:" + name;
         u.timed("stem_wgrad_unpack_kernel", 0.0, [&] { return stem_wgrad_unpack_launch(c->p("t:stemtmp" + sfx), grad(name + "/weights"), u.s); });
         if (u.rc) rc = u.rc;
+        ms_flush();
     }
 
     // ---- everything after the loss ----
@@ -459,6 +486,7 @@ struct Bwd : Fwd {
             }
             if (a.rc) rc = a.rc;
         }
+        ms_flush();               // (localisation, mask decoder, audio bottleneck and encoder: everything but the visual branches)
         // visual encoders: bottleneck FCs (video-fc tiled over the 3 steps), then the trunk
         int choff = 1024;
         for (int e = 0; e < 2 && !rc; ++e) {
@@ -477,6 +505,7 @@ struct Bwd : Fwd {
             relu_bwd("relu:bottleneck/" + enc + "-fc-red", c->p("t:g:fcred" + sfx), 128, nullptr, 0, c->p("fcred" + sfx), 128, dyr, 128,
                      (long)B * 98, 128, "bottleneck/" + enc + "-fc-red/biases");
             fc_bwd("bottleneck/" + enc + "-fc-red", c->p("t:out:7" + sfx), 512, B * 98, 512, dyr, 128, 128, c->p("t:g:feat" + sfx), 512);
+            ms_flush();
             resnet_bwd(enc + "_encoder", c->p("t:g:feat" + sfx));
             choff += 512;
         }
@@ -568,9 +597,18 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     w.redws = "t:redws2"; w.cslot = CACC_SLOTS / 2; w.wsname = "splitk_aux";      // its own scratch: it runs concurrently with `b`
     // (with the per-launch profiler on, everything stays on one stream: the events then time unoverlapped launches)
     if (c->aux && !one_stream && !c->tuning && !c->profiling) b.wg = &w;
+    if (!c->ms_bucket.empty()) {
+        c->ms_left = c->ms_count;
+        std::fill(c->ms_done.begin(), c->ms_done.end(), 0);
+        c->ms_touched.clear();
+    }
     b.run();
+    b.ms_flush();
     if (b.wg) b.aux_wait(b.aux_mark());          // join: the gradients are complete when the caller's stream gets here
     if (b.rc) return b.rc;
+    // (a bucket none of whose milestones fired - a variable this build's backward never asked for - completes here, never early)
+    for (size_t k = 0; k < c->ms_event.size(); ++k)
+        if (c->ms_left[k] > 0) SAGEN_HIP_CHECK(hipEventRecord(c->ms_event[k], s));
     if (update_moving) {
         // contrib batch_norm update ops (core.py:210, decay 0.99; run with the train op through UPDATE_OPS, train.py:147-148)
         for (int e = 0; e < 2; ++e) {
@@ -595,6 +633,29 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
             }
         }
     }
+    return SAGEN_OK;
+}
+
+int sagen_train_set_grad_events_impl(sagen_ctx* c, const char* const* names, const int32_t* bucket, int n, void* const* events, int n_buckets) {
+    if (!c->train_ready) return fail(SAGEN_ERR_WORKSPACE, "sagen_train_set_grad_events: call sagen_train_bind first");
+    c->ms_bucket.clear(); c->ms_count.clear(); c->ms_left.clear(); c->ms_event.clear(); c->ms_done.clear(); c->ms_touched.clear();
+    if (n == 0 || n_buckets == 0) return SAGEN_OK;             // (off)
+    if (!names || !bucket || !events) return fail(SAGEN_ERR_NULL, "sagen_train_set_grad_events: null argument");
+    std::vector<int> vb(c->vars.size(), -1), cnt(n_buckets, 0);
+    for (int i = 0; i < n; ++i) {
+        auto it = c->var_index.find(names[i]);
+        if (it == c->var_index.end()) return fail(SAGEN_ERR_WEIGHTS, "sagen_train_set_grad_events: unknown variable %s", names[i]);
+        if (bucket[i] < 0 || bucket[i] >= n_buckets) return fail(SAGEN_ERR_SHAPE, "sagen_train_set_grad_events: bucket %d of %s out of range", bucket[i], names[i]);
+        if (!c->grad_ptr[it->second]) return fail(SAGEN_ERR_WEIGHTS, "sagen_train_set_grad_events: %s has no gradient bound", names[i]);
+        if (vb[it->second] < 0) ++cnt[bucket[i]];
+        vb[it->second] = bucket[i];
+    }
+    for (int k = 0; k < n_buckets; ++k)
+        if (!events[k]) return fail(SAGEN_ERR_NULL, "sagen_train_set_grad_events: event %d is null", k);
+    if (!c->ms_tmp) SAGEN_HIP_CHECK(hipEventCreateWithFlags(&c->ms_tmp, hipEventDisableTiming));
+    c->ms_bucket = vb; c->ms_count = cnt; c->ms_left = cnt;
+    c->ms_done.assign(c->vars.size(), 0);
+    for (int k = 0; k < n_buckets; ++k) c->ms_event.push_back((hipEvent_t)events[k]);
     return SAGEN_OK;
 }
 

@@ -74,6 +74,39 @@ def test_training_converges_on_the_synthetic_task(T):
     assert np.mean(losses[-10:]) < 1e-2 * np.mean(losses[:10]), (losses[:10], losses[-10:])
 
 
+def test_gradient_bucket_events_fire_under_the_backward(T):
+    """sagen_train_set_grad_events: with the 123 MB of gradients in 16 MiB buckets (declaration order = forward order) the native
+    step records a bucket's event as soon as its last gradient has been enqueued.  The last bucket (mask decoder, localisation,
+    bottleneck) must complete well before the first (audio encoder + the stem and stage 2 of the trunk): that distance is what an
+    all-reduce on another stream overlaps with.  The gradients themselves do not change."""
+    enc, B = ['audio', 'video'], 8
+    from spatialaudiogen_amd.train import synthetic_batches
+    a, v, f, t, m = next(synthetic_batches(enc, B, seed=3, pool=1))
+    tr0, _ = _trainer(T, enc, B, bucket_bytes=16 << 20, overlap=False)
+    tr0.forward_backward(a, v, f, t, m)
+    ref = [g.clone() for g in tr0.opt.grads]
+    tr, _ = _trainer(T, enc, B, bucket_bytes=16 << 20, overlap=False)
+    tr._enable_overlap(timing=True)
+    nb = len(tr.bucket_events)
+    assert nb >= 6
+    for _ in range(2):                                   # (every step records every event again)
+        start = T.cuda.Event(enable_timing=True)
+        start.record()
+        tr.forward_backward(a, v, f, t, m)
+        end = T.cuda.Event(enable_timing=True)
+        end.record()
+        T.cuda.synchronize()
+        assert all(e.query() for e in tr.bucket_events)
+        at = [start.elapsed_time(e) for e in tr.bucket_events]
+        total = start.elapsed_time(end)
+        assert all(0.0 < x <= total + 1e-3 for x in at), (at, total)
+        assert at[nb - 1] < at[0] - 0.3, (at, total)     # ms: the trunk's backward lies between them
+        assert at[0] > 0.8 * total, (at, total)          # bucket 0 holds the stem: complete only at the end
+        assert min(at) < 0.75 * total, (at, total)
+    for g, r in zip(tr.opt.grads, ref):
+        assert T.equal(g, r)
+
+
 def test_nan_guard_stops_the_loop_and_still_saves(T, tmp_path):
     from spatialaudiogen_amd.train import synthetic_batches, train_loop
 
