@@ -322,6 +322,7 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {256, 64, 16, "igemm3s2_kernel<256,64,64,64>", true, false, true},  {128, 64, 16, "igemm3s2_kernel<128,64,64,32>", true, false, true},
     {128, 64, 16, "conv3p_kernel<128,64,64,32>", true, true, false, true},   {128, 128, 16, "conv3p_kernel<128,128,64,64>", true, true, false, true},
     {64, 64, 16, "conv3p_kernel<64,64,32,32>", true, true, false, true},
+    {128, 64, 16, "conv3pp_kernel<0>", true, true, false, true},          {128, 64, 16, "conv3pp_kernel<1>", true, true, false, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {

@@ -96,6 +96,8 @@ enum IgemmTile {
     TILE_B3S2_256x64, TILE_B3S2_128x64,
     // bf16x3 for dense 3x3 stride-1 SAME convs over pre-split activation planes (conv3p_kernel; needs IgemmDesc::xp3)
     TILE_P3_128x64, TILE_P3_128x128, TILE_P3_64x64,
+    // ... two phase-locked 4-wave teams per workgroup (conv3pp_kernel): two 128x64 tiles / the two K halves of one
+    TILE_P3PP_PAIR, TILE_P3PP_SPLITK,
     TILE_AUTO
 };
 

@@ -298,6 +298,11 @@ struct Fwd {
             const IgemmTile tile = (IgemmTile)t;
             const int bm = igemm_tile_bm(tile), bn = igemm_tile_bn(tile);
             if (!igemm_tile_ok(d, tile)) continue;
+            // conv3pp_kernel (two phase-locked teams per workgroup): faster than conv3p_kernel on its own (stage 5: 87 vs 93 us,
+            // stage 4: 80 vs 83) but its 121 KiB of LDS make it the only workgroup of a CU, and with a second batch in flight the
+            // forward gets slower (1 560 vs 1 610-1 637 ambisonic-s/s) - not a candidate unless asked for (SAGEN_P3PP=1)
+            static const bool p3pp = getenv("SAGEN_P3PP") != nullptr;
+            if (!p3pp && (tile == TILE_P3PP_PAIR || tile == TILE_P3PP_SPLITK)) continue;
             const int nk = d.Kpad / igemm_tile_bk(tile);
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;

@@ -16,6 +16,12 @@ for _ in range(3): net.inference_ops(a, v, f)
 if os.environ.get('TUNE', '1') == '1':
     plan = net.autotune(a, v, f)
     for row in plan: print('plan %-44s %-30s sk=%-3d %8.1f us' % row)
+# FORCE="<tile id>:<layer substring>[,...]": pin matching layers to a tile after tuning (A/B of kernel variants inside the forward)
+for item in filter(None, os.environ.get('FORCE', '').split(',')):
+    tid_, sub = item.split(':')
+    for name in variable_specs(enc):
+        if name.endswith('/weights') and sub in name:
+            net.plan_set(B, name[:-len('/weights')], int(tid_), 1)
 net.profile_enable(B, True)
 acc = None
 N = 5

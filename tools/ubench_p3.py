@@ -44,7 +44,7 @@ if not os.path.exists(out):
 lib = C.CDLL(out)
 from spatialaudiogen_amd.model import SptAudioGen
 tile = SptAudioGen.tile_names().index(tile_name)
-bm = int(tile_name.split('<')[1].split(',')[0])
+bm = 128 if tile_name.startswith('conv3pp') else int(tile_name.split('<')[1].split(',')[0])
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 for (B, H, W, Cin, N) in shapes:
     x = torch.randn(B, H, W, Cin, device='cuda')
@@ -80,6 +80,12 @@ for (B, H, W, Cin, N) in shapes:
         t = trc.cpu().numpy().reshape(nblk, 16).astype(np.int64)
         ok = t[:, 6] > 0
         t = t[ok]
+        if tile_name.startswith('conv3pp'):
+            g = np.maximum(t[:, 4], 1)[:, None]
+            ph = np.median(t[:, 8:15] / g, 0)
+            print('   workgroups %d, %d groups per team; life %d ticks; per group (median s_memtime ticks of team 0 / wave 0): tap-0 reads %d | wait partner %d | '
+                  'tap0 %d tap1 %d tap2 %d | DMA landed %d | end barrier %d  = %d per group' % ((len(t), np.median(t[:, 4]), np.median(t[:, 6] - t[:, 0])) + tuple(ph) + (ph.sum(),)))
+            continue
         print('   workgroups %d: tiles/WG min %d median %d max %d; per WG (median ticks): entry->first issue %d | K loops %d | epilogues %d | life %d; per tile: K %d, epilogue %d'
               % (len(t), t[:, 4].min(), np.median(t[:, 4]), t[:, 4].max(), np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2]), np.median(t[:, 3]),
                  np.median(t[:, 6] - t[:, 0]), np.median(t[:, 2] / np.maximum(t[:, 4], 1)), np.median(t[:, 3] / np.maximum(t[:, 4], 1))))
