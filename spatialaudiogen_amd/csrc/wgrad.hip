@@ -716,9 +716,10 @@ static WgradShape wgrad_shape(const WgradDesc& d) {
     w.bm = d.Cg > 64 ? 128 : 64;
     w.bn = (d.Cd > 64 && !w.row) ? 128 : 64;                      // (three accumulator sets: the row kernel keeps BN = 64)
     const long P = w.row ? (long)d.B * d.Hd * (d.Wd + 1) : (long)d.B * d.Hd * d.Wd;
-    // 32 gathered channels, a column of filter rows (the stem after its horizontal taps were folded into the channels): four rows per tile
+    // 32 / 16 gathered channels, a column of filter rows (the stem / the audio conv1 after their horizontal taps were folded into the
+    // channels): four / eight rows per tile
     static const bool nofold = getenv("SAGEN_WGRAD_NOFOLD") != nullptr;
-    w.fold = (!nofold && !wgrad_exact() && !w.row && d.TW == 1 && d.TH >= 2 && d.Cg == 32) ? 4 : 1;
+    w.fold = (!nofold && !wgrad_exact() && !w.row && d.TW == 1 && d.TH >= 2 && (d.Cg == 32 || d.Cg == 16)) ? 128 / d.Cg : 1;
     if (w.fold > 1) w.bm = 128;
     w.ntile = w.fold > 1 ? (long)cdiv(d.TH, w.fold) * cdiv(d.Cd, w.bn)
                          : (long)d.TH * (w.row ? 1 : d.TW) * cdiv(d.Cg, w.bm) * cdiv(d.Cd, w.bn);

@@ -48,6 +48,7 @@ CONV_CASES = [
     (2, 16, 16, 16, 32, 5, 3, 3, 2, 'VALID'),       # ragged: rows / columns the strided conv never reads
     (2, 21, 9, 32, 64, 7, 1, 2, 1, 'VALID'),        # 32 gathered channels, a column of 7 filter rows: four rows folded into one tile (the stem's form)
     (3, 12, 10, 32, 96, 5, 1, 1, 1, 'SAME'),        # the same with padding rows and a second, partly empty row group
+    (2, 23, 9, 16, 64, 7, 1, 4, 1, 'VALID'),        # 16 gathered channels, 7 filter rows in one tile (the audio conv1's form)
 ]
 
 
