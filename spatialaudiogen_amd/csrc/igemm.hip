@@ -527,6 +527,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The same for FEW outputs and MANY partials (weight gradients of small layers: 28 KB of gradient from 256 pixel ranges took 27 us
+// with one thread walking all 256 partials of its four columns): eight threads per column group, each summing every eighth partial
+// (four loads in flight), combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void splitk_reduce_sliced_kernel(const float* __restrict__ ws, int splitk, int M, int N,
+                                                                   const float* __restrict__ bias, int relu,
+                                                                   float* __restrict__ y, int ldy, int rep) {
+    __shared__ float4 red[8][32];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int NV = N / 4;
+    const long idx = (long)blockIdx.x * 32 + c;
+    const bool ok = idx < (long)M * NV;
+    const int m = ok ? (int)(idx / NV) : 0, n = ok ? (int)(idx - (long)m * NV) * 4 : 0;
+    const long MN = (long)M * N;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        const float* p = ws + (long)m * N + n + (long)sl * MN;
+        int z = sl;
+        for (; z + 24 < splitk; z += 32, p += 32 * MN) {
+            const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + 8 * MN);
+            const float4 t2 = *reinterpret_cast<const float4*>(p + 16 * MN), t3 = *reinterpret_cast<const float4*>(p + 24 * MN);
+            v.x += (t0.x + t1.x) + (t2.x + t3.x); v.y += (t0.y + t1.y) + (t2.y + t3.y);
+            v.z += (t0.z + t1.z) + (t2.z + t3.z); v.w += (t0.w + t1.w) + (t2.w + t3.w);
+        }
+        for (; z < splitk; z += 8, p += 8 * MN) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+    }
+    red[sl][c] = v;
+    __syncthreads();
+    if (sl == 0 && ok) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const float4 t = red[k][c]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (bias) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        for (int r = 0; r < rep; ++r) *reinterpret_cast<float4*>(y + ((long)m * rep + r) * ldy + n) = v;
+    }
+}
+
 // Same sum, plus the per-channel (sum, sumsq) of the raw sums over each block of SPLITK_RB rows
 // (training-mode batch-norm statistics of a split-K conv).  Thread t owns 4 columns n = 4*(t % CN4) and rows
 // (t / CN4) + i*(256 / CN4) of its row block; grid (row blocks, column blocks of 4*CN4).
@@ -590,6 +629,10 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
         while (RB < 128 && (long)cdiv(M, 2 * RB) * ncb >= 512) RB *= 2;
         dim3 grid(cdiv(M, RB), ncb);
         hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, s, ws, splitk, M, N, y, ldy, stats, CN4, RB);
+    } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && splitk >= 16 &&
+               (long)M * (N / 4) <= 65536) {
+        hipLaunchKernelGGL(splitk_reduce_sliced_kernel, dim3(cdiv((long)M * (N / 4), 32)), dim3(256), 0, s, ws, splitk, M, N, bias,
+                           relu, y, ldy, rep);
     } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0)) {
         hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, s, ws, splitk, M, N, bias,
                            relu, y, ldy, rep);
