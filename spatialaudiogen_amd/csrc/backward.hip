@@ -480,6 +480,37 @@ __global__ __launch_bounds__(256) void bn_moving_update_kernel(const BnRef bn, f
     mv[c] = decay * mv[c] + (1.f - decay) * (float)unbiased;
 }
 
+// every batch-norm layer of a step in ONE launch (34 launches of a few hundred threads were ~90 us of launch latency at the end of
+// the step): the job table travels as a kernel argument
+struct BnMovingJobs { BnMovingJob j[BN_MOVING_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void bn_moving_update_multi_kernel(const BnMovingJobs jobs, float decay) {
+    const BnMovingJob& j = jobs.j[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= j.C) return;
+    const double mean = j.acc[c] * j.inv_count;
+    double var = j.acc[j.C + c] * j.inv_count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double n = 1.0 / j.inv_count;
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    j.mm[c] = decay * j.mm[c] + (1.f - decay) * (float)mean;
+    j.mv[c] = decay * j.mv[c] + (1.f - decay) * (float)unbiased;
+}
+
+int bn_moving_update_multi_launch(const BnMovingJob* jobs, int n, float decay, hipStream_t s) {
+    if (n <= 0) return SAGEN_OK;
+    if (!jobs || n > BN_MOVING_MAX_JOBS) return fail(SAGEN_ERR_SHAPE, "bn_moving_update_multi: %d jobs (max %d)", n, BN_MOVING_MAX_JOBS);
+    BnMovingJobs t;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!jobs[i].acc || !jobs[i].mm || !jobs[i].mv) return fail(SAGEN_ERR_NULL, "bn_moving_update_multi: null argument");
+        t.j[i] = jobs[i];
+        cmax = std::max(cmax, jobs[i].C);
+    }
+    hipLaunchKernelGGL(bn_moving_update_multi_kernel, dim3(cdiv(cmax, 256), n), dim3(256), 0, s, t, decay);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 int bn_moving_update_launch(const BnRef& bn, float* moving_mean, float* moving_var, int C, float decay, hipStream_t s) {
     if (!bn.acc || !moving_mean || !moving_var) return fail(SAGEN_ERR_NULL, "bn_moving_update: null argument");
     hipLaunchKernelGGL(bn_moving_update_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, bn, moving_mean, moving_var, C, decay);

@@ -281,6 +281,9 @@ int sum_rows_launch(const float* ina, int lda, const float* inb, int ldb, int re
 int acc_to_f32_launch(const double* acc, float* dst, int n, hipStream_t s);
 // contrib batch_norm moving averages (UPDATE_OPS, train.py:147-148): m <- decay*m + (1-decay)*batch stat
 int bn_moving_update_launch(const BnRef& bn, float* moving_mean, float* moving_var, int C, float decay, hipStream_t s);
+constexpr int BN_MOVING_MAX_JOBS = 40;
+struct BnMovingJob { const double* acc = nullptr; double inv_count = 0.0; float* mm = nullptr; float* mv = nullptr; int C = 0; };
+int bn_moving_update_multi_launch(const BnMovingJob* jobs, int n, float decay, hipStream_t s);
 // filter packs for the data-gradient contractions
 // 3x3 (any kh x kw) stride-1 conv: Wp[n = ci][(tap', co)] = W_hwio[ntaps-1-tap'][ci][co]
 int pack_conv_flipT_launch(const float* w_hwio, int ntaps, int cin, int cout, float* wp, int Kpad, hipStream_t s);

@@ -611,6 +611,7 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
         if (c->ms_left[k] > 0) SAGEN_HIP_CHECK(hipEventRecord(c->ms_event[k], s));
     if (update_moving) {
         // contrib batch_norm update ops (core.py:210, decay 0.99; run with the train op through UPDATE_OPS, train.py:147-148)
+        std::vector<BnMovingJob> jobs;
         for (int e = 0; e < 2; ++e) {
             if (!(e == 0 ? c->has_video : c->has_flow)) continue;
             const std::string scope = e == 0 ? "video_encoder" : "flow_encoder";
@@ -628,10 +629,14 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
                 float* mm = c->mov_ptr[c->var_index.at(name + "/bn/moving_mean")];
                 float* mv = c->mov_ptr[c->var_index.at(name + "/bn/moving_variance")];
                 if (!mm || !mv) continue;
-                rc = bn_moving_update_launch(b.bn_ref(li, name, count), mm, mv, C, 0.99f, s);
-                if (rc) return rc;
+                const BnRef r = b.bn_ref(li, name, count);
+                BnMovingJob j;
+                j.acc = r.acc; j.inv_count = r.inv_count; j.mm = mm; j.mv = mv; j.C = C;
+                jobs.push_back(j);
             }
         }
+        rc = bn_moving_update_multi_launch(jobs.data(), (int)jobs.size(), 0.99f, s);
+        if (rc) return rc;
     }
     return SAGEN_OK;
 }

@@ -100,9 +100,9 @@ def test_gradient_bucket_events_fire_under_the_backward(T):
         at = [start.elapsed_time(e) for e in tr.bucket_events]
         total = start.elapsed_time(end)
         assert all(0.0 < x <= total + 1e-3 for x in at), (at, total)
-        assert at[nb - 1] < at[0] - 0.3, (at, total)     # ms: the trunk's backward lies between them
-        assert at[0] > 0.8 * total, (at, total)          # bucket 0 holds the stem: complete only at the end
-        assert min(at) < 0.75 * total, (at, total)
+        assert at[nb - 1] < at[0] - 0.2, (at, total)     # ms: the trunk's backward lies between them
+        assert at[0] > 0.6 * total, (at, total)          # bucket 0 holds the stem: complete only at the end
+        assert min(at) < 0.9 * total, (at, total)        # (B = 8: the forward is most of the step; 0.53 of it at B = 32)
     for g, r in zip(tr.opt.grads, ref):
         assert T.equal(g, r)
 
