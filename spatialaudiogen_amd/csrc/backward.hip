@@ -114,6 +114,41 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
     }
 }
 
+// The same for SMALL tensors (the FC layers: 96 x 512) in one launch: 32 column groups x 8 row slices per workgroup, every column's
+// sum finished inside the workgroup in a fixed order (the two-launch form above spends 12 + 5 us on a few KB).
+__global__ __launch_bounds__(256) void relu_bwd_small_kernel(const float* __restrict__ ga, int lda, const float* __restrict__ gb, int ldb,
+                                                             const float* __restrict__ act, int ldact, float* __restrict__ dy, int lddy,
+                                                             int R, int C4, double* __restrict__ colsum, float* __restrict__ colsum_f32, int C) {
+    __shared__ float4 red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c4 = blockIdx.x * 32 + cl;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4) {
+        for (int row = sl; row < R; row += 8) {
+            float4 v = *reinterpret_cast<const float4*>(ga + (long)row * lda + 4 * c4);
+            if (gb) v = add4(v, *reinterpret_cast<const float4*>(gb + (long)row * ldb + 4 * c4));
+            if (act) {
+                const float4 a = *reinterpret_cast<const float4*>(act + (long)row * ldact + 4 * c4);
+                v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+            }
+            if (dy) *reinterpret_cast<float4*>(dy + (long)row * lddy + 4 * c4) = v;
+            sum = add4(sum, v);
+        }
+    }
+    red[sl][cl] = sum;
+    __syncthreads();
+    if (sl == 0 && c4 < C4 && colsum) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float4 r = red[k][cl]; t[0] += r.x; t[1] += r.y; t[2] += r.z; t[3] += r.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            colsum[4 * c4 + k] = t[k];
+            if (colsum_f32 && 4 * c4 + k < C) colsum_f32[4 * c4 + k] = (float)t[k];
+        }
+    }
+}
+
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
                     int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32) {
     if (!ga || (!dy && !colsum)) return fail(SAGEN_ERR_NULL, "relu_bwd: null argument");
@@ -123,6 +158,13 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
     if (((uintptr_t)ga | (uintptr_t)gb | (uintptr_t)act | (uintptr_t)dy) % 16) return fail(SAGEN_ERR_UNSUPPORTED, "relu_bwd: operands must be 16-byte aligned");
     const int C4 = Cp / 4;
     const long n4 = R * C4;
+    static const bool no_small = getenv("SAGEN_RELU_BWD_TWO_LAUNCHES") != nullptr;
+    if (colsum && !no_small && n4 <= 32768 && R <= (1 << 20)) {
+        hipLaunchKernelGGL(relu_bwd_small_kernel, dim3(cdiv(C4, 32)), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, (int)R, C4, colsum,
+                           colsum_f32, C);
+        SAGEN_LAUNCH_CHECK();
+        return SAGEN_OK;
+    }
     const bool fast = colsum && scratch && 256 % C4 == 0;
     if (colsum && !fast) SAGEN_HIP_CHECK(hipMemsetAsync(colsum, 0, (size_t)Cp * sizeof(double), s));
     const int grid = colsum ? reduce_grid(n4, C4) : aligned_grid(n4, C4);
