@@ -733,6 +733,15 @@ __device__ __forceinline__ float pack_source(const PackJob& j, int n, int k) {
             const int pp = ry + sh * dp, q = rx + sw * dq;
             return (pp < kh && q < kw) ? w[(((long)pp * kw + q) * cout + o) * cin + c] : 0.f;
         }
+        case PACK_DECONV_PHASE: {  // n = o, k = (dp, dq, c) over the taps of phase (ry, rx) only: W[ry + 2*dp][rx + 2*dq][o][c]
+            const int kh = j.p[0], kw = j.p[1], cout = j.p[2], cin = j.p[3], ry = j.p[4], rx = j.p[5], ntw = j.p[6];
+            const int nth = (kh - ry + 1) / 2;
+            if (n >= cout || k >= nth * ntw * cin) return 0.f;
+            const int tap = k / cin, c = k - tap * cin;
+            const int dp = tap / ntw, dq = tap - dp * ntw;
+            const int pp = ry + 2 * dp, q = rx + 2 * dq;
+            return (pp < kh && q < kw) ? w[(((long)pp * kw + q) * cout + n) * cin + c] : 0.f;
+        }
         case PACK_FLIPT: {         // Wp[n = ci][(tap', co)] = W_hwio[ntaps-1-tap'][ci][co]
             const int ntaps = j.p[0], cin = j.p[1], cout = j.p[2];
             if (n >= cin || k >= ntaps * cout) return 0.f;

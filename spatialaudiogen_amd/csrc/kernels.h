@@ -132,12 +132,13 @@ int pack_split_launch(float* wp, int N, int Kpad, hipStream_t s);
 inline size_t packed_split_floats(size_t n_fp32) { return n_fp32 + (3 * n_fp32 + 1) / 2; }
 // ALL filter packs of a context in one launch (bind; once per training step): one job per variable, fp32 pack + its bf16x3 planes
 // written by the same thread (no read-back of the packed filter).  The single-variable launchers above / below stay for the op level.
-enum PackKind { PACK_CONV = 0, PACK_DECONV, PACK_FLIPT, PACK_ROWS };
+enum PackKind { PACK_CONV = 0, PACK_DECONV, PACK_FLIPT, PACK_ROWS, PACK_DECONV_PHASE };
 struct PackJob {
     const float* src = nullptr;      // the variable (TF layout)
     float* dst = nullptr;            // fp32 [N][Kpad], followed by the planes [Kpad/16][3][N][16] bf16
     int kind = 0, N = 0, Kpad = 0;
     // conv: ntaps, cin_src, cin_pad, cout, tw_src, tw_pad | deconv: kh, kw, cout, cin, sh, sw, ntw | flipT: ntaps, cin, cout | rows: rows, cols
+    // deconv phase (stride 2, ONE output phase (ry, rx), only its non-zero taps): kh, kw, cout, cin, ry, rx, ntw of the phase
     int p[7] = {0, 0, 0, 0, 0, 0, 0};
     int first_block = 0;             // of this job inside the launch (1024 elements per block)
 };

@@ -52,6 +52,28 @@ static PkdSpec pkd_spec(const VarSpec& vs) {
     return p;
 }
 
+// The stride-2 convs of the ResNet trunk (3x3 conv_1 and 1x1 shortcut of the first block of a stage; no padding before): their
+// input gradient in the depth-to-space form is a 2x2-tap contraction for each of the 4 output phases, but phase (ry, rx) only has
+// the taps with ry + 2 dp < kh, rx + 2 dq < kw - 9 of the 16 (tap, phase) blocks of a 3x3, 1 of the 4 of a 1x1.  One contraction
+// per phase over its own taps, writing every second pixel of every second row (SAGEN_DGRAD_UNPHASED=1: the single padded form).
+// Measured at batch 32 (tools/train_profile.py): the 1x1 shortcuts 31 / 36 / 41 -> 15 / 15 / 19 us; the 3x3 of stage 3 97 -> 90 us, but
+// those of stages 4 and 5 88 -> 98 and 92 -> 137 us: four contractions of 196 tiles each, no split-K into a strided output - so the
+// 3x3 goes phase-wise only where a phase still fills the chip (>= 512 tiles of 64 x 64).
+static bool dgrad_phased(int batch, const std::string& n, const PkdSpec& p) {
+    static const bool off = getenv("SAGEN_DGRAD_UNPHASED") != nullptr;
+    if (off || p.kind != PKD_STRIDED || p.sh != 2 || p.sw != 2 || n.rfind("audio_encoder/", 0) == 0 || p.kh != p.kw) return false;
+    if (p.kh == 1) return true;
+    if (p.kh != 3) return false;
+    const size_t at = n.find("_encoder/conv");
+    if (at == std::string::npos) return false;
+    const int st = n[at + 13] - '2';                              // "convS_1": stage index S - 2
+    if (st < 1 || st > 3) return false;
+    const long tiles = (long)cdiv(batch * RS_H[st] * RS_W[st], 64) * cdiv(p.a, 64);
+    static const long need = getenv("SAGEN_DGRAD_PHASE_TILES") ? atol(getenv("SAGEN_DGRAD_PHASE_TILES")) : 512;      // (tests: 0 = always)
+    return tiles >= need;
+}
+static int phase_taps(int k, int r) { return (k - r + 1) / 2; }      // taps dp >= 0 with r + 2 dp < k
+
 static bool is_weights(const std::string& n) { return n.size() >= 8 && n.compare(n.size() - 8, 8, "/weights") == 0; }
 
 static void train_carve(sagen_ctx* c) {
@@ -98,7 +120,10 @@ static void train_carve(sagen_ctx* c) {
         }
         // gradient activations of the trunk.  The weight gradients run on the context's second stream, so what they read (dy of conv_2 /
         // conv_1, dz of the merge) is double-buffered over the block parity: block k may overwrite only what block k+2 left behind
-        for (const char* nm : {"t:A0", "t:A1", "t:Z0", "t:Z1", "t:S", "t:DYc0", "t:DYc1", "t:DYd0", "t:DYd1", "t:DA"}) c->talloc(nm + x, stage);
+        for (const char* nm : {"t:A0", "t:A1", "t:Z0", "t:Z1", "t:DYc0", "t:DYc1", "t:DYd0", "t:DYd1", "t:DA"}) c->talloc(nm + x, stage);
+        // d(block input) through the 1x1 stride-2 shortcut: one buffer per stage, because the phase-wise data gradient only ever writes
+        // phase (0, 0) and relies on the other three being zero since bind (a shared buffer would keep another stage's values there)
+        for (int st = 1; st <= 3; ++st) c->talloc("t:S" + std::to_string(st) + x, stage);
         c->talloc("t:dz0" + x, (size_t)B * 112 * 224 * 64);
         c->talloc("t:bnbacc" + x, (size_t)24 * 2 * 512 * 2);
         c->talloc("t:stemtmp" + x, (size_t)7 * 32 * 64);
@@ -112,9 +137,16 @@ static void train_carve(sagen_ctx* c) {
         if (!is_weights(vs.name)) continue;
         const PkdSpec p = pkd_spec(vs);
         if (p.kind == PKD_NONE) continue;
-        c->talloc("pkd:" + vs.name, packed_split_floats((size_t)p.N * ceil16(p.K)));
+        if (dgrad_phased(c->B, vs.name, p)) {
+            for (int ph = 0; ph < 4; ++ph) {
+                const int nt = phase_taps(p.kh, ph >> 1) * phase_taps(p.kw, ph & 1);
+                if (nt > 0) c->talloc("pkd:" + vs.name + "#p" + std::to_string(ph), packed_split_floats((size_t)p.a * ceil16(nt * p.b)));
+            }
+        } else {
+            c->talloc("pkd:" + vs.name, packed_split_floats((size_t)p.N * ceil16(p.K)));
+        }
     }
-    c->talloc("pkd:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);
+    c->talloc("pkd:jobs", (c->vars.size() + 64) * sizeof(PackJob) / sizeof(float) + 64);
 }
 
 // data-gradient filter packs, once per step (the optimiser rewrote the variables): one batched launch (igemm.hip: pack_multi_kernel)
@@ -126,6 +158,19 @@ static int repack_dgrad(sagen_ctx* c, hipStream_t s) {
             if (p.kind == PKD_NONE) continue;
             PackJob j;
             j.src = c->v(vs.name);
+            if (dgrad_phased(c->B, vs.name, p)) {
+                for (int ph = 0; ph < 4; ++ph) {
+                    const int ry = ph >> 1, rx = ph & 1;
+                    const int nth = phase_taps(p.kh, ry), ntw = phase_taps(p.kw, rx);
+                    if (nth * ntw == 0) continue;
+                    PackJob q = j;
+                    q.dst = c->p("pkd:" + vs.name + "#p" + std::to_string(ph));
+                    q.kind = PACK_DECONV_PHASE; q.N = p.a; q.Kpad = ceil16(nth * ntw * p.b);
+                    q.p[0] = p.kh; q.p[1] = p.kw; q.p[2] = p.a; q.p[3] = p.b; q.p[4] = ry; q.p[5] = rx; q.p[6] = ntw;
+                    c->pack_jobs_bwd.push_back(q);
+                }
+                continue;
+            }
             j.dst = c->p("pkd:" + vs.name);
             j.N = p.N; j.Kpad = ceil16(p.K);
             switch (p.kind) {
@@ -250,6 +295,25 @@ struct Bwd : Fwd {
     void dgrad_strided(const std::string& name, const float* dy, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int H, int W,
                        int Cin, float* dx, int ldy) {
         if (rc) return;
+        if (c->tbufs.count("pkd:" + name + "/weights#p0")) {       // one contraction per output phase over its non-zero taps
+            for (int ph = 0; ph < 4 && !rc; ++ph) {
+                const int ry = ph >> 1, rx = ph & 1;
+                const int nth = phase_taps(kh, ry), ntw = phase_taps(kw, rx);
+                if (nth * ntw == 0) continue;                          // (1x1: the other three phases stay zero - written once at bind)
+                IgemmDesc d;
+                d.x = dy; d.w = c->p("pkd:" + name + "/weights#p" + std::to_string(ph));
+                d.y = dx + ((long)ry * W + rx) * ldy;
+                d.Hg = (H - ry + 1) / 2; d.Wg = (W - rx + 1) / 2;
+                d.M = c->B * d.Hg * d.Wg; d.N = Cin; d.K = nth * ntw * Cout; d.Kpad = ceil16(d.K);
+                d.Hin = Ho; d.Win = Wo; d.Cin = Cout; d.ldx = Cout; d.x_bstride = (long)Ho * Wo * Cout;
+                d.ntaps = nth * ntw; d.TW = ntw; d.tap_sh = -1; d.tap_sw = -1; d.log2Cin = ilog2_exact(Cout);
+                d.Cout = Cin; d.Hlim = d.Hg; d.Wlim = d.Wg;
+                d.ldy = 2 * ldy; d.y_rstride = 2L * W * ldy; d.y_bstride = (long)H * W * ldy;
+                layer = "dgrad:" + name + "#p" + std::to_string(ph);
+                contract(d, 1, false);
+            }
+            return;
+        }
         const int nth = cdiv(kh, sh), ntw = cdiv(kw, sw);
         IgemmDesc d;
         d.x = dy; d.w = c->p("pkd:" + name + "/weights"); d.y = dx;
@@ -302,7 +366,7 @@ struct Bwd : Fwd {
         const int B = c->B;
         const float* ga = gfeat;
         const float* gb = nullptr;
-        float* DA = c->p("t:DA" + sfx); float* S = c->p("t:S" + sfx);
+        float* DA = c->p("t:DA" + sfx);
         hipEvent_t done[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (int k = 7; k >= 0 && !rc; --k) {
             aux_wait(done[k + 2]);           // the weight gradients of block k+2 have read the buffers this block overwrites
@@ -331,6 +395,7 @@ struct Bwd : Fwd {
                 wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
                 wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));
                 dgrad_strided(pfx + "/conv_1", DY1, Ho, Wo, cout, 3, 3, 2, 2, H, W, cin, A, cin);
+                float* S = c->p("t:S" + std::to_string(st) + sfx);
                 dgrad_strided(pfx + "/shortcut", Z, Ho, Wo, cout, 1, 1, 2, 2, H, W, cin, S, cin);
                 gb = S;
             } else {
@@ -557,6 +622,9 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
     // buffers whose untouched parts must be zero: the border rows of d(mask), the pad column of d(coeffs), the dead rows of d(cat1)
     for (const char* nm : {"t:ddmask", "t:dcoeffs", "t:dcat1"})
         SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
+    // ... and the three output phases a 1x1 stride-2 shortcut never reaches (its phase-wise data gradient only writes phase (0, 0))
+    for (const char* nm : {"t:S1", "t:S2", "t:S3", "t:S1_b", "t:S2_b", "t:S3_b"})
+        if (c->tbufs.count(nm)) SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
     c->train_ready = true;
     return SAGEN_OK;
 }

@@ -334,6 +334,38 @@ np.savez(sys.argv[1], **{k.replace('/', '|'): tr.grad(k).cpu().numpy() for k in 
             assert np.array_equal(out[0][k], out[1][k]), k
 
 
+def test_data_gradients_of_the_strided_convs_in_both_forms(T):
+    """The stride-2 convs' input gradient runs either as ONE depth-to-space contraction with zero-padded taps or phase by phase over
+    the non-zero taps (train_model.hip: dgrad_phased picks by size).  Both forms, forced through the environment, must give the same
+    gradients for every variable upstream of them."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_backward import _setup
+from spatialaudiogen_amd.train import Trainer
+net, ref, P, inp, target = _setup(torch, ['audio', 'video'], 3, 8)
+tr = Trainer(net, batch=3)
+tr.forward_backward(inp['audio'], inp.get('video'), None, target)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **{k.replace('/', '|'): tr.grad(k).cpu().numpy() for k in tr.opt.layout})
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for mode in ({'SAGEN_DGRAD_UNPHASED': '1'}, {'SAGEN_DGRAD_PHASE_TILES': '0'}):
+        fn = tempfile.mktemp(suffix='.npz')
+        env = dict(os.environ)
+        env.update(mode)
+        subprocess.run([sys.executable, '-c', code % (root, os.path.join(root, 'tests')), fn], check=True, env=env, timeout=900)
+        out.append(dict(np.load(fn)))
+    assert len(out[0]) == 88
+    worst = max(rel_rms_err(out[0][k], out[1][k]) for k in out[0])
+    assert worst < 2e-5, worst      # (measured: bit-identical - the padded taps add exact zeros and the other taps keep their order)
+
+
 def test_three_adam_steps_follow_the_fp64_trajectory(T):
     """Trainer.step x3 (forward, loss, backward, fused Adam, filter re-pack) vs fp64 autograd + the oracle's TF-1.4 Adam."""
     from oracle import np_oracle as O
