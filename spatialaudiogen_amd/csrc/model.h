@@ -300,9 +300,10 @@ struct Fwd {
             if (!igemm_tile_ok(d, tile)) continue;
             // conv3pp_kernel (two phase-locked teams per workgroup): faster than conv3p_kernel on its own (stage 5: 87 vs 93 us,
             // stage 4: 80 vs 83) but its 121 KiB of LDS make it the only workgroup of a CU, and with a second batch in flight the
-            // forward gets slower (1 560 vs 1 610-1 637 ambisonic-s/s) - not a candidate unless asked for (SAGEN_P3PP=1)
+            // forward gets slower (1 560 vs 1 610-1 637 ambisonic-s/s) - a candidate only for the training step, which has one batch in
+            // flight (7.27 -> 7.23 ms per step on one box), or when asked for (SAGEN_P3PP=1)
             static const bool p3pp = getenv("SAGEN_P3PP") != nullptr;
-            if (!p3pp && (tile == TILE_P3PP_PAIR || tile == TILE_P3PP_SPLITK)) continue;
+            if (!p3pp && !c->train_mode && (tile == TILE_P3PP_PAIR || tile == TILE_P3PP_SPLITK)) continue;
             const int nk = d.Kpad / igemm_tile_bk(tile);
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;
