@@ -55,6 +55,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA peak (v_mfma_f32_32x32x
 # the bf16x3 kernels evaluate every fp32 product as 6 bf16 products (3-way operand split, fp32 accumulate): their matrix roof
 # in ALGORITHMIC fp32 FLOP/s is the bf16 peak / 6
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# Context, not the roof: a kernel issuing nothing but v_mfma_f32_32x32x16_bf16 on every SIMD sustains 1.66-1.81 PFLOP/s with normally
+# distributed operands (power management; 2.28-2.48 with all-zero operands) - tools/probe/mfma_peak.py, profiles/r03_mfma_sustained.txt
+SUSTAINED_BF16X3_TFLOPS = 1740.0 / 6.0
+SUSTAINED_NOTE = ('achieved / 290 TFLOP/s = the fp32-equivalent rate a pure v_mfma_f32_32x32x16_bf16 loop sustains chip-wide on '
+                  'normally distributed operands (1.66-1.81 PFLOP/s bf16: profiles/r03_mfma_sustained.txt); `frac` above is against the data-sheet peak')
 
 
 def parse():
@@ -229,6 +234,7 @@ def main_train(args, cfg):
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+        'frac_of_sustained_mfma_rate': round(achieved / SUSTAINED_BF16X3_TFLOPS, 4) if b3 else None, 'sustained_note': SUSTAINED_NOTE if b3 else None,
         'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
                        if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -521,6 +527,7 @@ def main():
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+        'frac_of_sustained_mfma_rate': round(achieved / SUSTAINED_BF16X3_TFLOPS, 4) if b3 else None, 'sustained_note': SUSTAINED_NOTE if b3 else None,
         'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
                        if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
