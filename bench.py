@@ -129,6 +129,37 @@ def cpu_baseline_train(P, inputs, target, budget_s, encoders, batch):
                       % (len(times), batch, '+'.join(encoders), med, warm)}
 
 
+def init_ranks(dist, world, rank):
+    """One process per GPU over RCCL: `nccl` IS RCCL on ROCm.  SAGEN_DIST_BACKEND=gloo is the test hook for several ranks on ONE GPU
+    (tests/test_gpu_bench.py); anything else than what was asked for is an error, not a silent fallback."""
+    backend = os.environ.get('SAGEN_DIST_BACKEND', 'nccl')
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        got = dist.get_backend()
+        assert got == backend, 'process group runs on %r, asked for %r' % (got, backend)
+        if 'SAGEN_DIST_BACKEND' not in os.environ:
+            assert got == 'nccl', 'the multi-GPU path must run over RCCL (backend nccl), got %r' % got
+    return backend
+
+
+def ranks_report(dist, torch, world, backend, elapsed_local, steps):
+    """What an 8-GPU run must show without anyone looking at the node: every rank took part (all-reduce of ones), which backend
+    carried it, and the spread of the per-rank step times (the headline uses the max)."""
+    if world <= 1:
+        return {'backend': None, 'ranks_seen': 1, 'rank_ms_per_step': {'min': round(1e3 * elapsed_local / max(steps, 1), 4), 'max': round(1e3 * elapsed_local / max(steps, 1), 4)}}
+    dev = 'cuda' if backend != 'gloo' else 'cpu'
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(ones)
+    t = torch.zeros(world, dtype=torch.float64, device=dev)
+    t[dist.get_rank()] = 1e3 * elapsed_local / max(steps, 1)
+    dist.all_reduce(t)
+    per = [round(float(x), 4) for x in t.cpu()]
+    return {'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ' (test hook: several ranks on one GPU)'),
+            'ranks_seen': int(round(float(ones.item()))), 'rank_ms_per_step': {'min': min(per), 'max': max(per), 'per_rank': per},
+            'gpus_visible_to_rank0': torch.cuda.device_count()}
+
+
 def main_train(args, cfg):
     """--config train: BASELINE configs[4]."""
     ENCODERS, BATCH = cfg['encoders'], cfg['batch']
@@ -143,10 +174,7 @@ def main_train(args, cfg):
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU implementation')
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    backend = os.environ.get('SAGEN_DIST_BACKEND', 'nccl')
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    backend = init_ranks(dist, world, rank)
     P = init_weights(variable_specs(ENCODERS), seed=0, mode='bench')           # same replica on every rank
     inp = synth_inputs(BATCH, ENCODERS, seed=1234 + rank)                      # every rank trains on its own windows
     target = (inp['audio'][:, 24000:28800, :] * np.array([0.5, 0.25, -0.5], np.float32)).astype(np.float32)
@@ -192,6 +220,11 @@ def main_train(args, cfg):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     last_loss = float(loss)
+    ranks = ranks_report(dist, torch, world, backend, elapsed, args.steps)
+    assert ranks['ranks_seen'] == world, ranks
+    comm = {}
+    if world > 1 and tr.bucket_events is not None:      # one more step with timing events on the communication stream
+        tr.step(*dev, comm_timing=comm)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend != 'gloo' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -260,6 +293,8 @@ def main_train(args, cfg):
                        len(tr.opt.grads), sum(g.numel() for g in tr.opt.grads) * 4 / 1e6, world, backend if world > 1 else 'none'),
                    'launch_plan': 'autotuned on rank 0 and broadcast (%d contractions)' % len(plan) if plan else 'shape heuristics',
                    'weights': 'random init (Xavier / BN identity), same replica on every rank', 'last_loss': last_loss},
+        'ranks': ranks,
+        'gradient_exchange_timing': comm or None,
         'roofline': roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -300,11 +335,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU implementation')
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    backend = os.environ.get('SAGEN_DIST_BACKEND', 'nccl')
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        # RCCL ('nccl') is the backend; SAGEN_DIST_BACKEND=gloo is a test hook for running several ranks on ONE GPU
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    backend = init_ranks(dist, world, rank)
 
     P = init_weights(variable_specs(ENCODERS), seed=0, mode='bench')           # same replica on every rank
     is_eval = args.config == 'eval'
@@ -439,6 +470,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks = ranks_report(dist, torch, world, backend, elapsed, steps)
+    assert ranks['ranks_seen'] == world, ranks
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend != 'gloo' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -557,6 +590,7 @@ def main():
                    'weights': 'random init (Xavier / BN identity), same replica on every rank',
                    'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics',
                    'batches_in_flight': NF},
+        'ranks': ranks,
         'step_latency_ms_event': {'median': round(float(np.median(step_ms)), 4), 'p10': round(step_ms[len(step_ms) // 10], 4),
                           'p90': round(step_ms[(9 * len(step_ms)) // 10], 4)},
         'roofline': roofline,

@@ -81,6 +81,10 @@ int  sagen_version(void);
 /* the compiler flags this library was built with (the Python host refuses a build without -fno-slp-vectorize -fno-vectorize:
  * packed-fp32 VALU next to bf16 MFMA waves of another stream returned wrong results on MI355X) */
 const char* sagen_build_info(void);
+/* sha256 (first 16 hex digits) over every source of this library (every .hip and .h under csrc/, and this header) at the moment it was
+ * linked: the prebuilt .so travels to the GPU box with the tree, and the tests compare this with the digest of the sources that
+ * travelled with it (spatialaudiogen_amd.build.source_digest) */
+const char* sagen_source_digest(void);
 const char* sagen_last_error(void);
 
 /* ---- model-level: replaces SptAudioGen.inference_ops (model.py:356-434), as called at

@@ -46,25 +46,34 @@ def deconv2d_tf(x, w_hwoi, stride):
 class TorchRef(object):
     """Forward pass of SptAudioGen.inference_ops (model.py:356-434) on torch CPU tensors."""
 
-    def __init__(self, P, encoders, sep_num_tracks=32, n_loc=2, dtype=torch.float32):
+    def __init__(self, P, encoders, sep_num_tracks=32, n_loc=2, dtype=torch.float32, device='cpu'):
+        """device='cuda' runs the same restatement through torch-ROCm (test infrastructure for long trajectories: a few hundred
+        fp64 autograd steps take minutes on the CPU); everything the product path is compared with stays THIS code."""
         self.dt = dtype
-        self.P = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in P.items()}
+        self.dev = torch.device(device)
+        self.P = {k: (v.detach().to(self.dev, dtype) if torch.is_tensor(v) else torch.as_tensor(np.asarray(v)).to(self.dev, dtype)) for k, v in P.items()}
         self.encoders = list(encoders)
         self.nsep = sep_num_tracks
         self.n_loc = n_loc
         self.W = 1024
         n = torch.arange(self.W, dtype=torch.float64)
-        self.hann = (0.5 - 0.5 * torch.cos(2 * math.pi / self.W * n)).to(torch.float32).to(dtype)
+        self.hann = (0.5 - 0.5 * torch.cos(2 * math.pi / self.W * n)).to(torch.float32).to(self.dev, dtype)
         self.ends = {}
         # optional {layer name: boolean NCHW / row mask}: ReLUs listed here are evaluated as x * mask instead of max(x, 0).  The
         # gradient tests pass the masks of the DEVICE activations: a ReLU whose input is within rounding distance of 0 may switch
         # differently in fp32 and fp64, and each such element changes its gradient by 100 % (a relative RMS error of
         # sqrt(fraction switched), 1e-3..1e-2 in the 1.6M-element ResNet layers) - a property of the comparison, not of the backward
         self.relu_masks = {}
+        # record_masks=True: the switching pattern of THIS forward ({key: bool ndarray, same layout as relu_masks}) is kept in
+        # own_masks - the tests bound how far the device's pattern is from it before they hand the device's pattern in
+        self.record_masks = False
+        self.own_masks = {}
 
     def _relu(self, x, key):
+        if self.record_masks:
+            self.own_masks[key] = (x.detach() > 0).cpu().numpy()
         m = self.relu_masks.get(key)
-        return F.relu(x) if m is None else x * torch.as_tensor(m).to(x.dtype)
+        return F.relu(x) if m is None else x * torch.as_tensor(m).to(x.device, x.dtype)
 
     def stft(self, audio):                     # [B, 52799] -> [B,200,1024] complex (myutils.py:119-147)
         fr = audio.unfold(1, self.W, self.W // 4)[:, :200]
@@ -104,7 +113,8 @@ class TorchRef(object):
 
     def _forward(self, audio, video=None, flow=None):
         P, dt = self.P, self.dt
-        audio = torch.as_tensor(np.asarray(audio)).to(dt)[:, :, 0]           # [B, 52799]
+        to_dev = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).to(self.dev, dt)
+        audio = to_dev(audio)[:, :, 0]                                     # [B, 52799]
         B = audio.shape[0]
         S = self.stft(audio)                                               # [B,200,1024]
         mag = S[:, 46:173].abs().to(dt)[:, None]                           # NCHW [B,1,127,1024]
@@ -122,7 +132,7 @@ class TorchRef(object):
         feats = [self.fc(a5, 'bottleneck/audio-fc')]
         for k, inp in ((VIDEO, video), (FLOW, flow)):
             if k in self.encoders:
-                v = torch.as_tensor(np.asarray(inp)).to(dt)[:, 0].permute(0, 3, 1, 2)
+                v = to_dev(inp)[:, 0].permute(0, 3, 1, 2)
                 v = self.resnet(v, k + '_encoder').permute(0, 2, 3, 1)      # NHWC [B,7,14,512]
                 v = self.fc(v, 'bottleneck/%s-fc-red' % k).reshape(B, 1, 7 * 14 * 128)
                 v = self.fc(v, 'bottleneck/%s-fc' % k)
@@ -150,12 +160,12 @@ class TorchRef(object):
         m = torch.sigmoid(x[:, :, 43:71, :])                               # [B,32,28,1024]
         sep = S[:, None, 89:117, :] * m                                    # complex
         y = torch.fft.ifft(sep, dim=-1).real.to(dt)                        # [B,32,28,1024]
-        ola = torch.zeros(B, self.nsep, 27 * 256 + 1024, dtype=dt)
+        ola = torch.zeros(B, self.nsep, 27 * 256 + 1024, dtype=dt, device=self.dev)
         for fidx in range(28):
             ola[:, :, fidx * 256:fidx * 256 + 1024] += y[:, :, fidx]
         xs = (ola / 4.)[:, :, 768:768 + 6400][:, :, 448:448 + 4800]        # myutils.py:196-205, model.py:344-347
         # decoder (model.py:421-434)
-        step = torch.arange(4800) // 1600
+        step = torch.arange(4800, device=self.dev) // 1600
         w_t = w_loc[:, step]                                               # [B,4800,o,k]
         out = torch.einsum('bnok,bkn->bno', w_t, xs) + b_loc[:, step]
         return out
@@ -175,14 +185,29 @@ class TorchRef(object):
             for k in keep:
                 self.ends[k].retain_grad()
                 kept[k] = self.ends[k]
-            loss = stft_loss_torch(pred, torch.as_tensor(np.asarray(target)).to(self.dt),
-                                   None if mask is None else torch.as_tensor(np.asarray(mask)).to(self.dt))
+            td = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).to(self.dev, self.dt)
+            loss = stft_loss_torch(pred, td(target), None if mask is None else td(mask))
             loss.backward()
-        grads = {k: self.P[k].grad.detach().numpy().copy() for k in names}
-        igr = {k: v.grad.detach().numpy().copy() for k, v in kept.items()}
+        grads = {k: self.P[k].grad.detach().cpu().numpy().copy() for k in names}
+        igr = {k: v.grad.detach().cpu().numpy().copy() for k, v in kept.items()}
         for k in names:
             self.P[k] = self.P[k].detach()
-        return float(loss.detach()), grads, pred.detach().numpy(), igr
+        return float(loss.detach()), grads, pred.detach().cpu().numpy(), igr
+
+    def loss_and_grad_tensors(self, audio, video, flow, target, mask=None):
+        """As loss_and_grads but everything stays a tensor on self.dev: (loss tensor, {name: gradient tensor}) - the long-trajectory
+        test keeps its whole Adam state on the device."""
+        names = [k for k in self.P if '/moving_' not in k]
+        for k in names:
+            self.P[k] = self.P[k].detach().requires_grad_(True)
+        with torch.enable_grad():
+            pred = self._forward(audio, video, flow)
+            td = lambda a: (a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).to(self.dev, self.dt)
+            loss = stft_loss_torch(pred, td(target), None if mask is None else td(mask))
+            gs = torch.autograd.grad(loss, [self.P[k] for k in names])
+        for k in names:
+            self.P[k] = self.P[k].detach()
+        return loss.detach(), dict(zip(names, gs))
 
 
 def stft_for_loss_torch(x, window=2048, n_overlap=2):
@@ -190,7 +215,7 @@ def stft_for_loss_torch(x, window=2048, n_overlap=2):
     x [B, N, C] -> complex [B, C, nW, window]."""
     B, N, C = x.shape
     n = torch.arange(window, dtype=torch.float64)
-    hann = (0.5 - 0.5 * torch.cos(2 * math.pi / window * n)).to(torch.float32).to(x.dtype)
+    hann = (0.5 - 0.5 * torch.cos(2 * math.pi / window * n)).to(torch.float32).to(x.device, x.dtype)
     wins = []
     stride = window // n_overlap
     for i in range(n_overlap):
@@ -204,7 +229,7 @@ def stft_loss_torch(pred, gt, mask=None):
     """losses['stft/mse'] = metrics['stft/avg'] (model.py:62-76, 122-127, 156-159)."""
     B, _, C = pred.shape
     if mask is None:
-        mask = torch.ones(B, C, dtype=pred.dtype)
+        mask = torch.ones(B, C, dtype=pred.dtype, device=pred.device)
     nm = torch.clamp(mask.sum(0), min=1.0)
     d = (stft_for_loss_torch(gt) - stft_for_loss_torch(pred)).abs() ** 2
     ps = d.mean(3).mean(2)                                   # [B, C]

@@ -33,6 +33,7 @@ SIGNATURES = {
     'sagen_version': (C.c_int, []),
     'sagen_last_error': (C.c_char_p, []),
     'sagen_build_info': (C.c_char_p, []),
+    'sagen_source_digest': (C.c_char_p, []),
     'sagen_create': (C.c_int, [C.POINTER(_P), C.POINTER(SagenConfig)]),
     'sagen_destroy': (None, [_P]),
     'sagen_workspace_bytes': (_SZ, [_P]),

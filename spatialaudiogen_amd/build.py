@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libsagen_hip.so')
 SOURCES = ['conv3p.hip', 'p3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'stempool.hip', 'igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'train.hip', 'wgrad.hip', 'backward.hip', 'model.hip', 'train_model.hip', 'api.hip']
-HEADERS = [os.path.join(CSRC, h) for h in ('common.h', 'kernels.h', 'igemm_common.h', 'igemm3_common.h', 'model.h')] + \
+HEADERS = [os.path.join(CSRC, h) for h in ('common.h', 'kernels.h', 'wave_reduce.h', 'igemm_common.h', 'igemm3_common.h', 'model.h')] + \
           [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'sagen.h')]
 # -fno-slp-vectorize -fno-vectorize: no packed-fp32 VALU (v_pk_add/mul/fma_f32).  Measured on MI355X: a wave executing packed-fp32 ops gives
 # wrong results while a wave of another kernel issues v_mfma_f32_32x32x16_bf16 on the same SIMD (the LDS FFT kernels next to the
@@ -35,6 +35,18 @@ def flags_digest():
     import hashlib
     h = hashlib.sha256(' '.join(FLAGS).encode())
     h.update(open(os.path.abspath(__file__), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def source_digest():
+    """sha256[:16] over the library's sources (name + contents, sorted): compiled into the library at link time
+    (sagen_source_digest) so that a stale prebuilt .so can be told from the tree it travels with."""
+    import hashlib
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.encode() + b'\0' + open(os.path.join(CSRC, f), 'rb').read() + b'\0')
+    h.update(b'sagen.h\0' + open(HEADERS[-1], 'rb').read())
     return h.hexdigest()[:16]
 
 
@@ -73,6 +85,17 @@ def build(force=False, verbose=True):
             if verbose and err.strip():
                 print(err)
     objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
+    # the digest object: one host-only translation unit, regenerated whenever the digest of the sources changes
+    digest = source_digest()
+    dsrc, dobj = os.path.join(OBJ, 'source_digest.cpp'), os.path.join(OBJ, 'source_digest.o')
+    text = 'extern "C" const char* sagen_source_digest(void) { return "%s"; }\n' % digest
+    if force or not os.path.exists(dsrc) or open(dsrc).read() != text or not os.path.exists(dobj):
+        with open(dsrc, 'w') as f:
+            f.write(text)
+        r = subprocess.run([hipcc, '-O1', '-fPIC', '-c', '-x', 'c++', dsrc, '-o', dobj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('digest object failed:\n%s' % r.stderr)
+    objs.append(dobj)
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
         if verbose:

@@ -336,7 +336,10 @@ def save_checkpoint(prefix, variables, block_entries=64):
     names = sorted(variables)
     offset = 0
     entries = [(b'', _pb(1, 0, _put_varint(1)) + _pb(3, 2, _put_varint(2) + _pb(1, 0, _put_varint(1))))]
-    with open(prefix + '.data-00000-of-00001', 'wb') as f:
+    # atomic: both files are written under temporary names and renamed, the `checkpoint` state file is replaced last - a run
+    # killed anywhere in here leaves `latest_checkpoint` pointing at the previous, complete bundle
+    tmp_tag = '.tmp-%d' % os.getpid()
+    with open(prefix + '.data-00000-of-00001' + tmp_tag, 'wb') as f:
         for n in names:
             a = np.asarray(variables[n])
             if a.ndim and not a.flags['C_CONTIGUOUS']:
@@ -344,6 +347,8 @@ def save_checkpoint(prefix, variables, block_entries=64):
             entries.append((n.encode('utf-8'), _entry_proto(a, offset)))
             f.write(a.tobytes())
             offset += a.nbytes
+        f.flush()
+        os.fsync(f.fileno())
     out = bytearray()
     index_items = []
     for i in range(0, len(entries), block_entries):
@@ -361,7 +366,22 @@ def save_checkpoint(prefix, variables, block_entries=64):
     footer = meta_handle + idx_handle
     footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', TABLE_MAGIC)
     out += footer
-    with open(prefix + '.index', 'wb') as f:
+    with open(prefix + '.index' + tmp_tag, 'wb') as f:
         f.write(bytes(out))
-    with open(os.path.join(os.path.dirname(prefix) or '.', 'checkpoint'), 'w') as f:
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(prefix + '.data-00000-of-00001' + tmp_tag, prefix + '.data-00000-of-00001')
+    os.replace(prefix + '.index' + tmp_tag, prefix + '.index')
+    state_fn = os.path.join(os.path.dirname(prefix) or '.', 'checkpoint')
+    with open(state_fn + tmp_tag, 'w') as f:
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % ((os.path.basename(prefix),) * 2))
+    os.replace(state_fn + tmp_tag, state_fn)
+
+
+def remove_checkpoint(prefix):
+    """Delete the files of one bundle (tf.train.Saver(max_to_keep=1) drops the previous periodic checkpoint, train.py:176)."""
+    for sfx in ('.index', '.data-00000-of-00001'):
+        try:
+            os.remove(prefix + sfx)
+        except OSError:
+            pass

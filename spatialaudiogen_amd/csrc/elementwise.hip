@@ -271,8 +271,7 @@ __global__ __launch_bounds__(256) void power_moments_kernel(const float4* __rest
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         float v = m[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = wave_sum(v);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
@@ -312,8 +311,7 @@ __global__ __launch_bounds__(256) void power_moments_batched_kernel(const float4
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         float v = m[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = wave_sum(v);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();

@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256) void eval_time_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float v = acc[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = wave_sum(v);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
@@ -102,8 +101,7 @@ __global__ __launch_bounds__(256) void eval_lsd_reduce_kernel(const float* __res
             const float d = 10.f * (logf(mg + 1e-2f) - logf(mp + 1e-2f)) / logf(10.f);
             acc += ((k == 0 || k == LSD_W / 2) ? 1.f : 2.f) * d * d;           // bins k and 1200-k are equal
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        acc = wave_sum(acc);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
         if (threadIdx.x == 0) lsd += sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)LSD_W);

@@ -221,8 +221,7 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-#pragma unroll
-            for (int m = 1; m < TPRW; m <<= 1) e[c] += __shfl_xor(e[c], m);
+            e[c] = wave_sum<1, TPRW>(e[c]);
             if (part == 0) E[c][ps * RPP + row] = e[c];
         }
         __syncthreads();                         // the staging area is rewritten by the next pass (and then by the FFT)
@@ -426,8 +425,7 @@ __global__ __launch_bounds__(256) void mask_istft_bwd_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float a = acc[c][u];
-#pragma unroll
-            for (int m = NC; m < 64; m <<= 1) a += __shfl_xor(a, m);
+            a = wave_sum<NC, 64>(a);
             acc[c][u] = a;
         }
     const int lane = tid & 63, wave = tid >> 6;
@@ -453,8 +451,7 @@ __global__ __launch_bounds__(256) void mask_bwd_finalize_kernel(const float* __r
     float a = 0.f;
     for (int n = 1600 * s + tid; n < 1600 * (s + 1); n += 256) a += dpred[((long)b * 4800 + n) * 3 + o];
     __shared__ float red[4];
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m);
+    a = wave_sum(a);
     if ((tid & 63) == 0) red[tid >> 6] = a;
     __syncthreads();
     float* out = dcoeffs + ((long)b * 3 + s) * ldc + o * (ntr + 1);

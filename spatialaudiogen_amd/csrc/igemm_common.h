@@ -159,8 +159,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)
         __syncthreads();                       // (the K loop already ended with a barrier; kept for clarity)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            float s = csum[j] + __shfl_xor(csum[j], 32);
-            float q = csq[j] + __shfl_xor(csq[j], 32);
+            float s = wave_xor_add<32>(csum[j]);
+            float q = wave_xor_add<32>(csq[j]);
             if (kk == 0) {
                 const int col = wn * WN + j * 32 + li;
                 red[(0 * WAVES_M + wm) * BN + col] = s;
@@ -341,7 +341,7 @@ __device__ __forceinline__ void igemm_epilogue_maskmix(const IgemmDesc& d, f32x1
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) e[c] += __shfl_xor(e[c], 1);
+            for (int c = 0; c < 6; ++c) e[c] = wave_xor_add<1>(e[c]);
             const int row = part * WM + r;
             const int x = (q0 + row) * d.dsw + rx0 + sub;
             if (half == 0 && m0 + row < d.M && x < d.Wlim) {

@@ -1,6 +1,7 @@
 // Launcher declarations of every HIP kernel family of the path (gfx950).
 #pragma once
 #include "common.h"
+#include "wave_reduce.h"
 
 namespace sagen {
 

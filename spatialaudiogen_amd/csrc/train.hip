@@ -49,8 +49,7 @@ __global__ __launch_bounds__(256) void stft_loss_grad_kernel(const float* __rest
         if (grad) grad[base + (long)n * TR_C] = gscale * w2 * d;
     }
     __shared__ float red[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0 && loss)

@@ -96,11 +96,14 @@ class AdamBuckets(object):
             if async_op:
                 self._pending.append(w)
 
-    def all_reduce_after(self, events, comm_stream):
+    def all_reduce_after(self, events, comm_stream, timing=None):
         """The same exchange, overlapped with the backward pass: bucket b's all-reduce is enqueued on `comm_stream` behind
         events[b], which the native step records as soon as the last gradient of bucket b has been enqueued
         (sagen_train_set_grad_events).  Buckets follow the declaration order of the variables = the order of the forward, so the
-        backward completes them last to first."""
+        backward completes them last to first.
+        timing (a list, measurement only): per bucket a pair of timing events on the communication stream is appended - (bucket,
+        ready = its gradients are complete and the stream is free, done = its all-reduce has finished); `comm_timing` turns them
+        into the time the stream spent waiting for gradients vs exchanging them."""
         import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
@@ -108,7 +111,15 @@ class AdamBuckets(object):
         for b in reversed(range(len(self.grads))):
             comm_stream.wait_event(events[b])
             with torch.cuda.stream(comm_stream):
-                self._pending.append(dist.all_reduce(self.grads[b], async_op=True))
+                if timing is None:
+                    self._pending.append(dist.all_reduce(self.grads[b], async_op=True))
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    w = dist.all_reduce(self.grads[b], async_op=True)
+                    w.wait()                                      # (the communication stream waits for the collective's stream)
+                    e1.record()
+                    timing.append((b, e0, e1))
 
     def wait(self):
         for w in self._pending:
@@ -285,14 +296,40 @@ class Trainer(object):
         check(_lib.lib().sagen_train_step(self.ctx.handle, p(a), p(v), p(f), p(t), p(mk), p(self.pred), p(self.loss), int(update_moving), stream))
         return self.loss
 
-    def step(self, audio, video, flow, target, mask=None):
-        """One training iteration (train.py:208): returns (loss tensor on device, learning rate used)."""
+    def step(self, audio, video, flow, target, mask=None, comm_timing=None):
+        """One training iteration (train.py:208): returns (loss tensor on device, learning rate used).
+        comm_timing (dict, measurement only, needs the overlapped exchange): filled with the milliseconds the communication stream
+        spent waiting for gradient buckets and inside all-reduces during this step (synchronises at the end)."""
+        import torch
+        timing = None
+        if comm_timing is not None and self.bucket_events is not None:
+            timing = []
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record(torch.cuda.current_stream(self.device))
+            self.comm_stream.wait_event(t_begin)
         loss = self.forward_backward(audio, video, flow, target, mask)
         if self.bucket_events is not None:
-            self.opt.all_reduce_after(self.bucket_events, self.comm_stream)      # under the rest of the (still running) backward
+            self.opt.all_reduce_after(self.bucket_events, self.comm_stream, timing)      # under the rest of the (still running) backward
+            if timing is not None:                                # the optimiser (current stream) consumes what the exchange produced
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         else:
             self.opt.all_reduce()
         lr = self.opt.apply()
+        if timing:
+            t_end = torch.cuda.Event(enable_timing=True)
+            t_end.record(torch.cuda.current_stream(self.device))
+            torch.cuda.synchronize(self.device)
+            wait_ms, xchg_ms, prev, rows = 0.0, 0.0, t_begin, []
+            for b, e0, e1 in timing:
+                w, x = max(prev.elapsed_time(e0), 0.0), e0.elapsed_time(e1)
+                rows.append({'bucket': b, 'mbytes': round(self.opt.grads[b].numel() * 4 / 1e6, 1), 'ready_ms': round(t_begin.elapsed_time(e0), 3),
+                             'wait_ms': round(w, 3), 'all_reduce_ms': round(x, 3)})
+                wait_ms += w
+                xchg_ms += x
+                prev = e1
+            comm_timing.update(step_ms=round(t_begin.elapsed_time(t_end), 3), waiting_for_gradients_ms=round(wait_ms, 3),
+                               in_all_reduce_ms=round(xchg_ms, 3), last_all_reduce_done_ms=round(t_begin.elapsed_time(timing[-1][2]), 3),
+                               buckets=rows)
         return loss, lr
 
     def grad(self, name):
@@ -397,18 +434,51 @@ class Trainer(object):
         out['beta2_power'] = np.asarray(ADAM_BETA2 ** (self.opt.step + 1), np.float32)
         return out
 
-    def load_state_dict(self, state):
+    def load_state_dict(self, state, strict_slots=False, log=None):
+        """Restore variables, Adam slots, moving averages and the step.  A checkpoint without the optimiser slots (a deploy /
+        weights-only bundle) cannot continue the Adam trajectory: the step is then reset to 0 with zero moments - a FRESH optimiser on
+        the restored weights, whose bias corrections are consistent - and a warning says so (strict_slots=True raises instead)."""
+        import warnings
         import torch
+        missing_slots = []
         for k in self.opt.layout:
             for which, sfx in (('params', ''), ('m', '/Adam'), ('v', '/Adam_1')):
+                dst = self.opt.view(which, k)
                 if k + sfx in state:
-                    self.opt.view(which, k).copy_(torch.as_tensor(np.asarray(state[k + sfx], np.float32)))
+                    src = np.asarray(state[k + sfx], np.float32)
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise ValueError('checkpoint entry %s has shape %s, the model expects %s' % (k + sfx, tuple(src.shape), tuple(dst.shape)))
+                    dst.copy_(torch.as_tensor(src))
                 elif not sfx:
                     raise KeyError('variable %s missing from the checkpoint' % k)
+                else:
+                    missing_slots.append(k + sfx)
         for k in self.moving:
             if k in state:
-                self.moving[k].copy_(torch.as_tensor(np.asarray(state[k], np.float32)))
-        self.opt.step = int(np.asarray(state.get('step', 0)))
+                src = np.asarray(state[k], np.float32)
+                if tuple(src.shape) != tuple(self.moving[k].shape):
+                    raise ValueError('checkpoint entry %s has shape %s, the model expects %s' % (k, tuple(src.shape), tuple(self.moving[k].shape)))
+                self.moving[k].copy_(torch.as_tensor(src))
+        step = int(np.asarray(state.get('step', 0)))
+        if missing_slots:
+            msg = ('%d Adam slots are missing from the checkpoint (first: %s): the optimiser restarts at step 0 with zero moments '
+                   'on the restored variables' % (len(missing_slots), missing_slots[0]))
+            if strict_slots:
+                raise KeyError(msg)
+            warnings.warn(msg)
+            if log:
+                log('WARNING: ' + msg)
+            for k in self.opt.layout:
+                self.opt.view('m', k).zero_()
+                self.opt.view('v', k).zero_()
+            step = 0
+        elif 'beta1_power' in state:
+            # TF keeps beta^(t+1) next to the slots; a bundle whose step and powers disagree was assembled from two runs
+            b1 = float(np.asarray(state['beta1_power']))
+            want = ADAM_BETA1 ** (step + 1)
+            if abs(b1 - want) > 1e-3 * max(want, 1e-30) and want > 1e-30:
+                warnings.warn('beta1_power %.6g of the checkpoint does not match step %d (expected %.6g)' % (b1, step, want))
+        self.opt.step = step
 
     def save(self, model_dir, global_step=None):
         from .checkpoint import save_checkpoint
@@ -451,7 +521,13 @@ def synthetic_batches(encoders, batch, seed=0, pool=2):
         i += 1
 
 
-def folder_batches(db_dir, ids, params, batch, layouts=None, seed=0, samples_per_clip=5):
+def silence_threshold(subset_fn, db_dir=None):
+    """feeder.py:310: `0.01 if 'REC-Street' in self.subset_fn else 0.2` - the SUBSET FILE NAME decides (README: `--subset_fn
+    meta/subsets/REC-Street.train.1.lst`); a match in the dataset folder name is accepted as well."""
+    return 0.01 if ('REC-Street' in str(subset_fn or '') or 'REC-Street' in str(db_dir or '')) else 0.2
+
+
+def folder_batches(db_dir, ids, params, batch, layouts=None, seed=0, samples_per_clip=5, subset_fn=None):
     """The training feeder (feeder.py:372-407 with for_eval=False): clips in shuffled order for ever, per clip a SampleReader with
     shuffled windows, silence skipping and random rotations about z, `samples_per_clip` (NUM_SAMPLING = 5) windows of each; the
     sample stream is cut into batches.  Yields (audio [B,n,1], video, flow, target [B,4800,3], channel mask [B,4])."""
@@ -459,7 +535,7 @@ def folder_batches(db_dir, ids, params, batch, layouts=None, seed=0, samples_per
     from .feeder import SampleReader, img_prep_fcn
     from .definitions import VIDEO, FLOW
     rnd = random.Random(seed)
-    thr = 0.01 if 'REC-Street' in str(db_dir) else 0.2                     # feeder.py:312
+    thr = silence_threshold(subset_fn if subset_fn is not None else getattr(params, 'subset_fn', None), db_dir)
     ss, t = int(params.audio_rate * params.context) // 2, int(params.audio_rate * 0.1)
     buf = []
     while True:
@@ -489,17 +565,29 @@ def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_
     import time
     import torch
     import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     history = []
     t_last, n_last = time.time(), init_step
     step = init_step
+    last_periodic = None
+    flag = None
     try:
         for step in range(init_step, n_iters):
             audio, video, flow, target, mask = next(batches)
             loss, lr = tr.step(audio, video, flow, target, mask)
             if step % log_every == 0:
-                lv = float(loss)                                            # the only host synchronisation of the loop
-                if math.isnan(lv):
+                if multi:
+                    # every rank learns about a NaN on ANY rank in the same step (sum of [loss, isnan]) and raises with the others - a
+                    # rank that left alone would leave the rest hanging in the next bucket all-reduce; the logged loss is the global mean
+                    flag = torch.stack([loss.detach().double().reshape(()), torch.isnan(loss.detach()).double().reshape(())])
+                    dist.all_reduce(flag)
+                    lv = float(flag[0]) / dist.get_world_size()
+                    bad = float(flag[1]) > 0 or math.isnan(lv)
+                else:
+                    lv = float(loss)                                        # the only host synchronisation of the loop
+                    bad = math.isnan(lv)
+                if bad:
                     raise ValueError('Training produced a NaN metric or loss.')
                 now = time.time()
                 rate = tr.batch * max(step - n_last, 1) / max(now - t_last, 1e-9)
@@ -508,10 +596,15 @@ def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_
                 if rank == 0:
                     log('TRAIN | step %d | stft/mse %.6g | lr %.3g | %.1f samples/s per GPU' % (step, lv, lr, rate))
             if step % ckpt_every == 0 and step != 0 and rank == 0:
-                tr.save(model_dir, global_step=tr.opt.step)
+                prefix = tr.save(model_dir, global_step=tr.opt.step)
+                if last_periodic and last_periodic != prefix:               # tf.train.Saver(max_to_keep=1), train.py:176
+                    from .checkpoint import remove_checkpoint
+                    remove_checkpoint(last_periodic)
+                last_periodic = prefix
                 log('=' * 60 + '\nCheckpoint saved\n' + '=' * 60)
     finally:
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         if rank == 0:
             log('End of training.\nSaving model.')
             tr.save(model_dir)
@@ -577,6 +670,7 @@ def main(argv=None):
     elif rank == 0:
         save_params(args, args.model_dir)
     args.encoders = sorted(args.encoders)
+    args.video_rate = int(1. / min(args.context, args.sample_dur, 1. / args.video_rate))      # train.py:83-84
     net = SptAudioGen(args.ambi_order, audio_rate=args.audio_rate, video_rate=args.video_rate, context=args.context,
                       sample_duration=args.sample_dur, encoders=list(args.encoders), separation=args.separation,
                       params=SptAudioGenParams(sep_num_tracks=args.num_sep_tracks, ctx_feats_fc_units=args.context_units,
@@ -593,7 +687,7 @@ def main(argv=None):
         ids = [i for i in ids if i and os.path.isdir(os.path.join(args.db_dir, i))]
         layouts = read_layouts(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'meta', 'audio_layouts.txt'))
         from .feeder import BatchPrefetcher
-        batches = iter(BatchPrefetcher(folder_batches(args.db_dir, ids, args, args.batch_size, layouts, seed=args.seed + rank), depth=4))
+        batches = iter(BatchPrefetcher(folder_batches(args.db_dir, ids, args, args.batch_size, layouts, seed=args.seed + rank, subset_fn=args.subset_fn), depth=4))
     train_loop(tr, batches, args.model_dir, args.n_iters, init_step)
 
 

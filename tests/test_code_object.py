@@ -73,3 +73,45 @@ def test_library_reports_its_build_flags():
     for flag in ('-fno-slp-vectorize', '-fno-vectorize', '--offload-arch=gfx950'):
         assert flag in info, info
     assert build.flags_digest() in open(os.path.join(build.OBJ, 'flags.stamp')).read()
+
+
+def test_library_matches_the_sources_it_travels_with():
+    """The .so is git-ignored and travels prebuilt: its link-time source digest must equal the digest of csrc/ + include/sagen.h in
+    this tree (a stale binary would make every parity test a statement about other sources)."""
+    from spatialaudiogen_amd import _lib, build
+    assert _lib.lib().sagen_source_digest().decode() == build.source_digest()
+
+
+def _kernel_bodies(text):
+    """{mangled symbol: disassembly} of every function in the objdump listing."""
+    out, name = {}, None
+    for line in text.splitlines():
+        m = re.match(r'^[0-9a-f]+ <([^>]+)>:', line)
+        if m:
+            name = m.group(1)
+            out[name] = []
+        elif name is not None:
+            out[name].append(line)
+    return {k: '\n'.join(v) for k, v in out.items()}
+
+
+def test_wave_reductions_use_dpp_not_the_lds_crossbar(disassembly):
+    """north_star: "wavefront-level DPP reductions for the per-bin magnitude and the ambisonic power map".  The reductions of the
+    power map, the evaluation metrics, the mask / iSTFT energy sums and the stft loss go through wave_reduce.h (DPP row controls
+    + v_permlane{16,32}_swap); none of those kernels may fall back to ds_bpermute_b32 (what __shfl_xor compiles to)."""
+    text, _ = disassembly
+    bodies = _kernel_bodies(text)
+    wanted = ('power_moments_kernel', 'power_moments_batched_kernel', 'eval_time_kernel', 'eval_lsd_reduce_kernel',
+              'stft_loss_grad_kernel', 'mask_istft_kernel', 'mask_istft_bwd_kernel', 'mask_bwd_finalize_kernel')
+    seen, with_dpp = set(), set()
+    for sym, body in bodies.items():
+        for w in wanted:
+            if w in sym:
+                seen.add(w)
+                assert 'ds_bpermute' not in body and 'ds_swizzle' not in body, '%s reduces through the LDS crossbar' % sym
+                if re.search(r'_dpp|permlane(16|32)_swap', body):    # (an instantiation may need no cross-lane step at all: mask_istft_kernel<16>)
+                    with_dpp.add(w)
+    missing = set(wanted) - seen
+    assert not missing, 'kernels not found in the code object: %s' % sorted(missing)
+    assert with_dpp == set(wanted), 'no DPP / permlane instruction in any instantiation of: %s' % sorted(set(wanted) - with_dpp)
+    assert 'ds_bpermute' not in text, 'some kernel still shuffles through ds_bpermute_b32'

@@ -164,3 +164,83 @@ def test_two_ranks_with_the_same_batches_equal_one_rank(T, tmp_path):
         assert np.array_equal(one[k], two[k]), k
     diff = _run_ranks(2, str(tmp_path / 'diff.npz'), {'DIFFERENT_DATA': '1'})
     assert rel_rms_err(diff['separation|deconv1|weights'], one['separation|deconv1|weights']) > 1e-9
+
+
+CHILD_DIFF = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_train_loop import _trainer
+from spatialaudiogen_amd.dist import init_process_group
+from spatialaudiogen_amd.train import synthetic_batches
+rank, world = init_process_group()
+tr, _ = _trainer(torch, ('audio', 'video'), 2, lr=1e-4)
+b = synthetic_batches(['audio', 'video'], 2, seed=7 + rank, pool=1)          # every rank trains on ITS OWN windows
+out = {}
+for s in range(2):
+    tr.step(*next(b))
+    torch.cuda.synchronize()
+    for k in tr.opt.layout:                                                  # the buckets now hold the SUM over the ranks
+        out['g%%d|' %% s + k.replace('/', '|')] = tr.grad(k).cpu().numpy()
+if rank == 0:
+    out.update({'p|' + k.replace('/', '|'): v.cpu().numpy() for k, v in tr.variables().items()})
+    np.savez(sys.argv[1], **out)
+'''
+
+
+def test_two_ranks_with_different_batches_follow_adam_on_the_mean_gradient(T, tmp_path):
+    """configs[4]'s exchange, checked against the oracle and not only against itself: two ranks, each with its own batch, two steps.
+    After every step the gradient buckets must hold g(rank 0's batch) + g(rank 1's batch) as fp64 autograd of the independent torch
+    restatement computes them at the SAME weights, and the variables must have moved by TF-1.4 Adam on the MEAN of the two.
+    Bars: the decoder / localisation gradients (no encoder ReLU lies between the loss and them) 1e-4; bottleneck, trunk and
+    audio-encoder variables the free-running bar of test_gpu_backward (ReLUs within rounding distance
+    of zero switch differently in fp32 and fp64: 2e-2); the update as in the 3-step trajectory test."""
+    from oracle import np_oracle as O
+    from oracle.torch_ref import TorchRef
+    from spatialaudiogen_amd.train import synthetic_batches
+    enc = ['audio', 'video']
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'diff.npz')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SAGEN_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, '-c', CHILD_DIFF % (ROOT, os.path.join(ROOT, 'tests')), out], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+    got = dict(np.load(out))
+    _, P = _trainer(T, enc, 2, lr=1e-4)
+    batches = [next(synthetic_batches(enc, 2, seed=7 + r, pool=1)) for r in range(2)]
+    state = {k: (np.asarray(v, np.float64), np.zeros(v.shape), np.zeros(v.shape)) for k, v in P.items() if '/moving_' not in k}
+    tight = ('separation/', 'localization/')                        # no ReLU of the encoders between the loss and these variables
+    for step in range(2):
+        cur = dict(P)
+        cur.update({k: v[0] for k, v in state.items()})
+        gs = []
+        for r in range(2):
+            a, v, f, t, m = batches[r]
+            gs.append(TorchRef(cur, enc, dtype=T.float64).loss_and_grads(a, v, f, t, m[:, 1:])[1])
+        worst_tight, worst_free = 0.0, 0.0
+        for k in state:
+            want = gs[0][k] + gs[1][k]
+            err = rel_rms_err(got['g%d|' % step + k.replace('/', '|')], want)
+            # not one rank's gradient doubled: the two batches give different gradients
+            assert rel_rms_err(2 * gs[0][k], want) > 10 * max(err, 1e-6) or rel_rms_err(2 * gs[0][k], want) > 1e-2, k
+            if k.startswith(tight):
+                worst_tight = max(worst_tight, err)
+                assert err < (1e-4 if step == 0 else 1e-2), (step, k, err)   # (step 1 runs at weights that already differ by the fp32 update)
+            else:
+                worst_free = max(worst_free, err)
+                assert err < (2e-2 if step == 0 else 5e-2), (step, k, err)
+        print('\n[2 ranks, step %d] summed gradient vs fp64 autograd: decoder side max %.2e, encoder side (free-running ReLUs) max %.2e'
+              % (step, worst_tight, worst_free))
+        for k in state:
+            state[k] = O.adam_tf(state[k][0], 0.5 * (gs[0][k] + gs[1][k]), state[k][1], state[k][2], step + 1, 1e-4)
+    errs = []
+    for k in state:
+        upd = got['p|' + k.replace('/', '|')].astype(np.float64) - np.asarray(P[k], np.float64)
+        upd_ref = state[k][0] - np.asarray(P[k], np.float64)
+        errs.append((k, rel_rms_err(upd, upd_ref)))
+    worst = max(errs, key=lambda t_: t_[1])
+    assert np.median([e for _, e in errs]) < 2e-2 and worst[1] < 0.2, worst

@@ -77,3 +77,116 @@ def test_gradient_buckets_all_reduce_two_ranks():
         assert set(out) == {'a/weights', 'b/biases', 'c/weights'}            # the moving average is not a trained variable
         for name, g in out.items():
             assert np.array_equal(g, np.full(g.shape, 3.0 * (1 + len(name)), np.float32))      # (1 + 2) x the per-rank value
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the loop of train.py:202-234 around a stand-in trainer (no device): checkpoint retention, collective NaN abort
+# ------------------------------------------------------------------------------------------------------------------------
+class _FakeOpt(object):
+    step = 0
+
+
+class _FakeTrainer(object):
+    """Trainer's loop-facing surface: step() -> (loss tensor, lr), save(), opt.step, batch."""
+    batch = 2
+
+    def __init__(self, nan_at=None):
+        import torch
+        self.torch = torch
+        self.opt = _FakeOpt()
+        self.nan_at = nan_at
+
+    def step(self, audio, video, flow, target, mask=None):
+        v = float('nan') if (self.nan_at is not None and self.opt.step == self.nan_at) else 1.0 / (1 + self.opt.step)
+        self.opt.step += 1
+        return self.torch.tensor(v), 1e-4
+
+    def save(self, model_dir, global_step=None):
+        from spatialaudiogen_amd.checkpoint import save_checkpoint
+        prefix = os.path.join(model_dir, 'model.ckpt' + ('-%d' % global_step if global_step is not None else ''))
+        save_checkpoint(prefix, {'step': np.asarray(self.opt.step, np.int32), 'w': np.arange(6, dtype=np.float32)})
+        return prefix
+
+
+def _endless():
+    while True:
+        yield (None, None, None, None, None)
+
+
+def test_train_loop_keeps_one_periodic_checkpoint(tmp_path):
+    """tf.train.Saver(max_to_keep=1) (train.py:176): the previous periodic bundle goes when the next one is complete; the final
+    `model.ckpt` is written at exit and `checkpoint` names it."""
+    from spatialaudiogen_amd.checkpoint import latest_checkpoint, load_checkpoint
+    d = str(tmp_path)
+    hist = T.train_loop(_FakeTrainer(), _endless(), d, n_iters=9, log_every=2, ckpt_every=2, log=lambda *_: None)
+    assert [h[0] for h in hist] == [0, 2, 4, 6, 8]
+    files = sorted(os.listdir(d))
+    assert files == ['checkpoint', 'model.ckpt-9.data-00000-of-00001', 'model.ckpt-9.index', 'model.ckpt.data-00000-of-00001',
+                     'model.ckpt.index'], files                      # saved after steps 2, 4, 6, 8 (opt.step 3, 5, 7, 9): only the last is left
+    assert latest_checkpoint(d) == os.path.join(d, 'model.ckpt')
+    assert int(load_checkpoint(latest_checkpoint(d))['step']) == 9
+
+
+def test_checkpoint_write_is_atomic(tmp_path, monkeypatch):
+    """A writer that dies between the data file and the state file must leave --resume pointing at the previous complete bundle."""
+    from spatialaudiogen_amd import checkpoint as C
+    d = str(tmp_path)
+    C.save_checkpoint(os.path.join(d, 'model.ckpt-1'), {'w': np.ones(3, np.float32)})
+    assert C.latest_checkpoint(d) == os.path.join(d, 'model.ckpt-1')
+    real, calls = os.replace, []
+
+    def dying_replace(a, b):
+        calls.append(b)
+        if len(calls) == 2:                                         # .data renamed, the .index rename "is killed"
+            raise KeyboardInterrupt()
+        return real(a, b)
+    monkeypatch.setattr(os, 'replace', dying_replace)
+    with pytest.raises(KeyboardInterrupt):
+        C.save_checkpoint(os.path.join(d, 'model.ckpt-2'), {'w': np.zeros(3, np.float32)})
+    monkeypatch.setattr(os, 'replace', real)
+    assert C.latest_checkpoint(d) == os.path.join(d, 'model.ckpt-1')
+    assert np.array_equal(C.load_checkpoint(C.latest_checkpoint(d))['w'], np.ones(3, np.float32))
+    C.save_checkpoint(os.path.join(d, 'model.ckpt-3'), {'w': np.full(3, 3, np.float32)})
+    assert not [f for f in os.listdir(d) if '.tmp-' in f and 'ckpt-3' in f]
+    C.remove_checkpoint(os.path.join(d, 'model.ckpt-1'))
+    assert not os.path.exists(os.path.join(d, 'model.ckpt-1.index'))
+
+
+def _nan_worker(rank, world, port, tmp, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from spatialaudiogen_amd.dist import init_process_group
+    from spatialaudiogen_amd import train as T
+    import test_train_host as me
+    init_process_group('gloo')
+    tr = me._FakeTrainer(nan_at=4 if rank == 1 else None)          # only rank 1 ever sees a NaN
+    err, hist = None, []
+    try:
+        T.train_loop(tr, me._endless(), os.path.join(tmp, 'r%d' % rank), n_iters=20, log_every=2, ckpt_every=1000,
+                     log=lambda *_: None)
+    except ValueError as e:
+        err = str(e)
+    dist.barrier()                                                   # both ranks left the loop: nobody hangs in a collective
+    dist.destroy_process_group()
+    q.put((rank, err, tr.opt.step))
+
+
+def test_nan_on_one_rank_stops_every_rank_in_the_same_step(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    for r in range(2):
+        os.makedirs(str(tmp_path / ('r%d' % r)))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, steps in res:
+        assert err and 'NaN' in err, (rank, err)
+        assert steps == 5                                            # the NaN appears in step 4, a logged step: both stop after it

@@ -22,4 +22,8 @@ def ensure_lib():
     import os
     if not os.path.exists(_lib.LIB_PATH):
         build.build(verbose=False)
-    return _lib.lib()
+    l = _lib.lib()
+    if not os.environ.get('SAGEN_LIB'):
+        got, want = l.sagen_source_digest().decode(), build.source_digest()
+        assert got == want, 'libsagen_hip.so was built from other sources (digest %s, tree %s): rebuild it' % (got, want)
+    return l
