@@ -76,6 +76,9 @@ def parse():
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
     ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
+    ap.add_argument('--float-frames', action='store_true',
+                    help='keep the resident video frames as the float32 the feeder would make of them (x/255 - 0.5) instead of the uint8 the '
+                         'JPEG decoder produced: the general float entry point (sagen_forward) in the timed region')
     return ap.parse_args()
 
 
@@ -357,6 +360,17 @@ def main():
     streams = []                        # created after the contexts (below): ROCm maps HIP streams to hardware queues in creation order
     dev_in = {k: torch.as_tensor(v).cuda() for k, v in inp.items()}
     names_in = ['audio'] + [k for k in ('video', 'flow') if k in dev_in]
+    # Video frames are resident the way the JPEG decoder produced them: uint8 (feeder.py reads .jpg; myutils.py:88-89 normalises with
+    # x / 255 - 0.5).  sagen_forward_u8 applies that normalisation on the device; the synthetic frames are exact images of uint8 values
+    # (checked here), so both entry points see the same pixels.  --float-frames keeps float32 frames (the general float entry point).
+    frames_note = 'float32 (x / 255 - 0.5 applied by the host), sagen_forward'
+    float_video = dev_in.get('video')
+    if 'video' in dev_in and not args.float_frames:
+        t = dev_in['video']
+        u8 = torch.round((t.double() + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
+        assert bool(((u8.double() / 255.0 - 0.5).float() == t).all()), 'synthetic frames are not exact images of uint8 values'
+        dev_in['video'] = u8
+        frames_note = 'uint8 as decoded (x / 255 - 0.5 applied on the device), sagen_forward_u8'
 
     def batch_inputs(b):                # device views of the windows of (global) batch b
         lo = (b * BATCH) % POOL
@@ -502,12 +516,26 @@ def main():
         torch.cuda.synchronize()
         extra['one_in_flight'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
                                   'note': 'strictly sequential forwards on one context (this rank x n_gpus), %d steps' % ks}
+        if float_video is not None and not args.float_frames:
+            af = [float_video[:BATCH] if k == 'video' else t for k, t in zip(names_in, a)]
+            net.inference_ops(*af, out=outs[0])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(ks):
+                j = i % NF
+                ctx = torch.cuda.stream(streams[j]) if NF > 1 else torch.cuda.stream(torch.cuda.current_stream())
+                with ctx:
+                    nets[j].inference_ops(*af, out=outs[j])
+            torch.cuda.synchronize()
+            extra['float_frames'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
+                                     'note': 'the same forward on float32 frames (the general float entry point sagen_forward: three-plane operand '
+                                             'split and six MFMA products in the stem as everywhere else), %d batches in flight, %d steps' % (NF, ks)}
         # H2D-inclusive: every batch starts in pinned host memory; copy (on the step's stream) + forward, NF in flight
         # frames travel as the uint8 the JPEG decoder produced (x/255 - 0.5 is applied on the device, bit-identical: the synthetic
         # frames are exact images of uint8 values, checked here); audio (and flow, which is decoded to float) as fp32
         host = []
         for k, t in zip(names_in, a):
-            if k == 'video':
+            if k == 'video' and t.dtype != torch.uint8:
                 u8 = torch.round((t.double() + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
                 if bool(((u8.double() / 255.0 - 0.5).float() == t).all()):
                     t = u8
@@ -589,6 +617,7 @@ def main():
                                'windows/clips over ranks, no data-path collective; 1 metric all-reduce at the end',
                    'weights': 'random init (Xavier / BN identity), same replica on every rank',
                    'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics',
+                   'video_frames': frames_note if 'video' in dev_in else None,
                    'batches_in_flight': NF},
         'ranks': ranks,
         'step_latency_ms_event': {'median': round(float(np.median(step_ms)), 4), 'p10': round(step_ms[len(step_ms) // 10], 4),

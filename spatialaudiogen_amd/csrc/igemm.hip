@@ -293,7 +293,7 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; bool p3 = false; };
+struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; bool p3 = false; bool g = false; };
 static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
     {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
@@ -323,6 +323,8 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 16, "conv3p_kernel<128,64,64,32>", true, true, false, true},   {128, 128, 16, "conv3p_kernel<128,128,64,64>", true, true, false, true},
     {64, 64, 16, "conv3p_kernel<64,64,32,32>", true, true, false, true},
     {128, 64, 16, "conv3pp_kernel<0>", true, true, false, true},          {128, 64, 16, "conv3pp_kernel<1>", true, true, false, true},
+    {128, 64, 16, "conv3g_kernel<128,64,64,32,2>", true, false, false, true, true}, {64, 64, 16, "conv3g_kernel<64,64,32,32,2>", true, false, false, true, true},
+    {64, 128, 16, "conv3g_kernel<64,128,32,64,2>", true, false, false, true, true}, {128, 128, 16, "conv3g_kernel<128,128,64,64,1>", true, false, false, true, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -364,6 +366,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     if (kTiles[t].dw3 && !dw3_ok(d)) return false;
     if (kTiles[t].p3 && (d.xp3 == nullptr || d.splitk != 1)) return false;
     if (!kTiles[t].p3 && d.xp3 != nullptr && d.x == nullptr) return false;      // only the planes were provided
+    if (kTiles[t].g) return conv3g_ok(d);                                        // gathered operand tiles: any stride / tap set on the plane rows
     if (kTiles[t].p3) return true;                                               // (the producer's BN+ReLU is already in the planes)
     if (kTiles[t].s2 && !s2_ok(d)) return false;
     if ((d.in_scale || d.bn_in.acc) && !uniform_taps_for(d, bk)) return false;
@@ -386,6 +389,8 @@ IgemmTile igemm_pick_tile(const IgemmDesc& d) {
             if ((long)cdiv(np, 128) * cdiv(d.N, 64) >= want) return TILE_P3_128x64;
             return TILE_P3_64x64;
         }
+        if (d.xp3 != nullptr && !dw3_ok(d) && d.splitk == 1 && conv3g_ok(d))    // planes + any other geometry: gathered operand tiles
+            return blocks(TILE_P3G_128x64_K2) >= 256 + 128 ? TILE_P3G_128x64_K2 : TILE_P3G_64x64_K2;
         if (dw3_ok(d) && (!pro || uniform_taps_for(d, 16))) {                   // 3x3 stride 1: shared horizontal taps
             if (d.N <= 64) return blocks(TILE_B3DW_128x64) >= want ? TILE_B3DW_128x64 : TILE_B3DWM_64x64;
             if (blocks(TILE_B3DW_128x128) >= 256 + 128) return TILE_B3DW_128x128;
@@ -452,6 +457,7 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
+    if (kTiles[tile].g) return conv3g_dispatch(d, tile, s);
     if (kTiles[tile].p3) return conv3p_dispatch(d, tile, s);
     if (kTiles[tile].s2) return igemm3s2_dispatch(d, tile, s);
     if (kTiles[tile].split) return igemm3_dispatch(d, tile, s);

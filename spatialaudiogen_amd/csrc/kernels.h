@@ -99,6 +99,8 @@ enum IgemmTile {
     TILE_P3_128x64, TILE_P3_128x128, TILE_P3_64x64,
     // ... two phase-locked 4-wave teams per workgroup (conv3pp_kernel): two 128x64 tiles / the two K halves of one
     TILE_P3PP_PAIR, TILE_P3PP_SPLITK,
+    // bf16x3 for ANY strided / multi-tap conv over pre-split activation planes, operand tiles gathered by LDS-DMA (conv3g_kernel)
+    TILE_P3G_128x64_K2, TILE_P3G_64x64_K2, TILE_P3G_64x128_K2, TILE_P3G_128x128_K1,
     TILE_AUTO
 };
 
@@ -114,6 +116,8 @@ int igemm3_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // lau
 int igemm3dw_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3dw.hip)
 int igemm3s2_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3s2.hip)
 int conv3p_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3p.hip)
+int conv3g_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3g.hip)
+bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel can run (given planes)
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
 bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
@@ -173,6 +177,10 @@ int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W
 // of the raw output, and the 3x3/2 pool of the RAW output taken as max or min per channel by the sign of gamma; the elementwise
 // BN + ReLU then runs on the pooled tensor.  wp = the stem's packed filter + planes; pooled [B,56,112,64]; stats fp64 [2][64].
 int stempool_launch(const float* xpad, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
+// the stem for uint8 frames (stem8.hip): centred bf16 plane of the decoded frame, then conv + statistics + raw pool with one operand plane
+size_t stem8_plane_bytes(int B);
+int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s);
+int stem8pool_launch(const void* plane, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);

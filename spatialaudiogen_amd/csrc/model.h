@@ -99,6 +99,8 @@ struct sagen_ctx {
     bool materialize_mask = false;         // sagen_set_option("materialize_mask"): keep deconv1 -> mask as two kernels so that the logits exist
     bool mask_fused_last = false;          // the last forward ran the fused decoder tail: "separation/deconv1" holds no logits
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
+    bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); SAGEN_NO_P3G=1 disables
+    bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels
     size_t tws_floats = 0;
     float* tws = nullptr;
     std::map<std::string, Buf> tbufs;
@@ -468,7 +470,12 @@ struct Fwd {
         if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
-        if (c->video_u8 && scope == "video_encoder")
+        // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
+        const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode &&
+                           !(c->use_p3 && c->p3_from_stage <= 2);
+        if (fast8)
+            timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s); });
+        else if (c->video_u8 && scope == "video_encoder")
             timed("pad_u8_nhwc3to4_kernel", 0.0, [&] { return pad_u8_nhwc3to4_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         else
             timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
@@ -481,7 +488,15 @@ struct Fwd {
         {
             const std::string name = scope + "/conv1/conv";
             const bool fused = c->stem_fused && !c->tuning && !c->fp32_only && !(c->use_p3 && c->p3_from_stage <= 2);
-            if (fused) {
+            if (fast8) {
+                H = 112; W = 224;
+                layer = name + "+pool";
+                timed("stem8pool_kernel", 2.0 * B * H * W * 64 * 224, [&] {
+                    return stem8pool_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });
+                const BnRef bnf = bn_ref(li, name, (long)B * H * W);
+                layer = name + "/bn-relu";
+                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, c->p("rx0" + sfx), (long)B * 56 * 112, 64, s); });
+            } else if (fused) {
                 // conv + statistics + pool of the RAW output in one kernel (max or min per channel by the sign of gamma), then BN + ReLU on
                 // the pooled tensor in place: relu(bn(.)) is monotone per channel, so this IS maxpool(relu(bn(conv))) (stempool.hip)
                 H = 112; W = 224;
@@ -510,6 +525,7 @@ struct Fwd {
         float* xout = c->p("rx1" + sfx);
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};
+        bool x_in_planes = c->use_p3 && c->p3_from_stage <= 2;        // p3_maxpool wrote the pooled tensor as planes (neither fused stem runs then)
         for (int st = 0; st < 4; ++st) {
             const int cout = couts[st];
             for (int unit = 1; unit <= 2; ++unit) {
@@ -518,21 +534,28 @@ struct Fwd {
                 const int stride = first ? 2 : 1;
                 int Ho = 0, Wo = 0;
                 const float* shortcut = xin;
-                if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
-                    IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
-                                            cout, c->p("rsc" + sfx), cout, Ho, Wo);
-                    layer = pfx + "/shortcut";
-                    gemm(d, 1, false);
-                    shortcut = c->p("rsc" + sfx);
-                }
                 // Pre-split planes pay where the tensors are small next to the contraction: per residual block the plane-writing
                 // passes cost 77 / 38 / 27 / 22 us (stage 2..5, batch 32) against ~30 / 15 / 8 / 5 us for the fp32 BN passes they
                 // replace, while conv3p saves ~19 us per conv at every stage (profiles/r02_*): stage 2 stays on igemm3dw.
                 const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage;
                 void* planes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;
-                // stride-1 conv_1: its input planes were written by the pool / the previous block's merge
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "",
-                        stride == 1 ? planes : nullptr);
+                // the block input as planes: written by the previous block's merge (x_in_planes) - stride-1 conv_1 (conv3p_kernel) and,
+                // since round 4, the stride-2 conv_1 + 1x1 shortcut of a stage's first block (conv3g_kernel: gathered operand tiles)
+                const void* in_planes = (p3_here && x_in_planes) ? planes : nullptr;
+                if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
+                    IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
+                                            cout, c->p("rsc" + sfx), cout, Ho, Wo);
+                    if (in_planes) {
+                        d.xp3 = in_planes;
+                        d.p3_np = B * H * (W + 1);
+                        d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
+                        d.xp3_bytes = (unsigned)p3_bytes(B, H, W, cin);
+                    }
+                    layer = pfx + "/shortcut";
+                    gemm(d, 1, false);
+                    shortcut = c->p("rsc" + sfx);
+                }
+                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "", in_planes);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
@@ -544,8 +567,11 @@ struct Fwd {
                     conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes);
                     const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                     layer = pfx + "/merge";
-                    const bool next_p3 = unit == 1;      // the next conv_1 is a stride-1 3x3 of this stage
+                    // the block output as planes when the next conv_1 reads planes: the stride-1 3x3 of this stage (unit 1), or the
+                    // stride-2 conv_1 + shortcut of the next stage's first block (conv3g_kernel)
+                    const bool next_p3 = unit == 1 || (c->use_p3g && st < 3);
                     timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s); });
+                    x_in_planes = next_p3;
                     ++li;
                     std::swap(xin, xout);
                     H = Ho; W = Wo; cin = cout;
@@ -585,6 +611,7 @@ struct Fwd {
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 layer = pfx + "/merge";
                 timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
+                x_in_planes = false;
                 ++li;
                 std::swap(xin, xout);
                 H = Ho; W = Wo; cin = cout;

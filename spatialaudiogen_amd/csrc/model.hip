@@ -36,6 +36,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     // fused stem + pool (stempool.hip): +0.8 % for a host that runs one forward at a time; with several batches in flight
     // (SAGEN_ONE_STREAM=1 hosts, bench.py) its one-workgroup-per-CU LDS footprint blocks co-residency and it is a wash (-0.3 %)
     c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
+    c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
+    c->use_p3g = c->use_p3 && getenv("SAGEN_NO_P3G") == nullptr;
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
@@ -536,6 +538,7 @@ int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32
 int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     const std::string n = name;
     if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
+    if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
     return fail(SAGEN_ERR_UNSUPPORTED, "sagen_set_option: unknown option %s", name);
 }
 

@@ -271,8 +271,13 @@ class SptAudioGen(object):
         out = self.inference_ops(audio, video, flow)            # validates / stages the inputs, creates the ctx
         B = out.shape[0]
         ctx = self.context_for(B)
-        to_dev = lambda t, tail: None if t is None else torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t).to(
-            device=self.device, dtype=torch.float32).contiguous()
+        def to_dev(t, tail):
+            if t is None:
+                return None
+            t = torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t).to(device=self.device)
+            if t.dtype == torch.uint8:                          # decoded frames: the tuner times the general kernels on the feeder's float frames
+                t = (t.double() / 255.0 - 0.5)
+            return t.to(dtype=torch.float32).contiguous()
         a, v, f = to_dev(audio, None), to_dev(video if VIDEO in self.encoders else None, None), to_dev(flow if FLOW in self.encoders else None, None)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None

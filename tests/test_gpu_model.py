@@ -222,6 +222,42 @@ def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
 
 
+def test_stride2_block_inputs_run_on_the_plane_fed_gather_kernel(T):
+    """The first block of ResNet stages 4 and 5: the merge of the previous stage also writes the block output as bf16x3 planes and
+    the 3x3 stride-2 conv_1 + the 1x1 stride-2 shortcut read THEM (conv3g_kernel: LDS-DMA gather -> MFMA, no operand split in the K
+    loop).  The shape heuristic must pick it, the result must hold the usual bars, and it must equal the igemm3_kernel route
+    (SAGEN_NO_P3G semantics, pinned here through the plan) to rounding."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    B = 3
+    P = init_weights(variable_specs(enc), seed=12, mode='test')
+    inp = synth_inputs(B, enc, seed=41)
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+    check_out(got, ref)
+    trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    assert rel_rms_err(trunk, orc.ends['video_encoder/conv5_2']) < 1e-4
+    net.profile_enable(B, True)
+    net.inference_ops(inp['audio'], inp['video'])
+    rows = net.profile_report(B)
+    net.profile_enable(B, False)
+    used = {layer: k for k, layer, us, fl in rows}
+    for layer in ('video_encoder/conv4_1/conv_1', 'video_encoder/conv4_1/shortcut', 'video_encoder/conv5_1/conv_1', 'video_encoder/conv5_1/shortcut'):
+        assert used[layer].startswith('conv3g_kernel'), (layer, used[layer])
+    assert used['video_encoder/conv3_1/conv_1'].startswith('igemm3_kernel')          # stage 2 keeps fp32 activations: no planes to read
+    # the same forward with those four layers pinned to the register-staged kernel
+    names = SptAudioGen.tile_names()
+    t3 = names.index('igemm3_kernel<64,64,32,32,1>')
+    for layer in ('video_encoder/conv4_1/conv_1', 'video_encoder/conv4_1/shortcut', 'video_encoder/conv5_1/conv_1', 'video_encoder/conv5_1/shortcut'):
+        net.plan_set(B, layer, t3, 1)
+    other = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+    check_out(other, ref)
+    assert rel_rms_err(got, other) < 1e-5
+
+
 def test_full_benchmark_batch_against_the_independent_cpu_reference(T):
     """BASELINE configs[1] at its real size (32 windows, audio + video): the heuristic launch plan AND the autotuned plan
     against oracle/torch_ref.py in fp64 (an implementation independent of both the numpy oracle and the HIP code).
@@ -243,22 +279,71 @@ def test_full_benchmark_batch_against_the_independent_cpu_reference(T):
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
 
 
-def test_uint8_video_entry_point_is_bit_identical(T):
-    """sagen_forward_u8: frames as uint8, x/255 - 0.5 (myutils.py:88-89) fused into the device-side pad pass - the output must equal,
-    bit for bit, the forward on the float32 frames the feeder would have produced (double-precision divide, one rounding)."""
+def test_uint8_video_entry_point(T):
+    """sagen_forward_u8: frames as the uint8 the decoder produced.
+    (a) general kernels (sagen_set_option 'u8_fast_stem' = 0): x/255 - 0.5 (myutils.py:88-89) fused into the device-side pad pass -
+        bit for bit the forward on the float32 frames the feeder would have produced (double-precision divide, one rounding);
+    (b) default: the one-operand-plane stem (stem8.hip: u - 128 is exact in bf16, three MFMA products instead of six, conv + raw pool
+        + statistics in one kernel).  Not bit-identical - it convolves the EXACT x where the float path convolves the rounded float32
+        x - but fp32-equivalent: against the fp64 oracle the same bar as every forward, and within 1e-5 (relative RMS) of (a)."""
     from spatialaudiogen_amd.model import SptAudioGen
     enc = ['audio', 'video']
+    B = 3
     P = init_weights(variable_specs(enc), seed=2, mode='test')
-    inp = synth_inputs(3, enc, seed=77)
+    inp = synth_inputs(B, enc, seed=77)
     r = np.random.Generator(np.random.PCG64(5))
-    u8 = r.integers(0, 256, size=(3, 1, 224, 448, 3)).astype(np.uint8)
+    u8 = r.integers(0, 256, size=(B, 1, 224, 448, 3)).astype(np.uint8)
     f32 = (u8 / 255. - 0.5).astype(np.float32)                      # feeder.img_prep_fcn on the decoded frame
     net = SptAudioGen(1, encoders=enc, separation='unet_mask')
     net.load_variables(P)
     a = net.inference_ops(inp['audio'], f32).cpu().numpy()
+    net.set_option(B, 'u8_fast_stem', 0)
     b = net.inference_ops(inp['audio'], u8).cpu().numpy()
     c = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
     assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
+    net.set_option(B, 'u8_fast_stem', 1)
+    d = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
+    trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    assert not np.array_equal(a, d)                                 # (it really ran other kernels)
+    assert rel_rms_err(d, a) < 1e-5, rel_rms_err(d, a)
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(inp['audio'], P, video=f32)
+    check_out(d, ref)
+    assert rel_rms_err(trunk, orc.ends['video_encoder/conv5_2']) < 1e-4
+    assert rms(d - ref) <= 1.5 * rms(a - ref) + 1e-7, (rms(d - ref), rms(a - ref))      # no less accurate than the float-frame kernels
+
+
+@pytest.mark.parametrize('B', [1, 5, 32])
+def test_uint8_stem_geometry_and_negative_gammas(T, B):
+    """stem8pool_kernel on its own terms: image borders (the -0.5 padding IS x = 0), the partial last patch row / column, dummy MFMA
+    rows, batch sizes that leave persistent workgroups without work (B = 1: 112 patches for 256 workgroups) or give them several
+    (B = 32: 14 each), min-pooling for negative gammas and the gamma = 0 channel - the trunk output conv5_2 and the final output
+    against the oracle."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=8 + B, mode='test')
+    g = P['video_encoder/conv1/conv/bn/gamma'].copy()
+    g[1::2] *= -1.0
+    g[6] = 0.0
+    P['video_encoder/conv1/conv/bn/gamma'] = g
+    inp = synth_inputs(B, enc, seed=31 + B)
+    r = np.random.Generator(np.random.PCG64(B))
+    u8 = r.integers(0, 256, size=(B, 1, 224, 448, 3)).astype(np.uint8)
+    u8[:, :, :3] = 255; u8[:, :, -3:] = 0; u8[:, :, :, :3] = 0; u8[:, :, :, -3:] = 255          # loud borders: a padding fault shows
+    f32 = (u8 / 255. - 0.5).astype(np.float32)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
+    trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    if B <= 5:
+        orc = SptAudioGenOracle(encoders=enc)
+        ref = orc.inference_ops(inp['audio'], P, video=f32)
+        check_out(got, ref)
+        assert rel_rms_err(trunk, orc.ends['video_encoder/conv5_2']) < 1e-4
+    else:                                                           # full size: against the general kernels on the float frames
+        ref = net.inference_ops(inp['audio'], f32).cpu().numpy()
+        assert rel_rms_err(got, ref) < 1e-5
+        assert rel_rms_err(trunk, net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()) < 1e-5
 
 
 def test_fused_stem_pool_with_negative_gammas(T):
