@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
         const int slot = U / 6, rem = U - 6 * slot;
         const int pl = rem >> 1, half = rem & 1;
         const int m = m0 + slot;
-        a_base[j] = OOB; a_bad[j] = 0xffffffffu;
+        a_base[j] = 0; a_bad[j] = 0xffffffffu;
         if (inst < A_INST && m < d.M) {
             const unsigned row = __umulhi((unsigned)m, d.p3_magic_wp);                 // m / Wg = b*Hg + ho   (exact: conv3g_dispatch)
             const int wo = m - (int)row * d.Wg;
@@ -112,10 +112,13 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
     auto begin_tile = [&](char* dst) {               // branch-free: the K loop stays one basic block (selects, no scalar branches)
         i_tile = dst;
         i_dead = q_kt >= NKT ? OOB : 0u;           // past the K range (NKT % KS != 0): range-check zeros
-        // per-lane validity of the rows above / below the image under filter row q_th
+        // per-lane validity of the rows above / below the image under filter row q_th.  The tap displacement goes into the VECTOR
+        // offset: the buffer range check looks at the vector offset alone, and the origin pixel of a row under SAME padding may lie
+        // above the tensor (a "negative" offset that only the displacement makes valid) - the scalar offset carries the chunk only
+        const unsigned tapd = (unsigned)((q_th * d.tap_sh * Wp + q_tw * d.tap_sw) * 96);
 #pragma unroll
-        for (int j = 0; j < A_PW; ++j) a_cur[j] = ((a_bad[j] >> q_th) & 1u) ? OOB : a_base[j];
-        i_asoff = (unsigned)((q_th * d.tap_sh * Wp + q_tw * d.tap_sw) * 96) + (unsigned)q_ch * d.xp3_cstride;
+        for (int j = 0; j < A_PW; ++j) a_cur[j] = ((a_bad[j] >> q_th) & 1u) ? OOB : a_base[j] + tapd;
+        i_asoff = (unsigned)q_ch * d.xp3_cstride;
         i_bsoff = (unsigned)q_kt * (unsigned)(d.N * 96);
         ++q_kt; ++q_ch;
         const int wrap_c = q_ch == nchunk ? 1 : 0;

@@ -99,7 +99,7 @@ struct sagen_ctx {
     bool materialize_mask = false;         // sagen_set_option("materialize_mask"): keep deconv1 -> mask as two kernels so that the logits exist
     bool mask_fused_last = false;          // the last forward ran the fused decoder tail: "separation/deconv1" holds no logits
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
-    bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); SAGEN_NO_P3G=1 disables
+    bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
     bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels
     size_t tws_floats = 0;
     float* tws = nullptr;
@@ -526,6 +526,7 @@ struct Fwd {
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};
         bool x_in_planes = c->use_p3 && c->p3_from_stage <= 2;        // p3_maxpool wrote the pooled tensor as planes (neither fused stem runs then)
+        bool x_fp32_valid = true;                                       // false: the previous merge wrote the block input as planes only
         for (int st = 0; st < 4; ++st) {
             const int cout = couts[st];
             for (int unit = 1; unit <= 2; ++unit) {
@@ -545,6 +546,7 @@ struct Fwd {
                 if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
                                             cout, c->p("rsc" + sfx), cout, Ho, Wo);
+                    if (!x_fp32_valid) d.x = nullptr;                   // the merge wrote this block input as planes only
                     if (in_planes) {
                         d.xp3 = in_planes;
                         d.p3_np = B * H * (W + 1);
@@ -555,7 +557,7 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "", in_planes);
+                conv_bn(x_fp32_valid ? xin : nullptr, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "", in_planes);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
@@ -569,9 +571,12 @@ struct Fwd {
                     layer = pfx + "/merge";
                     // the block output as planes when the next conv_1 reads planes: the stride-1 3x3 of this stage (unit 1), or the
                     // stride-2 conv_1 + shortcut of the next stage's first block (conv3g_kernel)
-                    const bool next_p3 = unit == 1 || (c->use_p3g && st < 3);
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s); });
+                    // ... whose consumers read nothing else: that block output is written as planes ONLY (hi + mid + lo IS the value)
+                    const bool to_next_stage = unit == 2 && c->use_p3g && st < 3;
+                    const bool next_p3 = unit == 1 || to_next_stage;
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, to_next_stage ? nullptr : xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s); });
                     x_in_planes = next_p3;
+                    x_fp32_valid = !to_next_stage;
                     ++li;
                     std::swap(xin, xout);
                     H = Ho; W = Wo; cin = cout;
@@ -610,8 +615,15 @@ struct Fwd {
                 }
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 layer = pfx + "/merge";
-                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
-                x_in_planes = false;
+                // the last block of a stage that keeps fp32 activations, in front of a stage on planes: its output feeds only the
+                // stride-2 conv_1 + shortcut of that stage's first block (conv3g_kernel) and is written as planes only
+                const bool planes_out = unit == 2 && st < 3 && c->use_p3g && c->use_p3 && st + 3 >= c->p3_from_stage;
+                if (planes_out)
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, nullptr, c->p("p3" + sfx), B, Ho, Wo, cout, s); });
+                else
+                    timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
+                x_in_planes = planes_out;
+                x_fp32_valid = !planes_out;
                 ++li;
                 std::swap(xin, xout);
                 H = Ho; W = Wo; cin = cout;

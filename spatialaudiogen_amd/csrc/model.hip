@@ -37,7 +37,9 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     // (SAGEN_ONE_STREAM=1 hosts, bench.py) its one-workgroup-per-CU LDS footprint blocks co-residency and it is a wash (-0.3 %)
     c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
     c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
-    c->use_p3g = c->use_p3 && getenv("SAGEN_NO_P3G") == nullptr;
+    // conv3g_kernel for the stride-2 conv_1 + shortcut of the first block of stages 3-5: measured (profiles/r04_layers_p3g.txt) no
+    // faster than igemm3_kernel on these small-M layers (56 / 58 / 72 us against 57 / 57 / 66; shortcuts equal) - off unless asked for
+    c->use_p3g = c->use_p3 && getenv("SAGEN_P3G") != nullptr;
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
@@ -539,6 +541,7 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     const std::string n = name;
     if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
+    if (n == "plane_gather") { c->use_p3g = c->use_p3 && value != 0; return SAGEN_OK; }
     return fail(SAGEN_ERR_UNSUPPORTED, "sagen_set_option: unknown option %s", name);
 }
 

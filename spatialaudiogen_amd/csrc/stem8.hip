@@ -11,12 +11,16 @@
 // float-frame kernels only by the rounding of x itself (the float path convolves the ROUNDED float32 x) and of the final scale.
 // The operand split disappears with it (the fragment of a lane is a 16-byte load of the plane: no VALU conversion at all).
 //
-// Structure (as stempool.hip): persistent workgroups of 8 waves, the whole filter (three planes, 86 KB) LDS-resident; a patch is
+// Structure: persistent workgroups of 8 waves, each owning HALF of the 64 output channels - its half of the filter (three planes,
+// 43 KB) stays LDS-resident and the raw tile staging is 32 KB, so TWO workgroups share a CU (78 KB each): while one pools its patch
+// the other multiplies (the first version - all 64 channels, 150 KB, one workgroup per CU - kept the matrix pipe 27 % busy: 133 us);
+// the batch statistics come straight from the accumulators (a 16-bit ownership mask per lane), not from LDS.  A patch is
 // 8 x 7 pooled pixels = 17 x 15 raw outputs (one halo row / column recomputed) = 255 of the 256 rows of 8 MFMA row tiles, one per
 // wave; K = 7 x 8 x 4 = 224 (seven taps down; seven + one zero tap across; three + one zero channel): 14 K steps of 16; K step ks of
-// raw pixel (r, c) is the 8 CONTIGUOUS bf16 of plane row 2r + ks/2 starting at pixel 2c + 4 (ks & 1) + 2g - every lane loads its own
-// fragment, seven steps ahead; raw tile -> LDS once, pooled with max or min per channel by the sign of gamma (relu(bn(.)) is
-// monotone per channel: stempool.hip), statistics over the 16 x 14 pixels the patch owns.
+// raw pixel (r, c) is the 8 CONTIGUOUS bf16 of plane row 2r + ks/2 starting at pixel 2c + 4 (ks & 1) + 2g.  The 39 x 36-pixel patch
+// of the plane a tile reads (11 KB) is staged through LDS - prefetched into registers a patch ahead, written once, fragments by
+// ds_read_b128 - in the space the raw tile occupies afterwards; raw tile -> LDS once, pooled with max or min per channel by the
+// sign of gamma (relu(bn(.)) is monotone per channel: stempool.hip), statistics over the 16 x 14 pixels the patch owns.
 #include "igemm3_common.h"
 
 namespace sagen {
@@ -26,11 +30,11 @@ constexpr int S8_RH = 2 * S8_PH + 1;           // raw rows per patch (17)
 constexpr int S8_RW = 2 * S8_PW + 1;           // raw cols per patch (15)
 constexpr int S8_M = S8_RH * S8_RW;            // 255
 constexpr int S8_UH = 229, S8_UW = 456;        // plane geometry: 2 + 224 + 3 rows, 2 + 448 + 6 pixels per row (row pitch 3648 B = 16 * 228)
-constexpr int S8_W_BYTES = 14 * 3 * 64 * 32;   // filter planes [K/16][plane][n][16] bf16
-constexpr int S8_CT_BYTES = 256 * 64 * 4;      // raw tile [256][64] fp32
+constexpr int S8_NH = 32;                      // output channels per workgroup: the two halves of the 64 run as separate workgroups
+constexpr int S8_W_BYTES = 14 * 3 * S8_NH * 32;   // this half's filter planes [K/16][plane][n][16] bf16 (43 KB)
+constexpr int S8_CT_BYTES = 256 * S8_NH * 4;   // raw tile [256][32] fp32
 constexpr int S8_THREADS = 512;
-constexpr int S8_D = 7;                        // operand loads in flight per lane (K steps ahead); must divide 14: the ring carries over to the next patch
-constexpr int S8_LDS = S8_W_BYTES + S8_CT_BYTES + 2 * 8 * 64 * 4 + 64 * 4;
+constexpr int S8_LDS = S8_W_BYTES + S8_CT_BYTES + 2 * 8 * S8_NH * 4 + S8_NH * 4;   // 77.9 KB: TWO workgroups per CU - one pools while the other multiplies
 
 size_t stem8_plane_bytes(int B) { return (size_t)B * S8_UH * S8_UW * 8; }
 
@@ -53,131 +57,158 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
     }
 }
 
-__global__ __launch_bounds__(S8_THREADS, 1) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
-                                                                  const __bf16* __restrict__ wplanes, const float* __restrict__ gamma,
+__global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
+                                                                  const char* __restrict__ wplanes, const float* __restrict__ gamma,
                                                                   float* __restrict__ pooled, double* __restrict__ stats, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wl = smem;
-    float* const ct = reinterpret_cast<float*>(smem + S8_W_BYTES);
-    float* const red = reinterpret_cast<float*>(smem + S8_W_BYTES + S8_CT_BYTES);                 // [2][8][64]
-    float* const cb = reinterpret_cast<float*>(smem + S8_W_BYTES + S8_CT_BYTES + 2 * 8 * 64 * 4); // [64]: (0.5 / 255) * sum_k W[n][k]
+    char* const pa = smem + S8_W_BYTES;                                                                 // the patch of the plane (K loop) ...
+    float* const ct = reinterpret_cast<float*>(smem + S8_W_BYTES);                                      // ... and the raw tile (epilogue) share this space
+    float* const red = reinterpret_cast<float*>(smem + S8_W_BYTES + S8_CT_BYTES);                       // [2][8][32]
+    float* const cb = reinterpret_cast<float*>(smem + S8_W_BYTES + S8_CT_BYTES + 2 * 8 * S8_NH * 4);    // [32]: (0.5 / 255) * sum_k W[n][k]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
+    const int nh = blockIdx.x & 1;                   // which 32 of the 64 channels
+    const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
 
-    {   // the filter planes, once
-        const f32x4* src = reinterpret_cast<const f32x4*>(wplanes);
-        f32x4* dst = reinterpret_cast<f32x4*>(wl);
-        for (int i = tid; i < S8_W_BYTES / 16; i += S8_THREADS) dst[i] = src[i];
+    // this half's filter planes, once: global row ((ks*3 + pl)*64 + nh*32 + n) -> LDS row ((ks*3 + pl)*32 + n), 32 B each
+    for (int i = tid; i < S8_W_BYTES / 16; i += S8_THREADS) {
+        const int row = i >> 1, hf = i & 1;
+        const int kp = row >> 5, n = row & 31;
+        reinterpret_cast<f32x4*>(wl)[i] = *reinterpret_cast<const f32x4*>(wplanes + ((long)(kp * 64 + nh * 32 + n) * 32 + 16 * hf));
     }
-    if (tid < 64) {
+    if (tid < S8_NH) {
         double s = 0.0;
-        for (int k = 0; k < 224; ++k) s += (double)wf32[tid * 224 + k];
+        for (int k = 0; k < 224; ++k) s += (double)wf32[(nh * S8_NH + tid) * 224 + k];
         cb[tid] = (float)(s * (0.5 / 255.0));
     }
-    const int pch4 = tid & 15;
+    const int pch4 = tid & 7;                        // pooling: this thread's 4 channels, max or min per channel
     bool use_min[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) use_min[k] = gamma[4 * pch4 + k] < 0.f;
-    const int sch = tid & 63, spart = tid >> 6;
+    for (int k = 0; k < 4; ++k) use_min[k] = gamma[nh * S8_NH + 4 * pch4 + k] < 0.f;
+    // statistics straight from the accumulators: which of this lane's 16 tile rows are pixels the patch OWNS (16 x 14 of the 17 x 15;
+    // the halo row / column belongs to the neighbour) - the same for every patch
+    unsigned own = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+        const int r = m / S8_RW, c = m - r * S8_RW;
+        if (m < S8_M && r < 2 * S8_PH && c < 2 * S8_PW) own |= 1u << e;
+    }
     float ssum = 0.f, ssq = 0.f;
     __syncthreads();
-    const float cb0 = cb[li], cb1 = cb[32 + li];
+    const float cbl = cb[li];
 
+    // The patch of the plane a tile needs - 39 rows x 36 pixels x 8 B = 11 KB - goes through LDS: every input pixel is fetched from
+    // global memory ONCE per workgroup (each is used by ~10 (row, tap) pairs: with per-lane fragment loads straight from global
+    // memory the kernel was bound by the vector-memory pipe, 133 / 95 us), as 702 chunks of 16 B, one or two per thread, prefetched
+    // into registers a whole patch ahead.
     const int npatch = B * 7 * 16;
-    // byte address of this lane's raw pixel (row `li` of the wave's MFMA tile) in patch `patch`, K step 0
-    auto pixel_base = [&](int patch) {
+    constexpr int PROWS = 2 * (S8_RH - 1) + 7, PCH = (2 * (S8_RW - 1) + 8) / 2;     // 39 rows x 18 chunks (36 pixels)
+    constexpr int NCHUNK = PROWS * PCH;                                             // 702
+    static_assert(NCHUNK <= 2 * S8_THREADS && PROWS * PCH * 16 <= S8_CT_BYTES, "patch staging");
+    const int ck0 = tid, ck1 = tid + S8_THREADS;
+    const int cr0 = ck0 / PCH, cc0 = ck0 - cr0 * PCH, cr1 = ck1 / PCH, cc1 = ck1 - cr1 * PCH;
+    auto patch_src = [&](int patch, int crow, int ccol) {
         const int b = patch / 112, rem = patch - b * 112;
         const int pr = rem >> 4, pc = rem & 15;
+        const int row = min(2 * 16 * pr + crow, S8_UH - 1);       // (rows past the plane only feed the raw row below the image, which is never pooled)
+        return plane + (((long)b * S8_UH + row) * S8_UW + 2 * 14 * pc) * 8 + ccol * 16;
+    };
+    f32x4 ld0 = f32x4{0.f, 0.f, 0.f, 0.f}, ld1 = ld0;
+    if (wg < npatch) {
+        ld0 = *reinterpret_cast<const f32x4*>(patch_src(wg, cr0, cc0));
+        if (ck1 < NCHUNK) ld1 = *reinterpret_cast<const f32x4*>(patch_src(wg, cr1, cc1));
+    }
+    // this lane's raw pixel (row `li` of the wave's MFMA tile): byte offset of its K-step-0 fragment inside the LDS patch
+    int aoff;
+    {
         const int m = wave * 32 + li;
         int r = m / S8_RW, c = m - r * S8_RW;
-        if (m >= S8_M || 16 * pr + r >= 112 || 14 * pc + c >= 224) { r = 0; c = 0; }      // dummy / outside the image: a valid address, dropped later
-        return plane + (((long)b * S8_UH + 2 * (16 * pr + r)) * S8_UW + 2 * (14 * pc + c)) * 8 + 16 * g;
-    };
-    auto kofs = [](int ks) { return ((ks >> 1) * S8_UW + (ks & 1) * 4) * 8; };
-    // operand loads run S8_D K steps ahead of the MFMAs (step s of a patch lives in q[s % S8_D]); the first steps of the next patch
-    // fly under the current patch's epilogue
-    static_assert(14 % S8_D == 0, "the prefetch ring must close over a patch");
-    bf16x8 q[S8_D];
-    const char* abase = blockIdx.x < npatch ? pixel_base(blockIdx.x) : plane;
-#pragma unroll
-    for (int k = 0; k < S8_D; ++k) q[k] = *reinterpret_cast<const bf16x8*>(abase + kofs(k));
-    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        if (m >= S8_M) { r = 0; c = 0; }                          // the 256th row: any valid address, dropped later
+        aoff = ((2 * r) * (2 * PCH) + 2 * c + 2 * g) * 8;
+    }
+    for (int patch = wg; patch < npatch; patch += nwg) {
         const int b = patch / 112, rem = patch - b * 112;
         const int pr = rem >> 4, pc = rem & 15;
         const int R0 = 16 * pr, C0 = 14 * pc;
-        const int next_patch = patch + gridDim.x;
-        const char* nbase = next_patch < npatch ? pixel_base(next_patch) : abase;
-        f32x16 acc[2];
+        reinterpret_cast<f32x4*>(pa)[ck0] = ld0;
+        if (ck1 < NCHUNK) reinterpret_cast<f32x4*>(pa)[ck1] = ld1;
+        __syncthreads();
+        const int next_patch = patch + nwg;
+        if (next_patch < npatch) {                                // flies under this patch's K loop and epilogue
+            ld0 = *reinterpret_cast<const f32x4*>(patch_src(next_patch, cr0, cc0));
+            if (ck1 < NCHUNK) ld1 = *reinterpret_cast<const f32x4*>(patch_src(next_patch, cr1, cc1));
+        }
+        f32x16 acc[2];                               // no accumulator twice in a row
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
-            const bf16x8 fa = q[ks % S8_D];
-            q[ks % S8_D] = *reinterpret_cast<const bf16x8*>(ks + S8_D < 14 ? abase + kofs(ks + S8_D) : nbase + kofs(ks + S8_D - 14));
-            bf16x8 fb[3][2];
+            // K step ks of raw pixel (r, c): the 8 bf16 at patch row 2r + ks/2, pixels 2c + 4 (ks & 1) + 2g, +1
+            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + aoff + ((ks >> 1) * (2 * PCH) + (ks & 1) * 4) * 8);
+            bf16x8 fb[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    fb[pl][j] = *reinterpret_cast<const bf16x8*>(wl + ((ks * 3 + pl) * 64 + j * 32 + li) * 32 + 16 * g);
-#pragma unroll
-            for (int pl = 2; pl >= 0; --pl)                     // u' x W_lo, x W_mid, x W_hi; the two accumulators alternate
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[pl][j], acc[j], 0, 0, 0);
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + ((ks * 3 + pl) * S8_NH + li) * 32 + 16 * g);
+            const int a = ks & 1;                    // u' x W_lo, x W_mid, x W_hi on accumulators a, a^1, a | a^1, a, a^1 | ...
+            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[2], acc[a], 0, 0, 0);
+            acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[1], acc[a ^ 1], 0, 0, 0);
+            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0], acc[a], 0, 0, 0);
         }
-        abase = nbase;
-        // raw output = acc / 255 + (0.5 / 255) sum(W)  -> LDS [pixel][64].  C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        __syncthreads();                       // every wave is done with the patch: its space becomes the raw tile
+        // raw output = acc / 255 + (0.5 / 255) sum(W) -> LDS [pixel][32] + this lane's share of the statistics.
+        // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            float* row = ct + (wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * 64;
-            row[li] = fmaf(acc[0][e], 1.f / 255.f, cb0);
-            row[32 + li] = fmaf(acc[1][e], 1.f / 255.f, cb1);
+            const float v = fmaf(acc[0][e] + acc[1][e], 1.f / 255.f, cbl);
+            ct[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * S8_NH + li] = v;
+            const float vo = ((own >> e) & 1u) ? v : 0.f;
+            ssum += vo;
+            ssq = fmaf(vo, vo, ssq);
         }
         __syncthreads();
-        // pool 3x3 / 2 (TF SAME: nothing before, one row / column after -> clipped at the image edge)
-        for (int p = tid >> 4; p < S8_PH * S8_PW; p += S8_THREADS / 16) {
+        // pool 3x3 / 2 (TF SAME: nothing before, one row / column after -> clipped at the image edge): one item per thread
+        if (tid < S8_PH * S8_PW * 8) {
+            const int p = tid >> 3;
             const int pr_l = p / S8_PW, pc_l = p - pr_l * S8_PW;
-            float4 ext;
-            bool first = true;
+            float4 v[9];
 #pragma unroll
-            for (int dr = 0; dr < 3; ++dr) {
-                if (R0 + 2 * pr_l + dr >= 112) continue;
+            for (int dr = 0; dr < 3; ++dr)
 #pragma unroll
                 for (int dc = 0; dc < 3; ++dc) {
-                    if (C0 + 2 * pc_l + dc >= 224) continue;
-                    const float4 v = *reinterpret_cast<const float4*>(ct + ((2 * pr_l + dr) * S8_RW + 2 * pc_l + dc) * 64 + 4 * pch4);
-                    if (first) { ext = v; first = false; }
-                    else {
-                        ext.x = use_min[0] ? fminf(ext.x, v.x) : fmaxf(ext.x, v.x); ext.y = use_min[1] ? fminf(ext.y, v.y) : fmaxf(ext.y, v.y);
-                        ext.z = use_min[2] ? fminf(ext.z, v.z) : fmaxf(ext.z, v.z); ext.w = use_min[3] ? fminf(ext.w, v.w) : fmaxf(ext.w, v.w);
-                    }
+                    // (rows / columns past the image edge are clamped to the window's first row / column: max / min is unchanged by a duplicate)
+                    const int rr = (R0 + 2 * pr_l + dr >= 112) ? 2 * pr_l : 2 * pr_l + dr;
+                    const int cc = (C0 + 2 * pc_l + dc >= 224) ? 2 * pc_l : 2 * pc_l + dc;
+                    v[dr * 3 + dc] = *reinterpret_cast<const float4*>(ct + (rr * S8_RW + cc) * S8_NH + 4 * pch4);
                 }
+            float4 ext = v[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) {
+                ext.x = use_min[0] ? fminf(ext.x, v[k].x) : fmaxf(ext.x, v[k].x); ext.y = use_min[1] ? fminf(ext.y, v[k].y) : fmaxf(ext.y, v[k].y);
+                ext.z = use_min[2] ? fminf(ext.z, v[k].z) : fmaxf(ext.z, v[k].z); ext.w = use_min[3] ? fminf(ext.w, v[k].w) : fmaxf(ext.w, v[k].w);
             }
-            *reinterpret_cast<float4*>(pooled + (((long)b * 56 + 8 * pr + pr_l) * 112 + 7 * pc + pc_l) * 64 + 4 * pch4) = ext;
+            *reinterpret_cast<float4*>(pooled + (((long)b * 56 + 8 * pr + pr_l) * 112 + 7 * pc + pc_l) * 64 + nh * S8_NH + 4 * pch4) = ext;
         }
-        // batch statistics over the 16 x 14 pixels this patch OWNS (the halo row / column belongs to the neighbour)
-        for (int qq = spart; qq < 16 * 14; qq += S8_THREADS / 64) {
-            const int r = qq / 14, cc = qq - r * 14;
-            const float v = ct[(r * S8_RW + cc) * 64 + sch];
-            ssum += v;
-            ssq = fmaf(v, v, ssq);
-        }
-        __syncthreads();                       // the tile is rewritten by the next patch
+        __syncthreads();                       // the raw tile is overwritten by the next patch
     }
-    red[(0 * 8 + spart) * 64 + sch] = ssum;
-    red[(1 * 8 + spart) * 64 + sch] = ssq;
+    // per-channel (sum, sumsq): the two lane halves of a wave hold the same channel, then the eight waves
+    ssum = wave_xor_add<32>(ssum);
+    ssq = wave_xor_add<32>(ssq);
+    if (g == 0) {
+        red[(0 * 8 + wave) * S8_NH + li] = ssum;
+        red[(1 * 8 + wave) * S8_NH + li] = ssq;
+    }
     __syncthreads();
-    if (tid < 128) {
-        const int which = tid >> 6, ch = tid & 63;
+    if (tid < 2 * S8_NH) {
+        const int which = tid >> 5, ch = tid & 31;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[(which * 8 + k) * 64 + ch];
-        atomicAdd(&stats[which * 64 + ch], (double)s);
+        for (int k = 0; k < 8; ++k) s += red[(which * 8 + k) * S8_NH + ch];
+        atomicAdd(&stats[which * 64 + nh * S8_NH + ch], (double)s);
     }
 }
 
@@ -199,9 +230,9 @@ int stem8pool_launch(const void* plane, const float* wp, const float* gamma, flo
         SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
-    const __bf16* planes = reinterpret_cast<const __bf16*>(wp + 64 * 224);
+    const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel, dim3(std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
+    hipLaunchKernelGGL(stem8pool_kernel, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
                        pooled, stats, B);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;

@@ -223,10 +223,10 @@ def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
 
 
 def test_stride2_block_inputs_run_on_the_plane_fed_gather_kernel(T):
-    """The first block of ResNet stages 4 and 5: the merge of the previous stage also writes the block output as bf16x3 planes and
-    the 3x3 stride-2 conv_1 + the 1x1 stride-2 shortcut read THEM (conv3g_kernel: LDS-DMA gather -> MFMA, no operand split in the K
-    loop).  The shape heuristic must pick it, the result must hold the usual bars, and it must equal the igemm3_kernel route
-    (SAGEN_NO_P3G semantics, pinned here through the plan) to rounding."""
+    """The first block of ResNet stages 3, 4 and 5: the last merge of the previous stage writes its block output as bf16x3 planes
+    (and nothing else) and the 3x3 stride-2 conv_1 + the 1x1 stride-2 shortcut read THEM (conv3g_kernel: LDS-DMA gather -> MFMA, no
+    operand split in the K loop).  With the option on the shape heuristic must pick it, the result must hold the usual bars, and it must equal the
+    register-staged route (sagen_set_option 'plane_gather' = 0: fp32 block outputs, igemm3_kernel) to rounding."""
     from spatialaudiogen_amd.model import SptAudioGen
     enc = ['audio', 'video']
     B = 3
@@ -236,26 +236,32 @@ def test_stride2_block_inputs_run_on_the_plane_fed_gather_kernel(T):
     ref = orc.inference_ops(inp['audio'], P, video=inp['video'])
     net = SptAudioGen(1, encoders=enc, separation='unet_mask')
     net.load_variables(P)
+    net.inference_ops(inp['audio'], inp['video'])
+    net.set_option(B, 'plane_gather', 1)            # (opt-in: measured no faster than igemm3_kernel on these small-M layers)
     got = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
     check_out(got, ref)
     trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
     assert rel_rms_err(trunk, orc.ends['video_encoder/conv5_2']) < 1e-4
-    net.profile_enable(B, True)
-    net.inference_ops(inp['audio'], inp['video'])
-    rows = net.profile_report(B)
-    net.profile_enable(B, False)
-    used = {layer: k for k, layer, us, fl in rows}
-    for layer in ('video_encoder/conv4_1/conv_1', 'video_encoder/conv4_1/shortcut', 'video_encoder/conv5_1/conv_1', 'video_encoder/conv5_1/shortcut'):
+    stride2 = ['video_encoder/conv%d_1/%s' % (st, nm) for st in (3, 4, 5) for nm in ('conv_1', 'shortcut')]
+
+    def kernels_used():
+        net.profile_enable(B, True)
+        net.inference_ops(inp['audio'], inp['video'])
+        rows = net.profile_report(B)
+        net.profile_enable(B, False)
+        return {layer: k for k, layer, us, fl in rows}
+    used = kernels_used()
+    for layer in stride2:
         assert used[layer].startswith('conv3g_kernel'), (layer, used[layer])
-    assert used['video_encoder/conv3_1/conv_1'].startswith('igemm3_kernel')          # stage 2 keeps fp32 activations: no planes to read
-    # the same forward with those four layers pinned to the register-staged kernel
-    names = SptAudioGen.tile_names()
-    t3 = names.index('igemm3_kernel<64,64,32,32,1>')
-    for layer in ('video_encoder/conv4_1/conv_1', 'video_encoder/conv4_1/shortcut', 'video_encoder/conv5_1/conv_1', 'video_encoder/conv5_1/shortcut'):
-        net.plan_set(B, layer, t3, 1)
+    net.set_option(B, 'plane_gather', 0)
     other = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+    used = kernels_used()
+    for layer in stride2:
+        assert used[layer].startswith('igemm3_kernel'), (layer, used[layer])
     check_out(other, ref)
     assert rel_rms_err(got, other) < 1e-5
+    net.set_option(B, 'plane_gather', 1)
+    assert np.array_equal(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), got)
 
 
 def test_full_benchmark_batch_against_the_independent_cpu_reference(T):

@@ -11,6 +11,8 @@ inp = synth_inputs(B, enc, seed=1234)
 net = SptAudioGen(1, encoders=enc, separation='unet_mask')
 net.load_variables(P)
 a = torch.as_tensor(inp['audio']).cuda(); v = torch.as_tensor(inp['video']).cuda() if 'video' in inp else None
+if v is not None and os.environ.get('U8', '1') == '1':        # frames as decoded (uint8): the default entry point of deploy / evaluate / bench
+    v = torch.round((v.double() + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
 f = torch.as_tensor(inp['flow']).cuda() if 'flow' in inp else None
 for _ in range(3): net.inference_ops(a, v, f)
 if os.environ.get('TUNE', '1') == '1':
