@@ -1,0 +1,380 @@
+// conv3h_kernel: conv3p_kernel (dense 3x3 stride-1 SAME convolution over pre-split activation planes; reference op tf.nn.convolution,
+// core.py:206, as the ResNet18 trunk uses it: resnet.py:141-190 / 215-235) on TWO fp16 planes per operand instead of three bf16
+// planes - three matrix products per fp32 product instead of six, 4 instead of 6 bytes per operand element.
+//
+// Arithmetic ("fp16x2").  An fp32 value v with |v| in fp16's NORMAL range splits as
+//     hi = rne_f16(v),  lo = rne_f16(v - hi)            (v - hi is exact in fp32)
+// into 11 + 11 significant bits plus the sign of the residual: |v - hi - lo| <= 2^-23.5 |v| - fp32's own resolution.  The product
+// a*b is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped lo*lo is below 2^-22
+// relative.  bf16 was chosen for the general kernels because it has fp32's EXPONENT range; fp16 does not (normal range 6.1e-5 ..
+// 65504, below that the absolute resolution stays at 2^-25 - v_mfma honours fp16 subnormals: tools/probe/f16_denorm.hip), so this
+// kernel is used only where the operands' magnitudes are known, and both are scaled into the middle of that range by exact powers
+// of two:
+//   * filters: per layer, 2^kw with max |w| 2^kw in [512, 1024) (h2_filter_pack: absmax on the device, planes [K/16][2][N][16]);
+//   * activations: the plane-writing pass (p3.hip, format 1) knows the batch-norm that produced them - relu(gamma x^ + beta) is bounded
+//     by |beta| + 8 |gamma| except for > 8 sigma outliers - and scales by 2^ka with (max_c |beta_c| + 8 |gamma_c|) 2^ka in [512, 1024),
+//     saturating at +-65000 (an outlier 64 times the 8-sigma bound); exact zeros (ReLU) stay exact.
+// The epilogue multiplies the tile by 2^-(ka + kw) (exact).  Measured against the fp64 oracle this path is as accurate as the
+// six-product bf16x3 path (fewer products = fewer fp32 accumulation roundings): DESIGN.md 3.2, profiles/r04_accuracy_modes.jsonl.
+//
+// Everything else is conv3p_kernel: P layout [Cin/16][NP][2 planes][16 ch] fp16 (64 B per pixel and chunk), NP = B*H*(W+1) with one
+// zero pixel closing every image row; K order (dh, chunk, dw): per group the workgroup stages the activation tile once (with one
+// halo pixel either side) and the three dw filter tiles by LDS-DMA; fragments by ds_read_b128; two-stage ring; one barrier per
+// group.  The LDS image of a slot is 64 B = four 16-byte units (plane, half); unit u of slot s sits at position u ^ ((s >> 2) & 3):
+// the 16 lanes of one ds_read_b128 group then cover all 64 banks for ANY slot base (with 96-byte slots conv3p_kernel needs only the
+// half swap).  40 KiB of LDS per 128x64 workgroup: three per CU.
+#include "igemm3_common.h"
+
+namespace sagen {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int conv3h_lds(int BM, int BN) { return 2 * (BM * 64 + 3 * 2 * BN * 32) + 256; }
+constexpr int conv3h_wgs_per_cu(int BM, int BN) { return 160 * 1024 / conv3h_lds(BM, BN) >= 3 ? 3 : (160 * 1024 / conv3h_lds(BM, BN) >= 2 ? 2 : 1); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(const IgemmDesc d) {
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
+    static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
+    constexpr int BME = BM - 2;                            // rows the workgroup owns: the image is BM slots = BME outputs + one halo pixel either side
+    constexpr int A_INST = BM / 16;                        // LDS-DMA wave-instructions (1 KiB) of one activation stage: BM slots x 64 B
+    constexpr int B_IPT = BN / 16;                         // per tap: 2 planes x BN rows x 32 B
+    constexpr int B_INST = 3 * B_IPT;
+    constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;
+    constexpr int A_BYTES = A_INST * 1024, B_BYTES = B_INST * 1024;
+    constexpr int ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int NM1 = 3 * MT * NT;                       // MFMAs per tap
+    constexpr int NMG = 3 * NM1;
+    constexpr int CNT_MAX = A_PW + B_PW;
+    static_assert(CNT_MAX <= NMG, "one DMA slot per MFMA slot at most");
+    constexpr int NF = 2 * (MT + NT);
+    constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
+    static_assert(WM % RPP == 0, "a wave row is a whole number of store passes");
+    constexpr int EPI_TILE = WM * BN * 4, EPI_DENSE = BM * 4, EPI_RED = 2 * RPP * BN * 4;
+    constexpr int SMEM_BYTES = 2 * ST_BYTES + 256;         // +256: fragment reads of the dropped rows
+    static_assert(EPI_TILE + EPI_DENSE + EPI_RED <= SMEM_BYTES, "epilogue staging must fit the ring");
+    static_assert(SMEM_BYTES == conv3h_lds(BM, BN), "occupancy bound uses the same footprint");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // ONE shared object (conv3p.hip)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int W = d.Win, H = d.Hin, Wp = W + 1, NP = d.p3_np;
+    const int nchunk = d.Cin >> 4;
+    const int G = 3 * nchunk;
+    const int nM = (NP + BME - 1) / BME, nN = (d.N + BN - 1) / BN;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.xp3, 0, d.xp3_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.wh2, 0, d.wh2_bytes, 0x00020000);
+
+    // block -> tile: XCD x owns M tiles [x*per, (x+1)*per) (vertically neighbouring tiles share input rows in one L2)
+    const int xcd = blockIdx.x & 7;
+    const int per = (nM + 7) >> 3;
+    const int t_run = blockIdx.x >> 3;
+    const int my_tiles = max(min((xcd + 1) * per, nM) - xcd * per, 0) * nN;
+    if (t_run >= my_tiles) return;
+    const int tq = t_run / nN;
+    const int m0 = (xcd * per + tq) * BME;                 // first PADDED pixel of the tile
+    const int n0 = (t_run - tq * nN) * BN;
+
+    // ---- per-lane DMA state: activation unit U = inst*64 + lane = (slot, position v); slot <-> padded pixel m0 - 1 + slot ----
+    unsigned a_v0[A_PW], a_v1[A_PW], a_v2[A_PW], a_cur[A_PW];      // per vertical tap dh = -1 / 0 / +1; the current one
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int inst = wave + 4 * j;
+        const int U = inst * 64 + lane;
+        const int slot = U >> 2, v = U & 3;
+        const int u = v ^ ((slot >> 2) & 3);               // which (plane, half) of the pixel lands at position v
+        const int p = m0 - 1 + slot;
+        unsigned bad = 7u;
+        if (inst < A_INST && p >= 0 && p < NP) {
+            const unsigned row = __umulhi((unsigned)p, d.p3_magic_wp);          // p / Wp  (exact: conv3h_dispatch)
+            const int h = (int)(row - __umulhi(row, d.p3_magic_h) * (unsigned)H);
+            bad = (h == 0 ? 1u : 0u) | (h == H - 1 ? 4u : 0u);
+        }
+        const int base = p * 64 + u * 16;
+        a_v0[j] = (bad & 1u) ? OOB : (unsigned)(base - Wp * 64);
+        a_v1[j] = (bad & 2u) ? OOB : (unsigned)base;
+        a_v2[j] = (bad & 4u) ? OOB : (unsigned)(base + Wp * 64);
+    }
+    // filter DMA lanes: per tap the image is [plane][BN rows][32 B]
+    unsigned b_voff[B_PW];
+    int b_tapoff[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int inst = wave + 4 * j;
+        b_tapoff[j] = __builtin_amdgcn_readfirstlane((inst / B_IPT) * nchunk * d.N * 64);
+        const int r = inst % B_IPT;
+        const int L = r * 64 + lane;
+        const int pl = L / (2 * BN), n = (L >> 1) % BN, half = L & 1;
+        b_voff[j] = (inst < B_INST && n0 + n < d.N) ? (unsigned)((pl * d.N + n0 + n) * 32 + 16 * (half ^ ((n >> 3) & 1))) : OOB;
+    }
+
+    // issue state (SGPRs): the group being issued
+    int q_dh = 0, q_ch = 0, cur_dh = -1;
+    unsigned i_asoff = 0, i_bsoff = 0;
+    char* i_stage = smem;
+    auto begin_issue = [&](int stage) {
+        i_stage = smem + stage * ST_BYTES;
+        if (q_dh != cur_dh) {
+            cur_dh = q_dh;
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j) a_cur[j] = q_dh == 0 ? a_v0[j] : (q_dh == 1 ? a_v1[j] : a_v2[j]);
+        }
+        i_asoff = (unsigned)q_ch * d.xp3_cstride;
+        i_bsoff = (unsigned)((q_dh * 3) * nchunk + q_ch) * (unsigned)(d.N * 64);
+        ++q_ch;
+        if (q_ch == nchunk) { q_ch = 0; ++q_dh; }
+    };
+    auto issue_one = [&](int s) {               // s = compile-time slot index: A slots first, then B slots
+        if (s < A_PW) {
+            const int inst = wave + 4 * s;
+            if (A_INST % 4 == 0 || inst < A_INST) dma16(x_rsrc, (float*)(i_stage + inst * 1024), a_cur[s], i_asoff);
+        } else {
+            const int j = s - A_PW;
+            const int inst = wave + 4 * j;
+            if (4 * (j + 1) <= B_INST || inst < B_INST)
+                dma16(w_rsrc, (float*)(i_stage + A_BYTES + inst * 1024), b_voff[j], i_bsoff + (unsigned)b_tapoff[j]);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- fragment addressing (bytes inside a stage): plane 0 at a_foff, plane 1 at a_foff ^ 32 ----
+    const int li = lane & 31, kk = lane >> 5;
+    int a_foff[3][MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int dwi = 0; dwi < 3; ++dwi) {
+            const int sl = wm * WM + i * 32 + li + dwi;              // output row r sits at slot r + 1; tap dw reads slot r + dw
+            a_foff[dwi][i] = sl * 64 + 16 * (kk ^ ((sl >> 2) & 3));
+        }
+    const int b_foff = A_BYTES + (wn * WN + li) * 32 + 16 * (kk ^ ((li >> 3) & 1));
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};             // lo*hi, hi*lo, hi*hi
+
+    int stage = 0;
+    begin_issue(0);
+#pragma unroll
+    for (int s = CNT_MAX - 1; s >= 0; --s) issue_one(s);            // filter tiles first
+
+    // one group: its 9*MT*NT MFMAs with the DMA of the next group (ISSUE) spread between them; every MFMA slot is fenced
+    // (conv3p.hip: the source order IS the schedule)
+    auto group = [&](auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        const char* st = smem + stage * ST_BYTES;
+        f16x8 fq[2][NF];                                             // [buffer][plane * (MT+NT) + (i | MT + j)]
+        auto load_frag = [&](int buf, int dwi, int f) {
+            const int pl = f / (MT + NT), r = f - pl * (MT + NT);
+            if (r < MT) fq[buf][f] = *reinterpret_cast<const f16x8*>(st + (a_foff[dwi][r] ^ (pl * 32)));
+            else fq[buf][f] = *reinterpret_cast<const f16x8*>(st + b_foff + (dwi * 2 + pl) * (BN * 32) + (r - MT) * 32 * 32);
+        };
+#pragma unroll
+        for (int f = 0; f < NF; ++f) load_frag(0, 0, f);
+#pragma unroll
+        for (int dwi = 0; dwi < 3; ++dwi) {
+            const int cb = dwi & 1;
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int k = (tt * MT + i) * NT + j;
+                        const int idx = dwi * NM1 + k;
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[cb][TA[tt] * (MT + NT) + i], fq[cb][TB[tt] * (MT + NT) + MT + j],
+                                                                           acc[i][j], 0, 0, 0);
+                        if (dwi < 2) {
+#pragma unroll
+                            for (int f = 0; f < NF; ++f)
+                                if (f * NM1 / NF == k) load_frag(cb ^ 1, dwi + 1, f);
+                        }
+#pragma unroll
+                        for (int s = 0; s < CNT_MAX; ++s)
+                            if (ISSUE && idx == s) issue_one(CNT_MAX - 1 - s);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage ^= 1;
+    };
+
+    for (int it = 0; it + 1 < G; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        begin_issue(stage ^ 1);
+        group(std::true_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    group(std::false_type{});
+
+    // ---- epilogue through the (now idle) ring: x 2^-(ka + kw), 16-byte row-contiguous stores, bias / ReLU, batch-norm statistics ----
+    const float osc = d.h2_a_inv[0] * d.h2_w_inv[0];
+    const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
+    lds_barrier();                                   // every wave is done with the last group's fragments
+    float* const tile = reinterpret_cast<float*>(smem);                              // [WM][BN]
+    int* const s_dense = reinterpret_cast<int*>(smem + EPI_TILE);                    // [BM] dense pixel index or -1
+    float* const red = reinterpret_cast<float*>(smem + EPI_TILE + EPI_DENSE);        // [2][RPP][BN]
+    for (int r = tid; r < BM; r += 256) {
+        const int p = m0 + r;
+        int dense = -1;
+        if (r < BME && p < NP) {
+            const int row = (int)__umulhi((unsigned)p, d.p3_magic_wp);   // p / Wp = b*H + h: one pad pixel per preceding row
+            if (p - row * Wp < W) dense = p - row;
+        }
+        s_dense[r] = dense;
+    }
+    const int c4 = tid % TPR, rg = tid / TPR;
+    const int n = n0 + 4 * c4;
+    const bool vec_ok = n + 3 < d.N && ldy_ok;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias) {
+        bias.x = n < d.N ? d.bias[n] : 0.f; bias.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
+        bias.z = n + 2 < d.N ? d.bias[n + 2] : 0.f; bias.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
+    }
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int part = 0; part < WAVES_M; ++part) {
+        if (part > 0) lds_barrier();                  // the staging rows are rewritten by the next wave row
+        if (wm == part) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)      // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+                        tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = acc[i][j][e] * osc;
+        }
+        lds_barrier();
+        int dn[NPASS];
+        float4 tv[NPASS];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) dn[k] = s_dense[part * WM + rg + k * RPP];
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) tv[k] = *reinterpret_cast<const float4*>(tile + (rg + k * RPP) * BN + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            if (dn[k] < 0) continue;
+            float4 v = tv[k];
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            if (d.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            float* dst = d.y + (long)dn[k] * d.ldy + n;
+            if (vec_ok) *reinterpret_cast<float4*>(dst) = v;
+            else {
+                if (n < d.N) dst[0] = v.x;
+                if (n + 1 < d.N) dst[1] = v.y;
+                if (n + 2 < d.N) dst[2] = v.z;
+                if (n + 3 < d.N) dst[3] = v.w;
+            }
+        }
+    }
+    if (d.stats != nullptr) {                 // per-channel (sum, sumsq) of the raw output -> fp64 accumulators [2][N]
+        *reinterpret_cast<float4*>(red + (0 * RPP + rg) * BN + 4 * c4) = cs;
+        *reinterpret_cast<float4*>(red + (1 * RPP + rg) * BN + 4 * c4) = cq;
+        lds_barrier();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int which = t / BN, col = t - which * BN;
+            if (n0 + col < d.N) {
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < RPP; ++g) sum += red[(which * RPP + g) * BN + col];
+                atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv3h(const IgemmDesc& d, hipStream_t s) {
+    const int per = (cdiv(d.p3_np, BM - 2) + 7) / 8;
+    const int grid = 8 * per * cdiv(d.N, BN);
+    hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), 0, s, d);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
+    IgemmDesc d = d_in;
+    if (!d.xp3 || d.p3_np <= 0 || d.xp3_fmt != 1) return fail(SAGEN_ERR_NULL, "conv3h: the fp16x2 activation planes are missing");
+    if (!d.wh2 || !d.h2_a_inv || !d.h2_w_inv) return fail(SAGEN_ERR_NULL, "conv3h: the fp16x2 filter planes / scales are missing");
+    if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: no split-K");
+    if ((long)(d.p3_np + 512) * (d.Win + 1) >= (1L << 32) || ((long)(d.p3_np + 512) / (d.Win + 1) + 1) * d.Hin >= (1L << 32))
+        return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: too many pixels for 32-bit index arithmetic");
+    if ((long)d.p3_np * 64 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)
+        return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: the activation planes exceed 2 GiB buffer addressing (use a smaller batch)");
+    d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)(d.Win + 1)) + 1u;
+    d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hin) + 1u;
+    switch (tile) {
+        case TILE_P3H_128x64: return launch_conv3h<128, 64, 64, 32>(d, s);
+        case TILE_P3H_128x128: return launch_conv3h<128, 128, 64, 64>(d, s);
+        case TILE_P3H_64x64: return launch_conv3h<64, 64, 32, 32>(d, s);
+        case TILE_P3H_256x64: return launch_conv3h<256, 64, 64, 64>(d, s);
+        default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: bad tile id %d", (int)tile);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// filter planes for conv3h_kernel: fp32 packed filter [N][Kpad] -> max |w| -> 2^kw -> fp16 (hi, lo) of w 2^kw, [Kpad/16][2][N][16]
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h2_absmax_kernel(const float* __restrict__ wp, long total, unsigned* __restrict__ amax_bits) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(wp[i]));
+    __shared__ unsigned s_m;
+    if (threadIdx.x == 0) s_m = 0u;
+    __syncthreads();
+    atomicMax(&s_m, __builtin_bit_cast(unsigned, m));            // non-negative floats order like their bit patterns
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax_bits, s_m);
+}
+
+// 2^k with bound * 2^k in [512, 1024) (k from the exponent field; bound == 0 or not finite -> 1)
+__device__ __forceinline__ float h2_scale_for(float bound) {
+    const unsigned b = __builtin_bit_cast(unsigned, bound);
+    const int e = (int)((b >> 23) & 0xff);
+    if (e == 0 || e == 255) return 1.f;
+    int k = 127 + 9 - e;                                         // bound in [2^(e-127), 2^(e-126)) -> bound 2^k in [512, 1024)
+    k = max(-60, min(60, k));
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+
+__global__ __launch_bounds__(256) void h2_filter_pack_kernel(const float* __restrict__ wp, long total, int N, int Kpad,
+                                                             const unsigned* __restrict__ amax_bits, _Float16* __restrict__ w2,
+                                                             float* __restrict__ w_inv) {
+    const float sc = h2_scale_for(__builtin_bit_cast(float, amax_bits[0]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) w_inv[0] = 1.f / sc;                // exact: a power of two
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long n = idx / Kpad;
+    const int k = (int)(idx - n * Kpad);
+    const float v = wp[idx] * sc;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    const long o = ((long)(k >> 4) * 2 * N + n) * 16 + (k & 15);          // plane 0 of K tile k/16
+    w2[o] = h;
+    w2[o + (long)N * 16] = l;
+}
+
+// wp: fp32 packed filter [N][Kpad]; w2: N*Kpad*2 fp16; scratch: one unsigned (zeroed here); w_inv: where 2^-kw is written
+int h2_filter_pack_launch(const float* wp, int N, int Kpad, void* w2, unsigned* scratch, float* w_inv, hipStream_t s) {
+    if (!wp || !w2 || !scratch || !w_inv) return fail(SAGEN_ERR_NULL, "h2_filter_pack: null argument");
+    const long total = (long)N * Kpad;
+    SAGEN_HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3((int)std::min<long>(cdiv(total, 256), 1024)), dim3(256), 0, s, wp, total, scratch);
+    hipLaunchKernelGGL(h2_filter_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, wp, total, N, Kpad, scratch,
+                       reinterpret_cast<_Float16*>(w2), w_inv);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+}  // namespace sagen

@@ -293,7 +293,7 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
     return SAGEN_OK;
 }
 
-struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; bool p3 = false; bool g = false; };
+struct TileCfg { int bm, bn, bk; const char* name; bool split = false; bool dw3 = false; bool s2 = false; bool p3 = false; bool g = false; bool h = false; };
 static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "igemm_kernel<128,128,64,64,3,16>"}, {128, 64, 16, "igemm_kernel<128,64,64,32,3,16>"},
     {256, 64, 16, "igemm_kernel<256,64,64,64,3,16>"},   {64, 64, 16, "igemm_kernel<64,64,32,32,3,16>"},
@@ -325,6 +325,8 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 16, "conv3pp_kernel<0>", true, true, false, true},          {128, 64, 16, "conv3pp_kernel<1>", true, true, false, true},
     {128, 64, 16, "conv3g_kernel<128,64,64,32,2>", true, false, false, true, true}, {64, 64, 16, "conv3g_kernel<64,64,32,32,2>", true, false, false, true, true},
     {64, 128, 16, "conv3g_kernel<64,128,32,64,2>", true, false, false, true, true}, {128, 128, 16, "conv3g_kernel<128,128,64,64,1>", true, false, false, true, true},
+    {128, 64, 16, "conv3h_kernel<128,64,64,32>", true, true, false, true, false, true},   {128, 128, 16, "conv3h_kernel<128,128,64,64>", true, true, false, true, false, true},
+    {64, 64, 16, "conv3h_kernel<64,64,32,32>", true, true, false, true, false, true},      {256, 64, 16, "conv3h_kernel<256,64,64,64>", true, true, false, true, false, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -365,6 +367,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     }
     if (kTiles[t].dw3 && !dw3_ok(d)) return false;
     if (kTiles[t].p3 && (d.xp3 == nullptr || d.splitk != 1)) return false;
+    if (kTiles[t].p3 && (kTiles[t].h ? (d.xp3_fmt != 1 || d.wh2 == nullptr) : d.xp3_fmt != 0)) return false;   // the planes' format decides the family
     if (!kTiles[t].p3 && d.xp3 != nullptr && d.x == nullptr) return false;      // only the planes were provided
     if (kTiles[t].g) return conv3g_ok(d);                                        // gathered operand tiles: any stride / tap set on the plane rows
     if (kTiles[t].p3) return true;                                               // (the producer's BN+ReLU is already in the planes)
@@ -383,6 +386,11 @@ IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     if (d.w_split && !fp32_only) {             // the bf16x3 kernels are the faster family wherever their planes exist
         const bool pro = d.in_scale != nullptr || d.bn_in.acc != nullptr;
         if (s2_ok(d)) return TILE_B3S2_128x64;                                  // the 7x7/2 stem
+        if (d.xp3 != nullptr && d.xp3_fmt == 1 && dw3_ok(d) && d.splitk == 1) {   // two fp16 planes: three products per multiply
+            const long np = d.p3_np;
+            if ((long)cdiv(np, 126) * cdiv(d.N, 64) >= 3 * 256) return TILE_P3H_128x64;
+            return TILE_P3H_64x64;
+        }
         if (d.xp3 != nullptr && dw3_ok(d) && d.splitk == 1) {                   // pre-split activation planes: LDS-DMA -> MFMA only
             const long np = d.p3_np;
             if (d.N <= 64) return cdiv(np, 128) >= want ? TILE_P3_128x64 : TILE_P3_64x64;
@@ -457,6 +465,7 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
+    if (kTiles[tile].h) return conv3h_dispatch(d, tile, s);
     if (kTiles[tile].g) return conv3g_dispatch(d, tile, s);
     if (kTiles[tile].p3) return conv3p_dispatch(d, tile, s);
     if (kTiles[tile].s2) return igemm3s2_dispatch(d, tile, s);

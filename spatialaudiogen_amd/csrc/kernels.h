@@ -62,6 +62,11 @@ struct IgemmDesc {
     const void* xp3 = nullptr;
     unsigned xp3_bytes = 0, xp3_cstride = 0;
     int p3_np = 0;
+    int xp3_fmt = 0;                  // 0: three bf16 planes (96 B per pixel and chunk); 1: two fp16 planes of v * 2^ka (64 B; conv3h.hip)
+    const void* wh2 = nullptr;        // conv3h_kernel: the filter as two fp16 planes of w * 2^kw, [Kpad/16][2][N][16]
+    unsigned wh2_bytes = 0;
+    const float* h2_a_inv = nullptr;  // device scalars 2^-ka (written by the plane producer) and 2^-kw (written by the filter pack)
+    const float* h2_w_inv = nullptr;
     unsigned p3_magic_wp = 0, p3_magic_h = 0;   // filled by conv3p_dispatch: floor(2^32 / d) + 1 for d = Win + 1, Hin (exact quotients by mul-hi)
     // Fused decoder tail (deconv1 of the mask decoder at inference, model.py:326-337 + 421-434): instead of the 32 mask logits of an
     // output pixel the epilogue writes E[c] = sum_j w[step_c][out_c][j] * sigmoid(logit_j + bias_j), c = (step lo/hi, output) -
@@ -101,6 +106,8 @@ enum IgemmTile {
     TILE_P3PP_PAIR, TILE_P3PP_SPLITK,
     // bf16x3 for ANY strided / multi-tap conv over pre-split activation planes, operand tiles gathered by LDS-DMA (conv3g_kernel)
     TILE_P3G_128x64_K2, TILE_P3G_64x64_K2, TILE_P3G_64x128_K2, TILE_P3G_128x128_K1,
+    // fp16x2 for dense 3x3 stride-1 SAME convs over TWO fp16 planes per operand: three products per multiply (conv3h_kernel)
+    TILE_P3H_128x64, TILE_P3H_128x128, TILE_P3H_64x64, TILE_P3H_256x64,
     TILE_AUTO
 };
 
@@ -117,6 +124,8 @@ int igemm3dw_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (ig
 int igemm3s2_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s); // (igemm3s2.hip)
 int conv3p_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3p.hip)
 int conv3g_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3g.hip)
+int conv3h_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3h.hip)
+int h2_filter_pack_launch(const float* wp, int N, int Kpad, void* w2, unsigned* scratch, float* w_inv, hipStream_t s);
 bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel can run (given planes)
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
 bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)
@@ -195,11 +204,20 @@ int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B,
 // -----------------------------------------------------------------------------------------
 size_t p3_bytes(int B, int H, int W, int C);
 // y = [relu](x*scale + shift [+ residual]) -> fp32 NHWC `y` (or null) and / or planes `p3` (or null)
+// fmt 0: three bf16 planes (conv3p / conv3g); fmt 1: two fp16 planes of v * 2^ka (conv3h.hip) - ka from the statistics in `h2`
+struct P3hScale {
+    float* a_inv = nullptr;             // out: 2^-ka
+    const float* res_bound = nullptr;   // in: bound of the residual tensor (identity shortcut), or null
+    const double* res_acc = nullptr;    // in: fp64 (sum, sumsq) [2][C] of the residual tensor (1x1 shortcut conv), or null
+    double res_inv_count = 0.0;
+    float* bound_out = nullptr;         // out: bound of the tensor written (null: not tracked)
+};
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
-                   float* y, void* p3, int B, int H, int W, int C, hipStream_t s);
+                   float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);
+size_t p3h_bytes(int B, int H, int W, int C);
 // 3x3/2 SAME max-pool of relu(bn(x)) -> fp32 NHWC `y` (or null) and planes `p3` (or null) of the pooled tensor
 int p3_maxpool_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, void* p3, int B, int H,
-                      int W, int C, hipStream_t s);
+                      int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);
 
 // -----------------------------------------------------------------------------------------
 // FFT family (fft.hip)

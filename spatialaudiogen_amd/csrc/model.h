@@ -99,6 +99,8 @@ struct sagen_ctx {
     bool materialize_mask = false;         // sagen_set_option("materialize_mask"): keep deconv1 -> mask as two kernels so that the logits exist
     bool mask_fused_last = false;          // the last forward ran the fused decoder tail: "separation/deconv1" holds no logits
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
+    bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
+    std::map<std::string, int> h2_slot;    // per layer: index of its 2^-kw in the "h2s" table
     bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
     bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels
     size_t tws_floats = 0;
@@ -431,6 +433,19 @@ struct Fwd {
         gemm(d);
     }
 
+    // fp16x2 planes (conv3h.hip) for this forward?  (inference only: the training step keeps the bf16x3 planes its backward was verified with)
+    bool h2() const { return c->use_h2 && c->use_p3 && !c->train_mode && !c->fp32_only; }
+    int p3_fmt() const { return h2() ? 1 : 0; }
+    float* h2_a_inv() { return c->p("h2s") + (sfx.empty() ? 0 : 1); }        // 2^-ka of the planes currently in this trunk's plane buffer
+    // statistical bound of the current block input / output (conv3h.hip, p3.hip: P3hScale), two slots used alternately so that a merge
+    // reads its input's bound from one and publishes its output's bound into the other
+    float* h2_xbound(int parity) { return c->p("h2s") + 2 + 2 * (parity & 1) + (sfx.empty() ? 0 : 1); }
+    P3hScale h2_scale(float* bound_out = nullptr, const float* res_bound = nullptr, const double* res_acc = nullptr, double res_inv_count = 0.0) {
+        P3hScale h;
+        h.a_inv = h2_a_inv(); h.bound_out = bound_out; h.res_bound = res_bound; h.res_acc = res_acc; h.res_inv_count = res_inv_count;
+        return h;
+    }
+
     double* bn_acc(int layer_index) { return reinterpret_cast<double*>(c->p("bnacc" + sfx)) + (size_t)layer_index * 2 * 512; }
     // batch-norm of layer `bn_name` by reference to its statistics accumulators (consumers finalize in-kernel)
     BnRef bn_ref(int layer_index, const std::string& bn_name, long count) {
@@ -451,11 +466,22 @@ struct Fwd {
         if (rc) return;
         IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
                                 Cout, Hout, Wout);
-        if (planes) {                       // the input as pre-split bf16 planes (p3.hip); x may be null then
+        if (planes) {                       // the input as pre-split planes (p3.hip); x may be null then
             d.xp3 = planes;
             d.p3_np = c->B * Hin * (Win + 1);
-            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
-            d.xp3_bytes = (unsigned)p3_bytes(c->B, Hin, Win, Cin);
+            auto hs = c->h2_slot.find(name);
+            if (h2() && stride == 1 && k == 3 && hs != c->h2_slot.end()) {       // two fp16 planes + the layer's fp16 filter planes
+                d.xp3_fmt = 1;
+                d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+                d.xp3_bytes = (unsigned)p3h_bytes(c->B, Hin, Win, Cin);
+                d.wh2 = c->p("pkh:" + name + "/weights");
+                d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+                d.h2_a_inv = h2_a_inv();
+                d.h2_w_inv = c->p("h2s") + hs->second;
+            } else {
+                d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
+                d.xp3_bytes = (unsigned)p3_bytes(c->B, Hin, Win, Cin);
+            }
         }
         d.bn_in = bn_in;
         d.stats = bn_acc(bn_index);
@@ -471,8 +497,8 @@ struct Fwd {
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
         // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
-        const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode &&
-                           !(c->use_p3 && c->p3_from_stage <= 2);
+        const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode;
+        const bool pool_planes = c->use_p3 && c->p3_from_stage <= 2;       // the pooled tensor is also wanted as planes (operand of conv2_1/conv_1)
         if (fast8)
             timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s); });
         else if (c->video_u8 && scope == "video_encoder")
@@ -495,7 +521,11 @@ struct Fwd {
                     return stem8pool_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });
                 const BnRef bnf = bn_ref(li, name, (long)B * H * W);
                 layer = name + "/bn-relu";
-                timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, c->p("rx0" + sfx), (long)B * 56 * 112, 64, s); });
+                const P3hScale hs0 = h2_scale(h2_xbound(0));
+                if (pool_planes)       // BN + ReLU of the pooled tensor in place (the residual of conv2_1) AND as planes
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, 1, c->p("rx0" + sfx), c->p("p3" + sfx), B, 56, 112, 64, s, p3_fmt(), &hs0); });
+                else
+                    timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, c->p("rx0" + sfx), (long)B * 56 * 112, 64, s); });
             } else if (fused) {
                 // conv + statistics + pool of the RAW output in one kernel (max or min per channel by the sign of gamma), then BN + ReLU on
                 // the pooled tensor in place: relu(bn(.)) is monotone per channel, so this IS maxpool(relu(bn(conv))) (stempool.hip)
@@ -514,7 +544,10 @@ struct Fwd {
             contract(d);
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
             if (c->use_p3 && c->p3_from_stage <= 2)       // pooled block input as fp32 (residual) AND as planes (operand of conv2_1/conv_1)
-                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s); });
+            {
+                const P3hScale hs0 = h2_scale(h2_xbound(0));
+                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s, p3_fmt(), &hs0); });
+            }
             else
                 timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
             }
@@ -525,7 +558,8 @@ struct Fwd {
         float* xout = c->p("rx1" + sfx);
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};
-        bool x_in_planes = c->use_p3 && c->p3_from_stage <= 2;        // p3_maxpool wrote the pooled tensor as planes (neither fused stem runs then)
+        bool x_in_planes = pool_planes;        // the pooled tensor exists as planes (p3_pack after the fused uint8 stem, p3_maxpool otherwise)
+        int xb_par = 0;                                                 // which h2_xbound slot holds the current block input's bound
         bool x_fp32_valid = true;                                       // false: the previous merge wrote the block input as planes only
         for (int st = 0; st < 4; ++st) {
             const int cout = couts[st];
@@ -553,6 +587,7 @@ struct Fwd {
                         d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
                         d.xp3_bytes = (unsigned)p3_bytes(B, H, W, cin);
                     }
+                    if (h2() && p3_here) d.stats = bn_acc(20 + st);      // (sum, sumsq) of the projection: the residual's magnitude for the merge's fp16 scale
                     layer = pfx + "/shortcut";
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
@@ -565,16 +600,21 @@ struct Fwd {
                     // relu(bn1(y1)) -> planes (one elementwise pass), conv_2 on the planes, then the residual merge, which also
                     // writes the planes of the block output when the next conv_1 is a stride-1 3x3 (unit 1 of a stage)
                     layer = pfx + "/bn1-relu";
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, 1, nullptr, planes, B, Ho, Wo, cout, s); });
+                    const P3hScale hs1 = h2_scale();
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, 1, nullptr, planes, B, Ho, Wo, cout, s, p3_fmt(), &hs1); });
                     conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes);
                     const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                     layer = pfx + "/merge";
                     // the block output as planes when the next conv_1 reads planes: the stride-1 3x3 of this stage (unit 1), or the
                     // stride-2 conv_1 + shortcut of the next stage's first block (conv3g_kernel)
                     // ... whose consumers read nothing else: that block output is written as planes ONLY (hi + mid + lo IS the value)
-                    const bool to_next_stage = unit == 2 && c->use_p3g && st < 3;
+                    const bool to_next_stage = unit == 2 && c->use_p3g && st < 3;      // (conv3g_kernel reads the three-plane format)
                     const bool next_p3 = unit == 1 || to_next_stage;
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, to_next_stage ? nullptr : xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s); });
+                    // the residual's statistical bound: tracked from the previous pass (identity) or from the shortcut conv's statistics
+                    const P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
+                                               : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
+                    xb_par ^= 1;
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, to_next_stage ? nullptr : xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s, to_next_stage ? 0 : p3_fmt(), &hs2); });
                     x_in_planes = next_p3;
                     x_fp32_valid = !to_next_stage;
                     ++li;

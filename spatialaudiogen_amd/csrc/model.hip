@@ -37,6 +37,10 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     // (SAGEN_ONE_STREAM=1 hosts, bench.py) its one-workgroup-per-CU LDS footprint blocks co-residency and it is a wash (-0.3 %)
     c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
     c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
+    c->use_h2 = getenv("SAGEN_NO_H2") == nullptr;
+    // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
+    // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
+    if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;
     // conv3g_kernel for the stride-2 conv_1 + shortcut of the first block of stages 3-5: measured (profiles/r04_layers_p3g.txt) no
     // faster than igemm3_kernel on these small-M layers (56 / 58 / 72 us against 57 / 57 / 66; shortcuts equal) - off unless asked for
     c->use_p3g = c->use_p3 && getenv("SAGEN_P3G") != nullptr;
@@ -123,7 +127,14 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
             n = packed_floats(vs.shape[1], vs.shape[0]);
         }
         c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
+        // the 3x3 convs of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
+        if (vs.ndim == 4 && vs.shape[0] == 3 && vs.shape[1] == 3 && vs.shape[2] % 16 == 0 && vs.name.find("_encoder/conv") != std::string::npos) {
+            c->alloc("pkh:" + vs.name, n);
+            const int slot = 8 + (int)c->h2_slot.size();
+            c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = slot;
+        }
     }
+    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [8..] 2^-kw per layer
     c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
     // activations
     c->alloc("mag", (size_t)B * 127 * 1024);
@@ -270,7 +281,19 @@ int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
         c->pack_blocks = sagen_upload_pack_jobs(c->pack_jobs, c->p("pk:jobs"), s);
         if (c->pack_blocks < 0) return fail(SAGEN_ERR_HIP, "pack job upload failed");
     }
-    return pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pk:jobs")), (int)c->pack_jobs.size(), c->pack_blocks, s);
+    int rc = pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pk:jobs")), (int)c->pack_jobs.size(), c->pack_blocks, s);
+    if (rc || c->train_mode || c->fp32_only) return rc;
+    // inference: the fp16x2 filter planes of the trunk's 3x3 convs, from the fp32 packs just written (bind time only)
+    for (const auto& kv : c->h2_slot) {
+        const VarSpec* vs = nullptr;
+        for (const auto& v : c->vars) if (v.name == kv.first + "/weights") vs = &v;
+        if (!vs) continue;
+        const int N = (int)vs->shape[3], Kpad = (int)(9 * vs->shape[2]);
+        rc = h2_filter_pack_launch(c->p("pk:" + vs->name), N, Kpad, c->p("pkh:" + vs->name), reinterpret_cast<unsigned*>(c->p("h2s") + 6),
+                                   c->p("h2s") + kv.second, s);
+        if (rc) return rc;
+    }
+    return SAGEN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -541,6 +564,8 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     const std::string n = name;
     if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
+    if (n == "fp16x2") { c->use_h2 = value != 0; return SAGEN_OK; }
+    if (n == "planes_from_stage") { if (value < 2 || value > 6) return fail(SAGEN_ERR_SHAPE, "planes_from_stage in 2..6"); c->p3_from_stage = value; return SAGEN_OK; }
     if (n == "plane_gather") { c->use_p3g = c->use_p3 && value != 0; return SAGEN_OK; }
     return fail(SAGEN_ERR_UNSUPPORTED, "sagen_set_option: unknown option %s", name);
 }

@@ -57,13 +57,77 @@ __device__ __forceinline__ void p3_store(char* p3, long cstride, long pp, int c8
     *reinterpret_cast<u32x4*>(dst + 64) = lo;
 }
 
+// ---- format 1 ("H2", conv3h.hip): two fp16 planes (hi, lo) of v * 2^ka, [C/16][NP][2][16], 64 B per pixel and chunk ----
+size_t p3h_bytes(int B, int H, int W, int C) { return (size_t)(C / 16) * B * H * (W + 1) * 64; }
+
+// 2^ka for the tensor this pass writes, from STATISTICS the forward already holds (no extra pass over the data):
+//   * the batch-norm branch: channel c of relu(bn(y)) has mean beta_c and standard deviation |gamma_c| sqrt(var_c / (var_c + eps))
+//     (NOT |gamma_c|: a batch-norm whose input variance is below eps does not normalise to unit variance) -> bound_c = |beta_c| + 8 std_c;
+//   * the residual branch of a block merge: either the bound of the block input, tracked from pass to pass in device memory
+//     (`h.res_bound`), or - first block of a stage - the (sum, sumsq) of the 1x1 shortcut conv's output: |mean_c| + 8 std_c.
+// bound = max_c(bn) + max_c(residual) is scaled into [512, 1024): fp16 overflows at 65504, i.e. 64 x headroom for what lies beyond
+// eight standard deviations, then saturation.  Every block derives the same value; block 0 publishes 2^-ka (read by conv3h_kernel's
+// epilogue) and the bound itself (the residual bound of the next merge).  Without a BnRef the scale is 1.
+
+__device__ __forceinline__ float p3h_act_scale(const BnRef& bn, const P3hScale& h, bool has_res, int C, unsigned* s_bits) {
+    if (threadIdx.x < 2) s_bits[threadIdx.x] = 0u;
+    __syncthreads();
+    if (bn.acc != nullptr) {
+        float m = 0.f, mr = 0.f;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const double mean = bn.acc[c] * bn.inv_count;
+            double var = bn.acc[C + c] * bn.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            m = fmaxf(m, fabsf(bn.beta[c]) + 8.f * fabsf(bn.gamma[c]) * (float)sqrt(var / (var + (double)bn.eps)));
+            if (has_res && h.res_acc != nullptr) {
+                const double rm = h.res_acc[c] * h.res_inv_count;
+                double rv = h.res_acc[C + c] * h.res_inv_count - rm * rm;
+                rv = rv < 0.0 ? 0.0 : rv;
+                mr = fmaxf(mr, (float)(fabs(rm) + 8.0 * sqrt(rv)));
+            }
+        }
+        atomicMax(&s_bits[0], __builtin_bit_cast(unsigned, m));            // non-negative floats order like their bit patterns
+        atomicMax(&s_bits[1], __builtin_bit_cast(unsigned, mr));
+    }
+    __syncthreads();
+    float bound = __builtin_bit_cast(float, s_bits[0]) + __builtin_bit_cast(float, s_bits[1]);
+    if (has_res && h.res_acc == nullptr && h.res_bound != nullptr) bound += h.res_bound[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && h.bound_out != nullptr) h.bound_out[0] = bound;
+    const unsigned b = __builtin_bit_cast(unsigned, bound);
+    const int e = (int)((b >> 23) & 0xff);
+    if (bn.acc == nullptr || e == 0 || e == 255) return 1.f;
+    const int k = max(-60, min(60, 127 + 9 - e));
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+
+__device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c8, const float (&v)[8], float sa) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = fminf(fmaxf(v[k] * sa, -65000.f), 65000.f);
+        hi[k] = (_Float16)t;
+        lo[k] = (_Float16)(t - (float)hi[k]);
+    }
+    char* dst = p3 + (long)(c8 >> 1) * cstride + pp * 64 + (c8 & 1) * 16;
+    *reinterpret_cast<h8*>(dst) = hi;
+    *reinterpret_cast<h8*>(dst + 32) = lo;
+}
+
+template <bool H2>
 __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const BnRef bn,
                                                       const float* __restrict__ res, int relu, float* __restrict__ y,
-                                                      char* __restrict__ p3, long nrows, int W, int C) {
+                                                      char* __restrict__ p3, long nrows, int W, int C, const P3hScale h2) {
     const int C8 = C >> 3;
     const long total = nrows * (W + 1) * C8;             // padded pixels x channel octets (the grid stride is a multiple of C8)
-    const long cstride = nrows * (W + 1) * 96;
+    const long cstride = nrows * (W + 1) * (H2 ? 64 : 96);
+    __shared__ unsigned s_bits[2];
+    float sa = 1.f;
+    if (H2) {
+        sa = p3h_act_scale(bn, h2, res != nullptr, C, s_bits);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && h2.a_inv) h2.a_inv[0] = 1.f / sa;
+    }
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
@@ -97,9 +161,13 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
             for (int k = 0; k < 8; ++k) v[k] = 0.f;
         }
         if (p3) {
-            u32x4 hi, mid, lo;
-            p3_split8(v, hi, mid, lo);
-            p3_store(p3, cstride, pp, c8, hi, mid, lo);
+            if (H2) {
+                p3h_store(p3, cstride, pp, c8, v, sa);
+            } else {
+                u32x4 hi, mid, lo;
+                p3_split8(v, hi, mid, lo);
+                p3_store(p3, cstride, pp, c8, hi, mid, lo);
+            }
         }
     }
 }
@@ -115,27 +183,39 @@ static int aligned_grid(long total, int unit_threads) {
 }
 
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
-                   float* y, void* p3, int B, int H, int W, int C, hipStream_t s) {
+                   float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt, const P3hScale* h2) {
     if (C % 16 || C > P3_MAX_C) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: C=%d must be a multiple of 16, at most %d", C, P3_MAX_C);
     if (!y && !p3) return fail(SAGEN_ERR_NULL, "p3_pack: no output");
     const long nrows = (long)B * H;
     if (p3_bytes(B, H, W, C) >= (1UL << 31)) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: tensor exceeds 2 GiB buffer addressing");
     const long total = nrows * (W + 1) * (C / 8);
-    hipLaunchKernelGGL(p3_pack_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
-                       (char*)p3, nrows, W, C);
+    if (fmt == 1 && p3 && !(h2 && h2->a_inv)) return fail(SAGEN_ERR_NULL, "p3_pack: the fp16x2 format needs a slot for its scale");
+    if (fmt == 1)
+        hipLaunchKernelGGL(p3_pack_kernel<true>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+                           (char*)p3, nrows, W, C, *h2);
+    else
+        hipLaunchKernelGGL(p3_pack_kernel<false>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+                           (char*)p3, nrows, W, C, P3hScale());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
 
 // tf.nn.max_pool(x,[1,3,3,1],[1,2,2,1],'SAME') (resnet.py:135) of relu(bn(x)), -inf padding; see elementwise.hip
+template <bool H2>
 __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const BnRef bn, float* __restrict__ y,
                                                          char* __restrict__ p3, int B, int H, int W, int C, int Ho, int Wo,
-                                                         int pt, int pl) {
+                                                         int pt, int pl, const P3hScale h2) {
     const int C8 = C >> 3;
     const long nrows = (long)B * Ho;
     const long total = nrows * (Wo + 1) * C8;
-    const long cstride = nrows * (Wo + 1) * 96;
+    const long cstride = nrows * (Wo + 1) * (H2 ? 64 : 96);
+    __shared__ unsigned s_bits[2];
+    float sa = 1.f;
+    if (H2) {
+        sa = p3h_act_scale(bn, h2, false, C, s_bits);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && h2.a_inv) h2.a_inv[0] = 1.f / sa;
+    }
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
@@ -183,21 +263,30 @@ __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict
             for (int k = 0; k < 8; ++k) v[k] = 0.f;
         }
         if (p3) {
-            u32x4 hi, mid, lo;
-            p3_split8(v, hi, mid, lo);
-            p3_store(p3, cstride, pp, c8, hi, mid, lo);
+            if (H2) {
+                p3h_store(p3, cstride, pp, c8, v, sa);
+            } else {
+                u32x4 hi, mid, lo;
+                p3_split8(v, hi, mid, lo);
+                p3_store(p3, cstride, pp, c8, hi, mid, lo);
+            }
         }
     }
 }
 
 int p3_maxpool_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, void* p3, int B, int H,
-                      int W, int C, hipStream_t s) {
+                      int W, int C, hipStream_t s, int fmt, const P3hScale* h2) {
     if (C % 16 || C > P3_MAX_C) return fail(SAGEN_ERR_UNSUPPORTED, "p3_maxpool: C=%d must be a multiple of 16, at most %d", C, P3_MAX_C);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
     const long total = (long)B * Ho * (Wo + 1) * (C / 8);
-    hipLaunchKernelGGL(p3_maxpool_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, y, (char*)p3, B, H,
-                       W, C, Ho, Wo, pth / 2, ptw / 2);
+    if (fmt == 1 && p3 && !(h2 && h2->a_inv)) return fail(SAGEN_ERR_NULL, "p3_maxpool: the fp16x2 format needs a slot for its scale");
+    if (fmt == 1)
+        hipLaunchKernelGGL(p3_maxpool_kernel<true>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, y, (char*)p3, B, H,
+                           W, C, Ho, Wo, pth / 2, ptw / 2, *h2);
+    else
+        hipLaunchKernelGGL(p3_maxpool_kernel<false>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, y, (char*)p3, B, H,
+                           W, C, Ho, Wo, pth / 2, ptw / 2, P3hScale());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

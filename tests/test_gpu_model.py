@@ -222,6 +222,58 @@ def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('case', ['tiny', 'huge', 'mixed', 'offset'])
+def test_fp16x2_trunk_planes_hold_over_the_range_of_batch_norm_parameters(T, case):
+    """conv3h_kernel evaluates the trunk's 3x3 convs on TWO fp16 planes per operand (three products per multiply).  fp16 has no
+    fp32 exponent range, so the plane pass scales each tensor by 2^ka derived from the batch-norm that produced it
+    (max_c |beta_c| + 8 |gamma_c| -> [512, 1024)) and the filter pack scales each filter by 2^kw.  The scheme must hold whatever the
+    learned gamma / beta are: activations 1000 times smaller ('tiny') or 300 times larger ('huge') than the usual O(1), channels of
+    very different size inside one tensor ('mixed'), a large common offset ('offset').  Same bars against the fp64 oracle as every
+    forward, and the result of the three-plane bf16 kernels (fp16x2 = 0) within 2e-5."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    B = 3
+    P = init_weights(variable_specs(enc), seed=21, mode='test')
+    r = np.random.Generator(np.random.PCG64(3))
+    for k in list(P):
+        if k.startswith('video_encoder/') and k.endswith('/bn/gamma') and '/conv1/' not in k:
+            g, b = P[k].copy(), P[k.replace('gamma', 'beta')].copy()
+            if case == 'tiny':
+                g *= 1e-3; b *= 1e-3
+            elif case == 'huge':
+                g *= 300.0; b *= 300.0
+            elif case == 'mixed':
+                g *= np.exp(r.uniform(np.log(1e-3), np.log(30.0), size=g.shape)).astype(np.float32)
+            else:
+                b += 40.0
+            P[k], P[k.replace('gamma', 'beta')] = g.astype(np.float32), b.astype(np.float32)
+    inp = synth_inputs(B, enc, seed=43)
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+    trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    net.profile_enable(B, True)
+    net.inference_ops(inp['audio'], inp['video'])
+    kernels = {k for k, layer, us, fl in net.profile_report(B)}
+    net.profile_enable(B, False)
+    assert any(k.startswith('conv3h_kernel') for k in kernels), kernels
+    net.set_option(B, 'fp16x2', 0)
+    other = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+    trunk3 = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    # these parameter sets move the output's scale by orders of magnitude and put batch-norms into their eps-dominated regime (rounding
+    # noise is amplified for EVERY arithmetic): the bars are relative, and the yardstick is the six-product bf16x3 path on the same input
+    tr = orc.ends['video_encoder/conv5_2']
+    e2, e3 = rel_rms_err(trunk, tr), rel_rms_err(trunk3, tr)
+    o2, o3 = rel_rms_err(got, ref), rel_rms_err(other, ref)
+    print('\n[%s] conv5_2 rel err: fp16x2 %.3g, bf16x3 %.3g; output rel err: fp16x2 %.3g, bf16x3 %.3g (output rms %.3g)' % (case, e2, e3, o2, o3, rms(ref)))
+    assert np.isfinite(got).all() and np.isfinite(trunk).all()
+    assert e2 < 1e-4 and o2 < 1e-3, (e2, o2)
+    assert e2 <= 1.5 * e3 + 1e-7 and o2 <= 1.5 * o3 + 1e-7, (e2, e3, o2, o3)     # no less accurate than the six-product path
+    assert rel_rms_err(trunk, trunk3) < 1e-4
+
+
 def test_stride2_block_inputs_run_on_the_plane_fed_gather_kernel(T):
     """The first block of ResNet stages 3, 4 and 5: the last merge of the previous stage writes its block output as bf16x3 planes
     (and nothing else) and the 3x3 stride-2 conv_1 + the 1x1 stride-2 shortcut read THEM (conv3g_kernel: LDS-DMA gather -> MFMA, no

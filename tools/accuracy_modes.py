@@ -8,7 +8,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
     from spatialaudiogen_amd.model import SptAudioGen
     from oracle.np_oracle import SptAudioGenOracle
-    mode = 'fp32_only' if os.environ.get('SAGEN_FP32_ONLY') else 'bf16x3'
+    mode = 'fp32_only' if os.environ.get('SAGEN_FP32_ONLY') else ('bf16x3' if os.environ.get('SAGEN_NO_H2') else
+            'bf16x3 + fp16x2 trunk planes from stage %s' % os.environ.get('SAGEN_P3_FROM_STAGE', '3'))
+    also_conv5 = True
     for enc in (['audio'], ['audio', 'video'], ['audio', 'video', 'flow']):
         for seed in (0, 1):
             P = init_weights(variable_specs(enc), seed=seed, mode='test')
@@ -18,9 +20,14 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
             net.load_variables(P)
             out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow')).cpu().numpy().astype(np.float64)
             err = float(np.sqrt(np.mean((out - ref) ** 2))); rms = float(np.sqrt(np.mean(ref ** 2)))
-            print(json.dumps({'mode': mode, 'encoders': '+'.join(e[0].upper() for e in enc), 'seed': seed, 'rms_err': err,
+            trunk = None
+            if 'video' in enc:
+                orc_t = SptAudioGenOracle(encoders=enc); orc_t.inference_ops(inp['audio'], P, video=inp.get('video'), flow=inp.get('flow'))
+                t = net.intermediate(4, 'video_encoder/conv5_2').cpu().numpy().astype(np.float64); r_ = orc_t.ends['video_encoder/conv5_2']
+                trunk = float(np.sqrt(np.mean((t - r_) ** 2)) / np.sqrt(np.mean(r_ ** 2)))
+            print(json.dumps({'mode': mode, 'trunk_conv5_2_rel_err': trunk, 'encoders': '+'.join(e[0].upper() for e in enc), 'seed': seed, 'rms_err': err,
                               'out_rms': rms, 'rel': err / rms, 'max_abs_err': float(np.abs(out - ref).max())}), flush=True)
 else:
-    for env in ({}, {'SAGEN_FP32_ONLY': '1'}):
+    for env in ({}, {'SAGEN_P3_FROM_STAGE': '2'}, {'SAGEN_NO_H2': '1'}, {'SAGEN_FP32_ONLY': '1'}):
         e = dict(os.environ); e.update(env)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'child'], env=e)
