@@ -55,6 +55,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA peak (v_mfma_f32_32x32x
 # the bf16x3 kernels evaluate every fp32 product as 6 bf16 products (3-way operand split, fp32 accumulate): their matrix roof
 # in ALGORITHMIC fp32 FLOP/s is the bf16 peak / 6
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# conv3h_kernel (the trunk's 3x3 convs since round 4): two fp16 planes per operand, 3 products per fp32 multiply on v_mfma_f32_32x32x16_f16
+# (same rate as bf16): roof = 2500 / 3 in algorithmic fp32 FLOP/s
+PEAK_FP16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 # Context, not the roof: a kernel issuing nothing but v_mfma_f32_32x32x16_bf16 on every SIMD sustains 1.66-1.81 PFLOP/s with normally
 # distributed operands (power management; 2.28-2.48 with all-zero operands) - tools/probe/mfma_peak.py, profiles/r03_mfma_sustained.txt
 SUSTAINED_BF16X3_TFLOPS = 1740.0 / 6.0
@@ -569,9 +572,11 @@ def main():
             a[0] += 1; a[1] += us; a[2] += fl
     net.profile_enable(BATCH, False)
     total_us = sum(a[1] for a in agg.values())
-    dom = max(agg, key=lambda k: agg[k][1])
+    dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][1])        # the dominant CONTRACTION (the path is matrix-bound)
     n_l, us_l, fl_l = agg[dom]
     achieved = fl_l / (us_l * 1e-6) / 1e12
+    # the largest HBM-bound kernel family beside it (the plane passes): algorithmic bytes are not tracked per launch, so only its share
+    hbm_dom = max((k for k in agg if agg[k][2] == 0), key=lambda k: agg[k][1], default=None)
     traffic, traffic_src = None, None
     try:     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
@@ -581,21 +586,27 @@ def main():
     except Exception:
         pass
     step_tflops = cfg['gflop'] * BATCH / (ms_per_step * 1e-3) / 1e3          # throughput-based (steps overlap when NF > 1)
-    b3 = dom.startswith('igemm3') or dom.startswith('conv3p')   # igemm3 / igemm3dw / igemm3s2 / conv3p kernels: the bf16x3 family
-    peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
-    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3') or k.startswith('conv3p'))
+    h2 = dom.startswith('conv3h') or dom.startswith('stem8pool')   # three matrix products per fp32 multiply (fp16x2 planes / the exact uint8 plane)
+    b3 = dom.startswith('igemm3') or dom.startswith('conv3p') or dom.startswith('conv3g')   # the six-product bf16x3 family
+    peak = PEAK_FP16X2_TFLOPS if h2 else (PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS)
+    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3') or k.startswith('conv3p') or k.startswith('conv3g'))
+    h2_us = sum(a[1] for k, a in agg.items() if k.startswith('conv3h') or k.startswith('stem8pool'))
     f32_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm_kernel'))
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),
         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-        'frac_of_sustained_mfma_rate': round(achieved / SUSTAINED_BF16X3_TFLOPS, 4) if b3 else None, 'sustained_note': SUSTAINED_NOTE if b3 else None,
-        'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
+        'frac_of_sustained_mfma_rate': round(achieved / (SUSTAINED_BF16X3_TFLOPS * (2.0 if h2 else 1.0)), 4) if (b3 or h2) else None,
+        'sustained_note': (SUSTAINED_NOTE.replace('290 TFLOP/s', '580 TFLOP/s (three products per multiply)') if h2 else SUSTAINED_NOTE) if (b3 or h2) else None,
+        'peak_basis': ('dense fp16 MFMA peak 2500 TF / 3 products per fp32 multiply (fp16x2 planes, conv3h_kernel); algorithmic fp32 FLOPs' if h2 else
+                       'dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
                        if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2),
         'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
         'share_of_step_time': round(us_l / total_us, 3),
-        'contraction_time_split': {'bf16x3_kernels_us': round(b3_us / nprof, 1), 'fp32_mfma_kernels_us': round(f32_us / nprof, 1)},
+        'largest_hbm_bound_kernel': None if hbm_dom is None else {'kernel': hbm_dom, 'launches_per_step': agg[hbm_dom][0] // nprof,
+                                                                  'us_per_step': round(agg[hbm_dom][1] / nprof, 1), 'share_of_step_time': round(agg[hbm_dom][1] / total_us, 3)},
+        'contraction_time_split': {'fp16x2_kernels_us': round(h2_us / nprof, 1), 'bf16x3_kernels_us': round(b3_us / nprof, 1), 'fp32_mfma_kernels_us': round(f32_us / nprof, 1)},
         'whole_step': {'achieved': round(step_tflops, 2), 'frac': round(step_tflops / peak, 4),
                        'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                        'gflop_per_window_needed_only': cfg['gflop'],
@@ -606,8 +617,10 @@ def main():
         'metric': 'ambisonic seconds generated/sec (0.1 s windows, 224x448 video)',
         'value': round(value, 2), 'unit': 'ambisonic-s/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None,
-        'dtype': 'f32 (products on the bf16 matrix cores as a 3-way bf16 operand split, 6 products per multiply, fp32 accumulate '
-                 '- fp32-equivalent, parity bar 1e-4 RMS unchanged; SAGEN_FP32_ONLY=1 selects the exact fp32 MFMA kernels)',
+        'dtype': 'f32 (fp32 in / out / accumulate; products on the 16-bit matrix cores with fp32-equivalent operand splits: two fp16 planes '
+                 '(3 products per multiply) for the ResNet trunk\'s 3x3 convs, whose operand ranges batch-norm bounds, three bf16 planes '
+                 '(6 products) elsewhere - measured against the fp64 oracle as accurate as the exact fp32 MFMA kernels '
+                 '(profiles/r04_accuracy_modes.jsonl; SAGEN_FP32_ONLY=1 selects those; parity bar 1e-4 RMS unchanged)',
         'data': 'synthetic' + (' (pool of %d distinct windows cycled over the %d x %d window set)' % (POOL, EVAL_CLIPS, EVAL_WINDOWS_PER_CLIP) if is_eval else
                                ' (%d distinct resident batches per GPU, cycled)' % NPOOL),
         'config': {'workload': cfg['workload'], 'name': args.config,

@@ -20,25 +20,34 @@
 
 namespace sagen {
 
-constexpr int conv3g_wgs_per_cu(int BM, int BN, int KS) { return 2 * (2 * KS * (BM + BN) * 96 + 512) <= 160 * 1024 ? 2 : 1; }
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, int KS>
-__global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_kernel(const IgemmDesc d) {
+// H2: the planes are two fp16 planes per operand (conv3h.hip: 64 B per pixel and chunk, three products per multiply, the tile scaled
+// back by 2^-(ka + kw) in the epilogue); otherwise three bf16 planes (96 B, six products)
+constexpr int conv3g_wgs_per_cu(int BM, int BN, int KS, bool H2) {
+    const int lds = 2 * KS * (BM + BN) * (H2 ? 64 : 96) + 512;
+    return 3 * lds <= 160 * 1024 ? 3 : (2 * lds <= 160 * 1024 ? 2 : 1);
+}
+
+template <int BM, int BN, int WM, int WN, int KS, bool H2>
+__global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g_kernel(const IgemmDesc d) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
-    constexpr int A_INST = BM * 6 / 64, B_INST = BN * 6 / 64;          // 1 KiB LDS-DMA wave-instructions per K tile
-    static_assert(BM * 6 % 64 == 0 && BN * 6 % 64 == 0, "operand images must be whole DMA instructions");
+    constexpr int NPL = H2 ? 2 : 3, SB = NPL * 32, UPS = NPL * 2;      // planes, bytes and 16-byte units per slot
+    constexpr int NPR = H2 ? 3 : 6;                                    // matrix products per fp32 product
+    constexpr int A_INST = BM * UPS / 64, B_INST = BN * UPS / 64;      // 1 KiB LDS-DMA wave-instructions per K tile
+    static_assert(BM * UPS % 64 == 0 && BN * UPS % 64 == 0, "operand images must be whole DMA instructions");
     constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;    // slots per wave and K tile
     constexpr int A_BYTES = A_INST * 1024, B_BYTES = B_INST * 1024;
     constexpr int T_BYTES = A_BYTES + B_BYTES;                         // one K tile: activation image, then filter image
     constexpr int ST_BYTES = KS * T_BYTES;
     constexpr int SPT = A_PW + B_PW;                                   // DMA slots per wave and K tile
     constexpr int CNT = KS * SPT;                                      // ... and group
-    constexpr int NM1 = 6 * MT * NT;                                   // MFMAs per K tile
+    constexpr int NM1 = NPR * MT * NT;                                 // MFMAs per K tile
     constexpr int NMG = KS * NM1;
     static_assert(CNT <= NMG, "one DMA slot per MFMA slot at most");
-    constexpr int NF = 3 * (MT + NT);
+    constexpr int NF = NPL * (MT + NT);
     constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
     static_assert(WM % RPP == 0, "a wave row is a whole number of store passes");
     constexpr int EPI_TILE = WM * BN * 4, EPI_RED = 2 * RPP * BN * 4;
@@ -57,8 +66,8 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
     const int nM = (d.M + BM - 1) / BM, nN = (d.N + BN - 1) / BN;
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.xp3, 0, d.xp3_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(d.w + (size_t)d.N * d.Kpad), 0, d.w_bytes / 2 * 3, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = H2 ? __builtin_amdgcn_make_buffer_rsrc((void*)d.wh2, 0, d.wh2_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)(d.w + (size_t)d.N * d.Kpad), 0, d.w_bytes / 2 * 3, 0x00020000);
 
     // block -> tile: XCD x owns a contiguous run of M tiles (neighbouring tiles share input rows in one L2)
     const int xcd = blockIdx.x & 7;
@@ -76,8 +85,9 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
     for (int j = 0; j < A_PW; ++j) {
         const int inst = wave + 4 * j;
         const int U = inst * 64 + lane;
-        const int slot = U / 6, rem = U - 6 * slot;
-        const int pl = rem >> 1, half = rem & 1;
+        const int slot = U / UPS, rem = U - UPS * slot;
+        // which 16-byte unit of the pixel lands at position `rem` of the slot (the swizzles of conv3p.hip / conv3h.hip)
+        const int unit = H2 ? (rem ^ ((slot >> 2) & 3)) : ((rem & ~1) | ((rem & 1) ^ ((slot >> 3) & 1)));
         const int m = m0 + slot;
         a_base[j] = 0; a_bad[j] = 0xffffffffu;
         if (inst < A_INST && m < d.M) {
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
             const int ho = (int)row - (int)b * d.Hg;
             const int hi = ho * d.in_sh + d.tap_h0, wi = wo * d.in_sw + d.tap_w0;
             const int pix = ((int)b * d.Hin + hi) * Wp + wi;                           // may be -1 at the very first pixel: wraps to an out-of-range offset
-            a_base[j] = (unsigned)(pix * 96 + pl * 32 + 16 * (half ^ ((slot >> 3) & 1)));
+            a_base[j] = (unsigned)(pix * SB + unit * 16);
             unsigned bad = 0;
             for (int th = 0; th * d.TW < d.ntaps; ++th) {
                 const int hh = hi + th * d.tap_sh;
@@ -115,11 +125,11 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
         // per-lane validity of the rows above / below the image under filter row q_th.  The tap displacement goes into the VECTOR
         // offset: the buffer range check looks at the vector offset alone, and the origin pixel of a row under SAME padding may lie
         // above the tensor (a "negative" offset that only the displacement makes valid) - the scalar offset carries the chunk only
-        const unsigned tapd = (unsigned)((q_th * d.tap_sh * Wp + q_tw * d.tap_sw) * 96);
+        const unsigned tapd = (unsigned)((q_th * d.tap_sh * Wp + q_tw * d.tap_sw) * SB);
 #pragma unroll
         for (int j = 0; j < A_PW; ++j) a_cur[j] = ((a_bad[j] >> q_th) & 1u) ? OOB : a_base[j] + tapd;
         i_asoff = (unsigned)q_ch * d.xp3_cstride;
-        i_bsoff = (unsigned)q_kt * (unsigned)(d.N * 96);
+        i_bsoff = (unsigned)q_kt * (unsigned)(d.N * SB);
         ++q_kt; ++q_ch;
         const int wrap_c = q_ch == nchunk ? 1 : 0;
         q_ch = wrap_c ? 0 : q_ch;
@@ -153,10 +163,10 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int sl = wm * WM + i * 32 + li;
-        a_foff[i] = sl * 96 + 16 * (kk ^ ((sl >> 3) & 1));
+        a_foff[i] = H2 ? sl * 64 + 16 * (kk ^ ((sl >> 2) & 3)) : sl * 96 + 16 * (kk ^ ((sl >> 3) & 1));     // plane pl: ^ (pl * 32) / + pl * 32
     }
     const int b_foff = A_BYTES + (wn * WN + li) * 32 + 16 * (kk ^ ((li >> 3) & 1));
-    constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // hh, hm, mh, hl, lh, mm
+    constexpr int TA[6] = {H2 ? 1 : 0, 0, H2 ? 0 : 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};   // bf16x3: hh, hm, mh, hl, lh, mm; fp16x2: lh, hl, hh
 
     // ---- prologue: group 0 ----
     int stage = 0;
@@ -174,11 +184,11 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
         constexpr bool ISSUE = decltype(issue_tag)::value;
         const char* st = smem + stage * ST_BYTES;
         char* const nst = smem + (stage ^ 1) * ST_BYTES;
-        bf16x8 fq[2][NF];
+        bf16x8 fq[2][NF];                            // (raw 16-byte fragments: reinterpreted as 8 x fp16 for the fp16x2 planes)
         auto load_frag = [&](int buf, int ks, int f) {
             const int pl = f / (MT + NT), r = f - pl * (MT + NT);
             const char* tb = st + ks * T_BYTES;
-            if (r < MT) fq[buf][f] = *reinterpret_cast<const bf16x8*>(tb + a_foff[r] + pl * 32);
+            if (r < MT) fq[buf][f] = *reinterpret_cast<const bf16x8*>(tb + (H2 ? (a_foff[r] ^ (pl * 32)) : a_foff[r] + pl * 32));
             else fq[buf][f] = *reinterpret_cast<const bf16x8*>(tb + b_foff + pl * (BN * 32) + (r - MT) * 32 * 32);
         };
 #pragma unroll
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
         for (int ks = 0; ks < KS; ++ks) {
             const int cb = ks & 1;
 #pragma unroll
-            for (int tt = 0; tt < 6; ++tt)
+            for (int tt = 0; tt < NPR; ++tt)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -195,8 +205,12 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
                         const int k = (tt * MT + i) * NT + j;
                         const int idx = ks * NM1 + k;
                         __builtin_amdgcn_sched_barrier(0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb][TA[tt] * (MT + NT) + i], fq[cb][TB[tt] * (MT + NT) + MT + j],
-                                                                            acc[i][j], 0, 0, 0);
+                        if constexpr (H2)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, fq[cb][TA[tt] * (MT + NT) + i]),
+                                                                               __builtin_bit_cast(f16x8g, fq[cb][TB[tt] * (MT + NT) + MT + j]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[cb][TA[tt] * (MT + NT) + i], fq[cb][TB[tt] * (MT + NT) + MT + j],
+                                                                                acc[i][j], 0, 0, 0);
                         if (ks + 1 < KS) {
 #pragma unroll
                             for (int f = 0; f < NF; ++f)
@@ -225,6 +239,8 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
     // ---- epilogue through the (now idle) ring (conv3p.hip): 16-byte row-contiguous stores, bias / ReLU,
     //      batch-norm statistics of the raw output ----
     const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
+    float osc = 1.f;
+    if constexpr (H2) osc = d.h2_a_inv[0] * d.h2_w_inv[0];
     lds_barrier();                                           // every wave is done with the last group's fragments: the whole ring is free
     char* const epi = smem;
     float* const tile = reinterpret_cast<float*>(epi);                       // [WM][BN]
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)      // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-                        tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = acc[i][j][e];
+                        tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = H2 ? acc[i][j][e] * osc : acc[i][j][e];
         }
         lds_barrier();
         float4 tv[NPASS];
@@ -289,11 +305,11 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS)) void conv3g_ker
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS>
+template <int BM, int BN, int WM, int WN, int KS, bool H2>
 static int launch_conv3g(const IgemmDesc& d, hipStream_t s) {
     const int per = (cdiv(d.M, BM) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
-    hipLaunchKernelGGL((conv3g_kernel<BM, BN, WM, WN, KS>), dim3(grid), dim3(256), 0, s, d);
+    hipLaunchKernelGGL((conv3g_kernel<BM, BN, WM, WN, KS, H2>), dim3(grid), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -318,13 +334,20 @@ int conv3g_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: too many pixels for 32-bit index arithmetic");
     if ((long)d.p3_np * 96 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the activation planes exceed 2 GiB buffer addressing (use a smaller batch)");
+    const bool h2 = tile == TILE_P3GH_128x64_K3 || tile == TILE_P3GH_64x64_K4 || tile == TILE_P3GH_128x128_K2 || tile == TILE_P3GH_64x128_K3;
+    if (h2 != (d.xp3_fmt == 1)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the planes' format does not match the tile");
+    if (h2 && (!d.wh2 || !d.h2_a_inv || !d.h2_w_inv)) return fail(SAGEN_ERR_NULL, "conv3g: the fp16x2 filter planes / scales are missing");
     d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)d.Wg) + 1u;      // (reused fields: here the divisors are the OUTPUT grid's Wg, Hg)
     d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hg) + 1u;
     switch (tile) {
-        case TILE_P3G_128x64_K2: return launch_conv3g<128, 64, 64, 32, 2>(d, s);
-        case TILE_P3G_64x64_K2: return launch_conv3g<64, 64, 32, 32, 2>(d, s);
-        case TILE_P3G_64x128_K2: return launch_conv3g<64, 128, 32, 64, 2>(d, s);
-        case TILE_P3G_128x128_K1: return launch_conv3g<128, 128, 64, 64, 1>(d, s);
+        case TILE_P3G_128x64_K2: return launch_conv3g<128, 64, 64, 32, 2, false>(d, s);
+        case TILE_P3G_64x64_K2: return launch_conv3g<64, 64, 32, 32, 2, false>(d, s);
+        case TILE_P3G_64x128_K2: return launch_conv3g<64, 128, 32, 64, 2, false>(d, s);
+        case TILE_P3G_128x128_K1: return launch_conv3g<128, 128, 64, 64, 1, false>(d, s);
+        case TILE_P3GH_128x64_K3: return launch_conv3g<128, 64, 64, 32, 3, true>(d, s);
+        case TILE_P3GH_64x64_K4: return launch_conv3g<64, 64, 32, 32, 4, true>(d, s);
+        case TILE_P3GH_128x128_K2: return launch_conv3g<128, 128, 64, 64, 2, true>(d, s);
+        case TILE_P3GH_64x128_K3: return launch_conv3g<64, 128, 32, 64, 3, true>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: bad tile id %d", (int)tile);
     }
 }

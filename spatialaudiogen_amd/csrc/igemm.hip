@@ -323,10 +323,12 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 16, "conv3p_kernel<128,64,64,32>", true, true, false, true},   {128, 128, 16, "conv3p_kernel<128,128,64,64>", true, true, false, true},
     {64, 64, 16, "conv3p_kernel<64,64,32,32>", true, true, false, true},
     {128, 64, 16, "conv3pp_kernel<0>", true, true, false, true},          {128, 64, 16, "conv3pp_kernel<1>", true, true, false, true},
-    {128, 64, 16, "conv3g_kernel<128,64,64,32,2>", true, false, false, true, true}, {64, 64, 16, "conv3g_kernel<64,64,32,32,2>", true, false, false, true, true},
-    {64, 128, 16, "conv3g_kernel<64,128,32,64,2>", true, false, false, true, true}, {128, 128, 16, "conv3g_kernel<128,128,64,64,1>", true, false, false, true, true},
+    {128, 64, 16, "conv3g_kernel<128,64,64,32,2,false>", true, false, false, true, true}, {64, 64, 16, "conv3g_kernel<64,64,32,32,2,false>", true, false, false, true, true},
+    {64, 128, 16, "conv3g_kernel<64,128,32,64,2,false>", true, false, false, true, true}, {128, 128, 16, "conv3g_kernel<128,128,64,64,1,false>", true, false, false, true, true},
     {128, 64, 16, "conv3h_kernel<128,64,64,32>", true, true, false, true, false, true},   {128, 128, 16, "conv3h_kernel<128,128,64,64>", true, true, false, true, false, true},
     {64, 64, 16, "conv3h_kernel<64,64,32,32>", true, true, false, true, false, true},      {256, 64, 16, "conv3h_kernel<256,64,64,64>", true, true, false, true, false, true},
+    {128, 64, 16, "conv3g_kernel<128,64,64,32,3,true>", true, false, false, true, true, true},   {64, 64, 16, "conv3g_kernel<64,64,32,32,4,true>", true, false, false, true, true, true},
+    {128, 128, 16, "conv3g_kernel<128,128,64,64,2,true>", true, false, false, true, true, true}, {64, 128, 16, "conv3g_kernel<64,128,32,64,3,true>", true, false, false, true, true, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -397,8 +399,10 @@ IgemmTile igemm_pick_tile(const IgemmDesc& d) {
             if ((long)cdiv(np, 128) * cdiv(d.N, 64) >= want) return TILE_P3_128x64;
             return TILE_P3_64x64;
         }
-        if (d.xp3 != nullptr && !dw3_ok(d) && d.splitk == 1 && conv3g_ok(d))    // planes + any other geometry: gathered operand tiles
+        if (d.xp3 != nullptr && !dw3_ok(d) && d.splitk == 1 && conv3g_ok(d)) {  // planes + any other geometry: gathered operand tiles
+            if (d.xp3_fmt == 1) return blocks(TILE_P3GH_128x64_K3) >= 256 + 128 ? TILE_P3GH_128x64_K3 : TILE_P3GH_64x64_K4;
             return blocks(TILE_P3G_128x64_K2) >= 256 + 128 ? TILE_P3G_128x64_K2 : TILE_P3G_64x64_K2;
+        }
         if (dw3_ok(d) && (!pro || uniform_taps_for(d, 16))) {                   // 3x3 stride 1: shared horizontal taps
             if (d.N <= 64) return blocks(TILE_B3DW_128x64) >= want ? TILE_B3DW_128x64 : TILE_B3DWM_64x64;
             if (blocks(TILE_B3DW_128x128) >= 256 + 128) return TILE_B3DW_128x128;
@@ -465,8 +469,8 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
     if (d.ntaps > MAX_TAPS) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %d taps (max %d)", d.ntaps, MAX_TAPS);
-    if (kTiles[tile].h) return conv3h_dispatch(d, tile, s);
     if (kTiles[tile].g) return conv3g_dispatch(d, tile, s);
+    if (kTiles[tile].h) return conv3h_dispatch(d, tile, s);
     if (kTiles[tile].p3) return conv3p_dispatch(d, tile, s);
     if (kTiles[tile].s2) return igemm3s2_dispatch(d, tile, s);
     if (kTiles[tile].split) return igemm3_dispatch(d, tile, s);

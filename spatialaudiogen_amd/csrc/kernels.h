@@ -108,6 +108,8 @@ enum IgemmTile {
     TILE_P3G_128x64_K2, TILE_P3G_64x64_K2, TILE_P3G_64x128_K2, TILE_P3G_128x128_K1,
     // fp16x2 for dense 3x3 stride-1 SAME convs over TWO fp16 planes per operand: three products per multiply (conv3h_kernel)
     TILE_P3H_128x64, TILE_P3H_128x128, TILE_P3H_64x64, TILE_P3H_256x64,
+    // ... and for any strided / multi-tap conv over them (conv3g_kernel, gathered operand tiles)
+    TILE_P3GH_128x64_K3, TILE_P3GH_64x64_K4, TILE_P3GH_128x128_K2, TILE_P3GH_64x128_K3,
     TILE_AUTO
 };
 

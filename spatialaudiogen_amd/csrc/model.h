@@ -470,7 +470,7 @@ struct Fwd {
             d.xp3 = planes;
             d.p3_np = c->B * Hin * (Win + 1);
             auto hs = c->h2_slot.find(name);
-            if (h2() && stride == 1 && k == 3 && hs != c->h2_slot.end()) {       // two fp16 planes + the layer's fp16 filter planes
+            if (h2() && (stride == 1 || c->use_p3g) && k == 3 && hs != c->h2_slot.end()) {       // two fp16 planes + the layer's fp16 filter planes
                 d.xp3_fmt = 1;
                 d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
                 d.xp3_bytes = (unsigned)p3h_bytes(c->B, Hin, Win, Cin);
@@ -584,8 +584,19 @@ struct Fwd {
                     if (in_planes) {
                         d.xp3 = in_planes;
                         d.p3_np = B * H * (W + 1);
-                        d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
-                        d.xp3_bytes = (unsigned)p3_bytes(B, H, W, cin);
+                        auto hs = c->h2_slot.find(pfx + "/shortcut");
+                        if (h2() && hs != c->h2_slot.end()) {
+                            d.xp3_fmt = 1;
+                            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+                            d.xp3_bytes = (unsigned)p3h_bytes(B, H, W, cin);
+                            d.wh2 = c->p("pkh:" + pfx + "/shortcut/weights");
+                            d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+                            d.h2_a_inv = h2_a_inv();
+                            d.h2_w_inv = c->p("h2s") + hs->second;
+                        } else {
+                            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
+                            d.xp3_bytes = (unsigned)p3_bytes(B, H, W, cin);
+                        }
                     }
                     if (h2() && p3_here) d.stats = bn_acc(20 + st);      // (sum, sumsq) of the projection: the residual's magnitude for the merge's fp16 scale
                     layer = pfx + "/shortcut";
@@ -608,13 +619,13 @@ struct Fwd {
                     // the block output as planes when the next conv_1 reads planes: the stride-1 3x3 of this stage (unit 1), or the
                     // stride-2 conv_1 + shortcut of the next stage's first block (conv3g_kernel)
                     // ... whose consumers read nothing else: that block output is written as planes ONLY (hi + mid + lo IS the value)
-                    const bool to_next_stage = unit == 2 && c->use_p3g && st < 3;      // (conv3g_kernel reads the three-plane format)
+                    const bool to_next_stage = unit == 2 && c->use_p3g && st < 3;
                     const bool next_p3 = unit == 1 || to_next_stage;
                     // the residual's statistical bound: tracked from the previous pass (identity) or from the shortcut conv's statistics
                     const P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
                                                : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
                     xb_par ^= 1;
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, to_next_stage ? nullptr : xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s, to_next_stage ? 0 : p3_fmt(), &hs2); });
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, to_next_stage ? nullptr : xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
                     x_in_planes = next_p3;
                     x_fp32_valid = !to_next_stage;
                     ++li;

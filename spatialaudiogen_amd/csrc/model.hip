@@ -41,9 +41,11 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
     // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
     if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;
-    // conv3g_kernel for the stride-2 conv_1 + shortcut of the first block of stages 3-5: measured (profiles/r04_layers_p3g.txt) no
-    // faster than igemm3_kernel on these small-M layers (56 / 58 / 72 us against 57 / 57 / 66; shortcuts equal) - off unless asked for
-    c->use_p3g = c->use_p3 && getenv("SAGEN_P3G") != nullptr;
+    // conv3g_kernel for the stride-2 conv_1 + shortcut of the first block of stages 3-5 (the previous stage's last merge then writes its
+    // output as planes ONLY).  Measured per layer, batch 32 (profiles/r04_layers_p3g*.txt): on three bf16 planes no faster than
+    // igemm3_kernel (56 / 58 / 72 us against 57 / 57 / 66) - on two fp16 planes 43 / 41 / 48 us against 60 / 61 / 74, shortcuts
+    // 24 / 14 / 13 against 25 / 19 / 18: on with the fp16x2 planes, opt-in (SAGEN_P3G=1) without them
+    c->use_p3g = c->use_p3 && (getenv("SAGEN_P3G") != nullptr || (c->use_h2 && getenv("SAGEN_NO_P3G") == nullptr));
     c->cfg = *cfg;
     c->B = cfg->batch;
     c->has_video = cfg->encoders & SAGEN_ENC_VIDEO;
@@ -127,8 +129,9 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
             n = packed_floats(vs.shape[1], vs.shape[0]);
         }
         c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
-        // the 3x3 convs of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
-        if (vs.ndim == 4 && vs.shape[0] == 3 && vs.shape[1] == 3 && vs.shape[2] % 16 == 0 && vs.name.find("_encoder/conv") != std::string::npos) {
+        // the 3x3 convs (and 1x1 projections) of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
+        if (vs.ndim == 4 && ((vs.shape[0] == 3 && vs.shape[1] == 3) || (vs.shape[0] == 1 && vs.shape[1] == 1)) && vs.shape[2] % 16 == 0 &&
+            vs.name.find("_encoder/conv") != std::string::npos) {
             c->alloc("pkh:" + vs.name, n);
             const int slot = 8 + (int)c->h2_slot.size();
             c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = slot;
@@ -288,7 +291,7 @@ int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
         const VarSpec* vs = nullptr;
         for (const auto& v : c->vars) if (v.name == kv.first + "/weights") vs = &v;
         if (!vs) continue;
-        const int N = (int)vs->shape[3], Kpad = (int)(9 * vs->shape[2]);
+        const int N = (int)vs->shape[3], Kpad = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]);
         rc = h2_filter_pack_launch(c->p("pk:" + vs->name), N, Kpad, c->p("pkh:" + vs->name), reinterpret_cast<unsigned*>(c->p("h2s") + 6),
                                    c->p("h2s") + kv.second, s);
         if (rc) return rc;
