@@ -11,10 +11,12 @@
 // kernel is used only where the operands' magnitudes are known, and both are scaled into the middle of that range by exact powers
 // of two:
 //   * filters: per layer, 2^kw with max |w| 2^kw in [512, 1024) (h2_filter_pack: absmax on the device, planes [K/16][2][N][16]);
-//   * activations: the plane-writing pass (p3.hip, format 1) knows the batch-norm that produced them - relu(gamma x^ + beta) is bounded
-//     by |beta| + 8 |gamma| except for > 8 sigma outliers - and scales by 2^ka with (max_c |beta_c| + 8 |gamma_c|) 2^ka in [512, 1024),
-//     saturating at +-65000 (an outlier 64 times the 8-sigma bound); exact zeros (ReLU) stay exact.
-// The epilogue multiplies the tile by 2^-(ka + kw) (exact).  Measured against the fp64 oracle this path is as accurate as the
+//   * activations: the plane-writing pass (p3.hip, format 1) derives 2^ka from STATISTICS the forward already holds - channel c of
+//     relu(bn(y)) has mean beta_c and standard deviation |gamma_c| sqrt(var_c / (var_c + eps)); the residual branch of a block merge adds
+//     the bound of the block input (tracked from pass to pass) or, behind a 1x1 projection, |mean| + 8 sigma of the projection's output
+//     (its conv accumulates (sum, sumsq) like the batch-norm convs do): bound = max_c(|beta_c| + 8 std_c) [+ residual bound] is scaled
+//     into [512, 1024) and the planes saturate at +-65000 - 64 times beyond eight standard deviations; exact zeros (ReLU) stay exact.
+// The epilogue multiplies the tile by 2^-(ka + kw) (exact).  Measured against an fp64 evaluation of the network this path is as accurate as the
 // six-product bf16x3 path (fewer products = fewer fp32 accumulation roundings): DESIGN.md 3.2, profiles/r04_accuracy_modes.jsonl.
 //
 // Everything else is conv3p_kernel: P layout [Cin/16][NP][2 planes][16 ch] fp16 (64 B per pixel and chunk), NP = B*H*(W+1) with one
