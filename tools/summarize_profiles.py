@@ -63,7 +63,7 @@ json.dump(traffic, open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1
 label = {}
 wsum = collections.defaultdict(lambda: [0.0, 0.0])
 for k, v in traffic.items():
-    if k.startswith('igemm_kernel<') or k.startswith('igemm3s2_kernel<') or k.startswith('conv3p_kernel<'):
+    if k.startswith(('igemm_kernel<', 'igemm3s2_kernel<', 'conv3p_kernel<', 'conv3h_kernel<', 'conv3g_kernel<')) or k.startswith(('stem8pool_kernel', 'p3_pack_kernel')):
         label[k.replace(' ', '')] = round(v['hbm_bytes_fetch_x2'])
     elif k.startswith('igemm3_kernel<') or k.startswith('igemm3dw_kernel<'):
         # the runtime labels the bf16x3 kernels without their last template argument (batch-norm prologue flag):
@@ -90,5 +90,5 @@ if os.path.exists(b):
     open(os.path.join(dst, tag + '_bench_under_rocprof.json'), 'w').write(open(b).read())
 print(open(os.path.join(dst, tag + '_kernel_stats.csv')).read())
 for k, v in sorted(keep.items()):
-    if 'igemm' in k or 'conv3p' in k or 'p3_' in k or 'wgrad' in k or 'bwd' in k:
+    if 'igemm' in k or 'conv3' in k or 'p3_' in k or 'stem8' in k or 'wgrad' in k or 'bwd' in k:
         print(k, {c: ('%.4g' % x) for c, x in v.items() if not c.startswith('launches')})
