@@ -77,7 +77,9 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     for (int i = tid; i < S8_W_BYTES / 16; i += S8_THREADS) {
         const int row = i >> 1, hf = i & 1;
         const int kp = row >> 5, n = row & 31;
-        reinterpret_cast<f32x4*>(wl)[i] = *reinterpret_cast<const f32x4*>(wplanes + ((long)(kp * 64 + nh * 32 + n) * 32 + 16 * hf));
+        // (the two 16-byte halves of a 32-byte row swapped in rows 8-15 / 24-31: lanes li and li + 8 of a fragment read would
+        //  otherwise hit the same banks - 49 % of the LDS cycles were conflict cycles, profiles/r04_pmc_per_launch.json)
+        reinterpret_cast<f32x4*>(wl)[i] = *reinterpret_cast<const f32x4*>(wplanes + ((long)(kp * 64 + nh * 32 + n) * 32 + 16 * (hf ^ ((n >> 3) & 1))));
     }
     if (tid < S8_NH) {
         double s = 0.0;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
             const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + aoff + ((ks >> 1) * (2 * PCH) + (ks & 1) * 4) * 8);
             bf16x8 fb[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + ((ks * 3 + pl) * S8_NH + li) * 32 + 16 * g);
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + ((ks * 3 + pl) * S8_NH + li) * 32 + 16 * (g ^ ((li >> 3) & 1)));
             const int a = ks & 1;                    // u' x W_lo, x W_mid, x W_hi on accumulators a, a^1, a | a^1, a, a^1 | ...
             acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[2], acc[a], 0, 0, 0);
             acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[1], acc[a ^ 1], 0, 0, 0);
