@@ -69,6 +69,15 @@ size_t p3h_bytes(int B, int H, int W, int C) { return (size_t)(C / 16) * B * H *
 // eight standard deviations, then saturation.  Every block derives the same value; block 0 publishes 2^-ka (read by conv3h_kernel's
 // epilogue) and the bound itself (the residual bound of the next merge).  Without a BnRef the scale is 1.
 
+__device__ __forceinline__ float wave_max_f(float v) {              // max over the wavefront (values >= 0), by DPP / permlane swaps
+    v = fmaxf(v, dpp_mov<0xB1>(v, v)); v = fmaxf(v, dpp_mov<0x4E>(v, v));
+    { float t = dpp_mov<0x104, 0x5>(v, v); t = dpp_mov<0x114, 0xA>(t, v); v = fmaxf(v, t); }
+    { float t = dpp_mov<0x108, 0x3>(v, v); t = dpp_mov<0x118, 0xC>(t, v); v = fmaxf(v, t); }
+    { float a = v, b = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); v = fmaxf(a, b); }
+    { float a = v, b = v; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); v = fmaxf(a, b); }
+    return v;
+}
+
 __device__ __forceinline__ float p3h_act_scale(const BnRef& bn, const P3hScale& h, bool has_res, int C, unsigned* s_bits) {
     if (threadIdx.x < 2) s_bits[threadIdx.x] = 0u;
     __syncthreads();
@@ -100,6 +109,60 @@ __device__ __forceinline__ float p3h_act_scale(const BnRef& bn, const P3hScale& 
     return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
 }
 
+// Both tables in ONE pass over the channels (one round trip to the statistics, two barriers): the batch-norm coefficients and, for
+// the fp16x2 format, the activation scale (p3h_act_scale above is the same computation on its own).
+template <bool H2>
+__device__ __forceinline__ float p3_tables(const float* scale, const float* shift, const BnRef& bn, const P3hScale& h, bool has_res, int C,
+                                           float (*tab)[P3_MAX_C], unsigned* s_bits) {
+    if (H2 && threadIdx.x < 2) s_bits[threadIdx.x] = 0u;
+    if (H2) __syncthreads();
+    float m = 0.f, mr = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sc = 1.f, sh = 0.f;
+        if (bn.acc != nullptr) {
+            const double mean = bn.acc[c] * bn.inv_count;
+            double var = bn.acc[C + c] * bn.inv_count - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double inv = 1.0 / sqrt(var + (double)bn.eps);
+            const double a = (double)bn.gamma[c] * inv;
+            sc = (float)a;
+            sh = (float)((double)bn.beta[c] - mean * a);
+            if (H2) {
+                m = fmaxf(m, fabsf(bn.beta[c]) + 8.f * fabsf(bn.gamma[c]) * (float)(sqrt(var) * inv));
+                if (has_res && h.res_acc != nullptr) {
+                    const double rm = h.res_acc[c] * h.res_inv_count;
+                    double rv = h.res_acc[C + c] * h.res_inv_count - rm * rm;
+                    rv = rv < 0.0 ? 0.0 : rv;
+                    mr = fmaxf(mr, (float)(fabs(rm) + 8.0 * sqrt(rv)));
+                }
+            }
+        } else if (scale != nullptr) {
+            sc = scale[c];
+            sh = shift[c];
+        }
+        tab[0][c] = sc;
+        tab[1][c] = sh;
+    }
+    if (H2 && bn.acc != nullptr) {
+        m = wave_max_f(m); mr = wave_max_f(mr);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&s_bits[0], __builtin_bit_cast(unsigned, m));        // non-negative floats order like their bit patterns
+            atomicMax(&s_bits[1], __builtin_bit_cast(unsigned, mr));
+        }
+    }
+    __syncthreads();
+    if (!H2) return 1.f;
+    float bound = __builtin_bit_cast(float, s_bits[0]) + __builtin_bit_cast(float, s_bits[1]);
+    if (has_res && h.res_acc == nullptr && h.res_bound != nullptr) bound += h.res_bound[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && h.bound_out != nullptr) h.bound_out[0] = bound;
+    const unsigned b = __builtin_bit_cast(unsigned, bound);
+    const int e = (int)((b >> 23) & 0xff);
+    float sa = 1.f;
+    if (bn.acc != nullptr && e != 0 && e != 255) sa = __builtin_bit_cast(float, (unsigned)(127 + max(-60, min(60, 127 + 9 - e))) << 23);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && h.a_inv) h.a_inv[0] = 1.f / sa;
+    return sa;
+}
+
 __device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c8, const float (&v)[8], float sa) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 hi, lo;
@@ -123,15 +186,10 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
     const long total = nrows * (W + 1) * C8;             // padded pixels x channel octets (the grid stride is a multiple of C8)
     const long cstride = nrows * (W + 1) * (H2 ? 64 : 96);
     __shared__ unsigned s_bits[2];
-    float sa = 1.f;
-    if (H2) {
-        sa = p3h_act_scale(bn, h2, res != nullptr, C, s_bits);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && h2.a_inv) h2.a_inv[0] = 1.f / sa;
-    }
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
-    p3_bn_table(scale, shift, bn, C, tab);
+    const float sa = p3_tables<H2>(scale, shift, bn, h2, res != nullptr, C, tab, s_bits);
     const float4 sc0 = *reinterpret_cast<const float4*>(&tab[0][8 * c8]), sc1 = *reinterpret_cast<const float4*>(&tab[0][8 * c8 + 4]);
     const float4 sh0 = *reinterpret_cast<const float4*>(&tab[1][8 * c8]), sh1 = *reinterpret_cast<const float4*>(&tab[1][8 * c8 + 4]);
     for (long i = t0; i < total; i += (long)gridDim.x * 256) {
@@ -211,15 +269,10 @@ __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict
     const long total = nrows * (Wo + 1) * C8;
     const long cstride = nrows * (Wo + 1) * (H2 ? 64 : 96);
     __shared__ unsigned s_bits[2];
-    float sa = 1.f;
-    if (H2) {
-        sa = p3h_act_scale(bn, h2, false, C, s_bits);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && h2.a_inv) h2.a_inv[0] = 1.f / sa;
-    }
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
-    p3_bn_table(scale, shift, bn, C, tab);
+    const float sa = p3_tables<H2>(scale, shift, bn, h2, false, C, tab, s_bits);
     const float4 sc0 = *reinterpret_cast<const float4*>(&tab[0][8 * c8]), sc1 = *reinterpret_cast<const float4*>(&tab[0][8 * c8 + 4]);
     const float4 sh0 = *reinterpret_cast<const float4*>(&tab[1][8 * c8]), sh1 = *reinterpret_cast<const float4*>(&tab[1][8 * c8 + 4]);
     const bool has_bn = scale != nullptr || bn.acc != nullptr;
