@@ -31,11 +31,14 @@ namespace sagen {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int conv3h_lds(int BM, int BN) { return 2 * (BM * 64 + 3 * 2 * BN * 32) + 256; }
-constexpr int conv3h_wgs_per_cu(int BM, int BN) { return 160 * 1024 / conv3h_lds(BM, BN) >= 3 ? 3 : (160 * 1024 / conv3h_lds(BM, BN) >= 2 ? 2 : 1); }
+// KC = 16-channel chunks per barrier step (group): the deep layers (Cin 256 / 512: 48 / 96 groups of only 9*MT*NT MFMAs) are bound by
+// the per-group latency (barrier, DMA round trip, first fragments) - two chunks per group halve the groups.  No slack behind the ring:
+// the fragment reads of the two dropped rows run past the activation image into the filter image of the SAME stage.
+constexpr int conv3h_lds(int BM, int BN, int KC) { return 2 * KC * (BM * 64 + 3 * 2 * BN * 32); }
+constexpr int conv3h_wgs_per_cu(int BM, int BN, int KC) { return 160 * 1024 / conv3h_lds(BM, BN, KC) >= 3 ? 3 : (160 * 1024 / conv3h_lds(BM, BN, KC) >= 2 ? 2 : 1); }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(const IgemmDesc d) {
+template <int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_kernel(const IgemmDesc d) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
@@ -45,18 +48,19 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
     constexpr int B_INST = 3 * B_IPT;
     constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;
     constexpr int A_BYTES = A_INST * 1024, B_BYTES = B_INST * 1024;
-    constexpr int ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int ST_BYTES = KC * (A_BYTES + B_BYTES);     // a stage: the KC activation images, then the KC filter images
     constexpr int NM1 = 3 * MT * NT;                       // MFMAs per tap
-    constexpr int NMG = 3 * NM1;
-    constexpr int CNT_MAX = A_PW + B_PW;
+    constexpr int NMG = 3 * KC * NM1;
+    constexpr int SPT = A_PW + B_PW;                       // DMA slots per wave and chunk
+    constexpr int CNT_MAX = KC * SPT;
     static_assert(CNT_MAX <= NMG, "one DMA slot per MFMA slot at most");
     constexpr int NF = 2 * (MT + NT);
     constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
     static_assert(WM % RPP == 0, "a wave row is a whole number of store passes");
     constexpr int EPI_TILE = WM * BN * 4, EPI_DENSE = BM * 4, EPI_RED = 2 * RPP * BN * 4;
-    constexpr int SMEM_BYTES = 2 * ST_BYTES + 256;         // +256: fragment reads of the dropped rows
+    constexpr int SMEM_BYTES = 2 * ST_BYTES;
     static_assert(EPI_TILE + EPI_DENSE + EPI_RED <= SMEM_BYTES, "epilogue staging must fit the ring");
-    static_assert(SMEM_BYTES == conv3h_lds(BM, BN), "occupancy bound uses the same footprint");
+    static_assert(SMEM_BYTES == conv3h_lds(BM, BN, KC), "occupancy bound uses the same footprint");
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // ONE shared object (conv3p.hip)
 
     const int tid = threadIdx.x;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int W = d.Win, H = d.Hin, Wp = W + 1, NP = d.p3_np;
     const int nchunk = d.Cin >> 4;
-    const int G = 3 * nchunk;
+    const int G = 3 * nchunk / KC;                         // (nchunk % KC == 0: conv3h_dispatch)
     const int nM = (NP + BME - 1) / BME, nN = (d.N + BN - 1) / BN;
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.xp3, 0, d.xp3_bytes, 0x00020000);
@@ -127,18 +131,21 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
         }
         i_asoff = (unsigned)q_ch * d.xp3_cstride;
         i_bsoff = (unsigned)((q_dh * 3) * nchunk + q_ch) * (unsigned)(d.N * 64);
-        ++q_ch;
+        q_ch += KC;
         if (q_ch == nchunk) { q_ch = 0; ++q_dh; }
     };
-    auto issue_one = [&](int s) {               // s = compile-time slot index: A slots first, then B slots
+    auto issue_one = [&](int sg) {              // sg = compile-time slot index of the group: chunk kc, then A slots first, then B slots
+        const int kc = sg / SPT, s = sg - kc * SPT;
         if (s < A_PW) {
             const int inst = wave + 4 * s;
-            if (A_INST % 4 == 0 || inst < A_INST) dma16(x_rsrc, (float*)(i_stage + inst * 1024), a_cur[s], i_asoff);
+            if (A_INST % 4 == 0 || inst < A_INST)
+                dma16(x_rsrc, (float*)(i_stage + kc * A_BYTES + inst * 1024), a_cur[s], i_asoff + (unsigned)kc * d.xp3_cstride);
         } else {
             const int j = s - A_PW;
             const int inst = wave + 4 * j;
             if (4 * (j + 1) <= B_INST || inst < B_INST)
-                dma16(w_rsrc, (float*)(i_stage + A_BYTES + inst * 1024), b_voff[j], i_bsoff + (unsigned)b_tapoff[j]);
+                dma16(w_rsrc, (float*)(i_stage + KC * A_BYTES + kc * B_BYTES + inst * 1024), b_voff[j],
+                      i_bsoff + (unsigned)b_tapoff[j] + (unsigned)(kc * d.N * 64));
         }
     };
 
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
             const int sl = wm * WM + i * 32 + li + dwi;              // output row r sits at slot r + 1; tap dw reads slot r + dw
             a_foff[dwi][i] = sl * 64 + 16 * (kk ^ ((sl >> 2) & 3));
         }
-    const int b_foff = A_BYTES + (wn * WN + li) * 32 + 16 * (kk ^ ((li >> 3) & 1));
+    const int b_foff = KC * A_BYTES + (wn * WN + li) * 32 + 16 * (kk ^ ((li >> 3) & 1));
     constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};             // lo*hi, hi*lo, hi*hi
 
     int stage = 0;
@@ -174,16 +181,17 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
         constexpr bool ISSUE = decltype(issue_tag)::value;
         const char* st = smem + stage * ST_BYTES;
         f16x8 fq[2][NF];                                             // [buffer][plane * (MT+NT) + (i | MT + j)]
-        auto load_frag = [&](int buf, int dwi, int f) {
+        auto load_frag = [&](int buf, int t, int f) {               // t = kc*3 + dwi: the (chunk, horizontal tap) step inside the group
+            const int kc = t / 3, dwi = t - 3 * kc;
             const int pl = f / (MT + NT), r = f - pl * (MT + NT);
-            if (r < MT) fq[buf][f] = *reinterpret_cast<const f16x8*>(st + (a_foff[dwi][r] ^ (pl * 32)));
-            else fq[buf][f] = *reinterpret_cast<const f16x8*>(st + b_foff + (dwi * 2 + pl) * (BN * 32) + (r - MT) * 32 * 32);
+            if (r < MT) fq[buf][f] = *reinterpret_cast<const f16x8*>(st + kc * A_BYTES + (a_foff[dwi][r] ^ (pl * 32)));
+            else fq[buf][f] = *reinterpret_cast<const f16x8*>(st + b_foff + kc * B_BYTES + (dwi * 2 + pl) * (BN * 32) + (r - MT) * 32 * 32);
         };
 #pragma unroll
         for (int f = 0; f < NF; ++f) load_frag(0, 0, f);
 #pragma unroll
-        for (int dwi = 0; dwi < 3; ++dwi) {
-            const int cb = dwi & 1;
+        for (int t = 0; t < 3 * KC; ++t) {
+            const int cb = t & 1;
 #pragma unroll
             for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
@@ -191,18 +199,18 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const int k = (tt * MT + i) * NT + j;
-                        const int idx = dwi * NM1 + k;
+                        const int idx = t * NM1 + k;
                         __builtin_amdgcn_sched_barrier(0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[cb][TA[tt] * (MT + NT) + i], fq[cb][TB[tt] * (MT + NT) + MT + j],
                                                                            acc[i][j], 0, 0, 0);
-                        if (dwi < 2) {
+                        if (t + 1 < 3 * KC) {
 #pragma unroll
                             for (int f = 0; f < NF; ++f)
-                                if (f * NM1 / NF == k) load_frag(cb ^ 1, dwi + 1, f);
+                                if (f * NM1 / NF == k) load_frag(cb ^ 1, t + 1, f);
                         }
 #pragma unroll
-                        for (int s = 0; s < CNT_MAX; ++s)
-                            if (ISSUE && idx == s) issue_one(CNT_MAX - 1 - s);
+                        for (int sg = 0; sg < CNT_MAX; ++sg)
+                            if (ISSUE && idx == sg) issue_one(CNT_MAX - 1 - sg);
                     }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -297,11 +305,12 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN)) void conv3h_kernel(
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KC>
 static int launch_conv3h(const IgemmDesc& d, hipStream_t s) {
+    if ((d.Cin / 16) % KC) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: %d channel chunks are not a multiple of %d per group", d.Cin / 16, KC);
     const int per = (cdiv(d.p3_np, BM - 2) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
-    hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), 0, s, d);
+    hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -318,10 +327,13 @@ int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)(d.Win + 1)) + 1u;
     d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hin) + 1u;
     switch (tile) {
-        case TILE_P3H_128x64: return launch_conv3h<128, 64, 64, 32>(d, s);
-        case TILE_P3H_128x128: return launch_conv3h<128, 128, 64, 64>(d, s);
-        case TILE_P3H_64x64: return launch_conv3h<64, 64, 32, 32>(d, s);
-        case TILE_P3H_256x64: return launch_conv3h<256, 64, 64, 64>(d, s);
+        case TILE_P3H_128x64: return launch_conv3h<128, 64, 64, 32, 1>(d, s);
+        case TILE_P3H_128x128: return launch_conv3h<128, 128, 64, 64, 1>(d, s);
+        case TILE_P3H_64x64: return launch_conv3h<64, 64, 32, 32, 1>(d, s);
+        case TILE_P3H_256x64: return launch_conv3h<256, 64, 64, 64, 1>(d, s);
+        case TILE_P3H_128x64_C2: return launch_conv3h<128, 64, 64, 32, 2>(d, s);
+        case TILE_P3H_64x64_C2: return launch_conv3h<64, 64, 32, 32, 2>(d, s);
+        case TILE_P3H_64x64_C4: return launch_conv3h<64, 64, 32, 32, 4>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: bad tile id %d", (int)tile);
     }
 }

@@ -325,10 +325,12 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 16, "conv3pp_kernel<0>", true, true, false, true},          {128, 64, 16, "conv3pp_kernel<1>", true, true, false, true},
     {128, 64, 16, "conv3g_kernel<128,64,64,32,2,false>", true, false, false, true, true}, {64, 64, 16, "conv3g_kernel<64,64,32,32,2,false>", true, false, false, true, true},
     {64, 128, 16, "conv3g_kernel<64,128,32,64,2,false>", true, false, false, true, true}, {128, 128, 16, "conv3g_kernel<128,128,64,64,1,false>", true, false, false, true, true},
-    {128, 64, 16, "conv3h_kernel<128,64,64,32>", true, true, false, true, false, true},   {128, 128, 16, "conv3h_kernel<128,128,64,64>", true, true, false, true, false, true},
-    {64, 64, 16, "conv3h_kernel<64,64,32,32>", true, true, false, true, false, true},      {256, 64, 16, "conv3h_kernel<256,64,64,64>", true, true, false, true, false, true},
+    {128, 64, 16, "conv3h_kernel<128,64,64,32,1>", true, true, false, true, false, true},   {128, 128, 16, "conv3h_kernel<128,128,64,64,1>", true, true, false, true, false, true},
+    {64, 64, 16, "conv3h_kernel<64,64,32,32,1>", true, true, false, true, false, true},      {256, 64, 16, "conv3h_kernel<256,64,64,64,1>", true, true, false, true, false, true},
     {128, 64, 16, "conv3g_kernel<128,64,64,32,3,true>", true, false, false, true, true, true},   {64, 64, 16, "conv3g_kernel<64,64,32,32,4,true>", true, false, false, true, true, true},
     {128, 128, 16, "conv3g_kernel<128,128,64,64,2,true>", true, false, false, true, true, true}, {64, 128, 16, "conv3g_kernel<64,128,32,64,3,true>", true, false, false, true, true, true},
+    {128, 64, 32, "conv3h_kernel<128,64,64,32,2>", true, true, false, true, false, true}, {64, 64, 32, "conv3h_kernel<64,64,32,32,2>", true, true, false, true, false, true},
+    {64, 64, 64, "conv3h_kernel<64,64,32,32,4>", true, true, false, true, false, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {

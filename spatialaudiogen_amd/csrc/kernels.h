@@ -110,6 +110,8 @@ enum IgemmTile {
     TILE_P3H_128x64, TILE_P3H_128x128, TILE_P3H_64x64, TILE_P3H_256x64,
     // ... and for any strided / multi-tap conv over them (conv3g_kernel, gathered operand tiles)
     TILE_P3GH_128x64_K3, TILE_P3GH_64x64_K4, TILE_P3GH_128x128_K2, TILE_P3GH_64x128_K3,
+    // conv3h_kernel with two / four 16-channel chunks per barrier step (the deep, latency-bound layers)
+    TILE_P3H_128x64_C2, TILE_P3H_64x64_C2, TILE_P3H_64x64_C4,
     TILE_AUTO
 };
 
