@@ -391,4 +391,59 @@ int h2_filter_pack_launch(const float* wp, int N, int Kpad, void* w2, unsigned* 
     return SAGEN_OK;
 }
 
+
+// ---- the same for MANY layers in two launches (bind; and once per training step, after the optimiser rewrote the variables) ----
+__global__ __launch_bounds__(256) void h2_absmax_multi_kernel(const H2Job* __restrict__ jobs, int njobs, unsigned* __restrict__ amax) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+    const H2Job job = jobs[j];
+    const long total = (long)job.N * job.Kpad;
+    const long i0 = ((long)blockIdx.x - job.first_block) * 1024 + threadIdx.x;
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i = i0 + 256 * k;
+        if (i < total) m = fmaxf(m, fabsf(job.wp[i]));
+    }
+    __shared__ unsigned s_m;
+    if (threadIdx.x == 0) s_m = 0u;
+    __syncthreads();
+    atomicMax(&s_m, __builtin_bit_cast(unsigned, m));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&amax[j], s_m);
+}
+
+__global__ __launch_bounds__(256) void h2_filter_pack_multi_kernel(const H2Job* __restrict__ jobs, int njobs, const unsigned* __restrict__ amax) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+    const H2Job job = jobs[j];
+    const float sc = h2_scale_for(__builtin_bit_cast(float, amax[j]));
+    if ((int)blockIdx.x == job.first_block && threadIdx.x == 0) job.w_inv[0] = 1.f / sc;
+    const long total = (long)job.N * job.Kpad;
+    const long i0 = ((long)blockIdx.x - job.first_block) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long idx = i0 + 256 * k;
+        if (idx >= total) continue;
+        const long n = idx / job.Kpad;
+        const int kk = (int)(idx - n * job.Kpad);
+        const float v = job.wp[idx] * sc;
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        const long o = ((long)(kk >> 4) * 2 * job.N + n) * 16 + (kk & 15);
+        reinterpret_cast<_Float16*>(job.w2)[o] = h;
+        reinterpret_cast<_Float16*>(job.w2)[o + (long)job.N * 16] = l;
+    }
+}
+
+int h2_filter_pack_multi_launch(const H2Job* jobs_dev, int njobs, int nblocks, unsigned* amax, hipStream_t s) {
+    if (njobs <= 0) return SAGEN_OK;
+    if (!jobs_dev || !amax) return fail(SAGEN_ERR_NULL, "h2_filter_pack_multi: null argument");
+    SAGEN_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)njobs * sizeof(unsigned), s));
+    hipLaunchKernelGGL(h2_absmax_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs, amax);
+    hipLaunchKernelGGL(h2_filter_pack_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs, amax);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 }  // namespace sagen

@@ -130,6 +130,13 @@ int conv3p_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (co
 int conv3g_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3g.hip)
 int conv3h_dispatch(const IgemmDesc& d, IgemmTile tile, hipStream_t s);   // (conv3h.hip)
 int h2_filter_pack_launch(const float* wp, int N, int Kpad, void* w2, unsigned* scratch, float* w_inv, hipStream_t s);
+struct H2Job {                       // one layer of the batched fp16x2 filter pack (1024 elements per block)
+    const float* wp = nullptr;       // fp32 packed filter [N][Kpad]
+    void* w2 = nullptr;              // out: two fp16 planes [Kpad/16][2][N][16] of w * 2^kw
+    float* w_inv = nullptr;          // out: 2^-kw
+    int N = 0, Kpad = 0, first_block = 0, pad_ = 0;
+};
+int h2_filter_pack_multi_launch(const H2Job* jobs_dev, int njobs, int nblocks, unsigned* amax, hipStream_t s);
 bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel can run (given planes)
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
 bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)

@@ -99,8 +99,11 @@ struct sagen_ctx {
     bool materialize_mask = false;         // sagen_set_option("materialize_mask"): keep deconv1 -> mask as two kernels so that the logits exist
     bool mask_fused_last = false;          // the last forward ran the fused decoder tail: "separation/deconv1" holds no logits
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
+    bool train_h2 = true;                  // the training step's forward also runs the trunk's stride-1 3x3 convs on the fp16x2 planes (SAGEN_TRAIN_NO_H2=1: bf16x3)
     bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
     std::map<std::string, int> h2_slot;    // per layer: index of its 2^-kw in the "h2s" table
+    std::vector<H2Job> h2_jobs;            // the batched fp16x2 filter pack (host copy of the job table)
+    int h2_blocks = 0;
     bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
     bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels
     size_t tws_floats = 0;
@@ -433,8 +436,9 @@ struct Fwd {
         gemm(d);
     }
 
-    // fp16x2 planes (conv3h.hip) for this forward?  (inference only: the training step keeps the bf16x3 planes its backward was verified with)
-    bool h2() const { return c->use_h2 && c->use_p3 && !c->train_mode && !c->fp32_only; }
+    // fp16x2 planes (conv3h.hip) for this forward?  (the training step's forward too, unless SAGEN_TRAIN_NO_H2=1: its backward reads the
+    // retained fp32 activations, not the planes)
+    bool h2() const { return c->use_h2 && c->use_p3 && !c->fp32_only && (!c->train_mode || c->train_h2); }
     int p3_fmt() const { return h2() ? 1 : 0; }
     float* h2_a_inv() { return c->p("h2s") + (sfx.empty() ? 0 : 1); }        // 2^-ka of the planes currently in this trunk's plane buffer
     // statistical bound of the current block input / output (conv3h.hip, p3.hip: P3hScale), two slots used alternately so that a merge
@@ -715,6 +719,7 @@ struct Fwd {
         }
         const float* xin = c->p("t:x0" + sfx);
         int cin = 64;
+        int xb_par = 0;
         const int couts[4] = {64, 128, 256, 512};
         for (int st = 0; st < 4; ++st) {
             const int cout = couts[st];
@@ -725,14 +730,15 @@ struct Fwd {
                 const int stride = first ? 2 : 1;
                 int Ho = 0, Wo = 0, H2, W2;
                 const float* shortcut = xin;
+                const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage && st + 2 >= 3;   // (the pool writes no planes here)
                 if (first) {
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
                                             cout, c->p("rsc" + sfx), cout, Ho, Wo);
+                    if (h2() && p3_here) d.stats = bn_acc(20 + st);      // the projection's (sum, sumsq): the residual bound of the merge's fp16 scale
                     layer = pfx + "/shortcut";
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage && st + 2 >= 3;   // (the pool writes no planes here)
                 void* planes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;
                 float* y1 = c->p("t:y1:" + k); float* a1 = c->p("t:a1:" + k); float* y2 = c->p("t:y2:" + k); float* xout = c->p("t:out:" + k);
                 // unit 2 of a plane stage finds the planes of its input written by unit 1's merge
@@ -741,13 +747,17 @@ struct Fwd {
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 layer = pfx + "/bn1-relu";
-                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y1, nullptr, nullptr, bn1, nullptr, 1, a1, planes, B, Ho, Wo, cout, s); });
+                const P3hScale hs1 = h2_scale();
+                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y1, nullptr, nullptr, bn1, nullptr, 1, a1, planes, B, Ho, Wo, cout, s, p3_fmt(), &hs1); });
                 else timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(y1, nullptr, nullptr, bn1, nullptr, a1, (long)B * Ho * Wo, cout, s); });
                 conv_bn(a1, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), y2, H2, W2, li, p3_here ? "" : pfx + "/conv_2#mat", planes);
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 ++li;
                 layer = pfx + "/merge";
-                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y2, nullptr, nullptr, bn2, shortcut, 1, xout, unit == 1 ? planes : nullptr, B, Ho, Wo, cout, s); });
+                const P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
+                                           : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
+                if (p3_here) xb_par ^= 1;
+                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y2, nullptr, nullptr, bn2, shortcut, 1, xout, unit == 1 ? planes : nullptr, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
                 else timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(y2, nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
                 xin = xout;
                 H = Ho; W = Wo; cin = cout;

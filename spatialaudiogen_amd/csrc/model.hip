@@ -38,6 +38,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
     c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
     c->use_h2 = getenv("SAGEN_NO_H2") == nullptr;
+    c->train_h2 = getenv("SAGEN_TRAIN_NO_H2") == nullptr;
     // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
     // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
     if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;
@@ -137,6 +138,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
             c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = slot;
         }
     }
+    c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
+    c->alloc("h2:amax", c->h2_slot.size() + 64);
     c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [8..] 2^-kw per layer
     c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
     // activations
@@ -224,6 +227,7 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
     }
     c->var_ptr = ptr;
     c->pack_jobs.clear();                 // (the table holds the variables' addresses)
+    c->h2_jobs.clear();
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     rc = sagen_repack_impl(c, s);
@@ -285,18 +289,29 @@ int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
         if (c->pack_blocks < 0) return fail(SAGEN_ERR_HIP, "pack job upload failed");
     }
     int rc = pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pk:jobs")), (int)c->pack_jobs.size(), c->pack_blocks, s);
-    if (rc || c->train_mode || c->fp32_only) return rc;
-    // inference: the fp16x2 filter planes of the trunk's 3x3 convs, from the fp32 packs just written (bind time only)
-    for (const auto& kv : c->h2_slot) {
-        const VarSpec* vs = nullptr;
-        for (const auto& v : c->vars) if (v.name == kv.first + "/weights") vs = &v;
-        if (!vs) continue;
-        const int N = (int)vs->shape[3], Kpad = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]);
-        rc = h2_filter_pack_launch(c->p("pk:" + vs->name), N, Kpad, c->p("pkh:" + vs->name), reinterpret_cast<unsigned*>(c->p("h2s") + 6),
-                                   c->p("h2s") + kv.second, s);
-        if (rc) return rc;
+    if (rc || c->fp32_only || !c->use_p3) return rc;
+    // the fp16x2 filter planes of the trunks' 3x3 convs and 1x1 projections, from the fp32 packs just written: two launches for all
+    // of them (bind; every training step)
+    if (c->h2_jobs.empty()) {
+        int nb = 0;
+        for (const auto& kv : c->h2_slot) {
+            const VarSpec* vs = nullptr;
+            for (const auto& v : c->vars) if (v.name == kv.first + "/weights") vs = &v;
+            if (!vs) continue;
+            H2Job j;
+            j.N = (int)vs->shape[3]; j.Kpad = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]);
+            j.wp = c->p("pk:" + vs->name); j.w2 = c->p("pkh:" + vs->name); j.w_inv = c->p("h2s") + kv.second;
+            j.first_block = nb;
+            nb += (int)(((long)j.N * j.Kpad + 1023) / 1024);
+            c->h2_jobs.push_back(j);
+        }
+        c->h2_blocks = nb;
+        if (c->h2_jobs.size() * sizeof(H2Job) > c->bufs.at("h2:jobs").n * sizeof(float)) return fail(SAGEN_ERR_WORKSPACE, "fp16x2 job table too small");
+        if (!c->h2_jobs.empty() && hipMemcpyAsync(c->p("h2:jobs"), c->h2_jobs.data(), c->h2_jobs.size() * sizeof(H2Job), hipMemcpyHostToDevice, s) != hipSuccess)
+            return fail(SAGEN_ERR_HIP, "fp16x2 job upload failed");
     }
-    return SAGEN_OK;
+    return h2_filter_pack_multi_launch(reinterpret_cast<const H2Job*>(c->p("h2:jobs")), (int)c->h2_jobs.size(), c->h2_blocks,
+                                       reinterpret_cast<unsigned*>(c->p("h2:amax")), s);
 }
 
 // ------------------------------------------------------------------------------------------------
