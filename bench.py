@@ -281,7 +281,10 @@ def main_train(args, cfg):
         'share_of_step_time': round(us_l / total_us, 3),
         'phases_us_per_step': {k: round(v[0] / nprof, 1) for k, v in sorted(by_phase.items())},
         'phases_tflops': {k: round(v[1] / (v[0] * 1e-6) / 1e12, 1) for k, v in sorted(by_phase.items()) if v[1] > 0},
-        'whole_step': {'achieved': round(step_tflops, 2), 'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+        'whole_step': {'achieved': round(step_tflops, 2), 'frac': round(step_tflops / PEAK_BF16X3_TFLOPS, 4),
+                       'frac_basis': 'all launched fp32-equivalent FLOPs of the step / step time, against the six-product bf16x3 roof (417 TFLOP/s) - the '
+                                     'family of the backward kernels; the forward trunk convs run on the three-product fp16x2 kernels',
+                       'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                        'gflop_per_window_launched': round(total_fl / nprof / BATCH / 1e9, 2),
                        'gflop_per_window_forward_needed_only': cfg['gflop'],
                        'kernel_time_us_per_step': round(total_us / nprof, 1)},
