@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     from spatialaudiogen_amd.model import SptAudioGen
     from oracle.np_oracle import SptAudioGenOracle
     mode = 'fp32_only' if os.environ.get('SAGEN_FP32_ONLY') else ('bf16x3' if os.environ.get('SAGEN_NO_H2') else
-            'bf16x3 + fp16x2 trunk planes from stage %s' % os.environ.get('SAGEN_P3_FROM_STAGE', '3'))
+            'bf16x3 + fp16x2 trunk planes from stage %s' % os.environ.get('SAGEN_P3_FROM_STAGE', '2 (default)'))
     also_conv5 = True
     for enc in (['audio'], ['audio', 'video'], ['audio', 'video', 'flow']):
         for seed in (0, 1):
@@ -28,6 +28,6 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
             print(json.dumps({'mode': mode, 'trunk_conv5_2_rel_err': trunk, 'encoders': '+'.join(e[0].upper() for e in enc), 'seed': seed, 'rms_err': err,
                               'out_rms': rms, 'rel': err / rms, 'max_abs_err': float(np.abs(out - ref).max())}), flush=True)
 else:
-    for env in ({}, {'SAGEN_P3_FROM_STAGE': '2'}, {'SAGEN_NO_H2': '1'}, {'SAGEN_FP32_ONLY': '1'}):
+    for env in ({}, {'SAGEN_P3_FROM_STAGE': '3'}, {'SAGEN_NO_H2': '1'}, {'SAGEN_FP32_ONLY': '1'}):
         e = dict(os.environ); e.update(env)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'child'], env=e)
