@@ -146,6 +146,13 @@ int    sagen_profile_enable(sagen_ctx* ctx, int on);
  * application as two kernels so that the logits exist in the workspace ("separation/deconv1" of sagen_get_intermediate); 0 lets the
  * forward fold sigmoid + track mix into the deconvolution's epilogue (same result, 94 MB less HBM traffic per batch of 32). */
 int    sagen_set_option(sagen_ctx* ctx, const char* name, int value);
+/* Further switches: "fp16x2" (default 1: the ResNet trunk's convs - resnet.py:141-236 - run on two fp16 planes per operand, three matrix
+ * products per multiply; 0: three bf16 planes, six products), "plane_gather", "u8_fast_stem", "planes_from_stage" (INTEGRATION.md 5).
+ * sagen_counter reads a diagnostic counter of the context after synchronising `stream`: "fp16x2_saturations" = activation elements the
+ * fp16x2 plane passes had to clamp to +-65000 since sagen_bind_weights (scales come from batch statistics with 64 x headroom beyond
+ * eight standard deviations: 0 unless an activation is not finite or that far out; > 0 means results of the affected forwards are
+ * not fp32-equivalent - rerun with "fp16x2" = 0). */
+int    sagen_counter(sagen_ctx* ctx, const char* name, uint64_t* value, void* stream);
 int    sagen_profile_report(sagen_ctx* ctx, char* buf, size_t buflen);
 
 /* ---- op-level (unit-testable; same conventions) ----------------------------------------- */

@@ -22,6 +22,7 @@ int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen);
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride);
 int sagen_set_option_impl(sagen_ctx* c, const char* name, int value);
+int sagen_counter_impl(sagen_ctx* c, const char* name, uint64_t* value, hipStream_t s);
 size_t sagen_train_workspace_bytes_impl(sagen_ctx* c);
 int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving, void* tws,
                           size_t tws_bytes, hipStream_t s);
@@ -102,6 +103,10 @@ int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float**
     return guarded([&] { return sagen_get_intermediate_impl(ctx, name, data, ndim, shape, pixel_stride); });
 }
 
+int sagen_counter(sagen_ctx* ctx, const char* name, uint64_t* value, void* stream) {
+    if (!ctx || !name || !value) return fail(SAGEN_ERR_NULL, "sagen_counter: null argument");
+    return guarded([&] { return sagen_counter_impl(ctx, name, value, (hipStream_t)stream); });
+}
 int sagen_set_option(sagen_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return fail(SAGEN_ERR_NULL, "sagen_set_option: null argument");
     return guarded([&] { return sagen_set_option_impl(ctx, name, value); });

@@ -222,6 +222,7 @@ struct P3hScale {
     const double* res_acc = nullptr;    // in: fp64 (sum, sumsq) [2][C] of the residual tensor (1x1 shortcut conv), or null
     double res_inv_count = 0.0;
     float* bound_out = nullptr;         // out: bound of the tensor written (null: not tracked)
+    unsigned* sat_count = nullptr;      // out: incremented once per element that had to be clamped to +-65000 (stays 0 unless the statistics lie)
 };
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
                    float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);

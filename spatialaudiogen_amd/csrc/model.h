@@ -447,6 +447,7 @@ struct Fwd {
     P3hScale h2_scale(float* bound_out = nullptr, const float* res_bound = nullptr, const double* res_acc = nullptr, double res_inv_count = 0.0) {
         P3hScale h;
         h.a_inv = h2_a_inv(); h.bound_out = bound_out; h.res_bound = res_bound; h.res_acc = res_acc; h.res_inv_count = res_inv_count;
+        h.sat_count = reinterpret_cast<unsigned*>(c->p("h2s") + 7);
         return h;
     }
 

@@ -140,7 +140,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     }
     c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
     c->alloc("h2:amax", c->h2_slot.size() + 64);
-    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [8..] 2^-kw per layer
+    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [7] saturation counter, [8..] 2^-kw per layer
     c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
     // activations
     c->alloc("mag", (size_t)B * 127 * 1024);
@@ -228,6 +228,7 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
     c->var_ptr = ptr;
     c->pack_jobs.clear();                 // (the table holds the variables' addresses)
     c->h2_jobs.clear();
+    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("h2s"), 0, 256 * sizeof(float), s));       // fp16x2 scales, bounds, saturation counter
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     rc = sagen_repack_impl(c, s);
@@ -586,6 +587,16 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     if (n == "planes_from_stage") { if (value < 2 || value > 6) return fail(SAGEN_ERR_SHAPE, "planes_from_stage in 2..6"); c->p3_from_stage = value; return SAGEN_OK; }
     if (n == "plane_gather") { c->use_p3g = c->use_p3 && value != 0; return SAGEN_OK; }
     return fail(SAGEN_ERR_UNSUPPORTED, "sagen_set_option: unknown option %s", name);
+}
+
+int sagen_counter_impl(sagen_ctx* c, const char* name, uint64_t* value, hipStream_t s) {
+    if (!c->ws) return fail(SAGEN_ERR_WORKSPACE, "no workspace bound");
+    if (std::string(name) != "fp16x2_saturations") return fail(SAGEN_ERR_UNSUPPORTED, "sagen_counter: unknown counter %s", name);
+    unsigned v = 0;
+    SAGEN_HIP_CHECK(hipMemcpyAsync(&v, c->p("h2s") + 7, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    SAGEN_HIP_CHECK(hipStreamSynchronize(s));
+    *value = v;
+    return SAGEN_OK;
 }
 
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],

@@ -163,11 +163,13 @@ __device__ __forceinline__ float p3_tables(const float* scale, const float* shif
     return sa;
 }
 
-__device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c8, const float (&v)[8], float sa) {
+__device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c8, const float (&v)[8], float sa, unsigned* sat_count) {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 hi, lo;
+    bool clamped = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        clamped = clamped || !(fabsf(v[k] * sa) <= 65000.f);
         const float t = fminf(fmaxf(v[k] * sa, -65000.f), 65000.f);
         hi[k] = (_Float16)t;
         lo[k] = (_Float16)(t - (float)hi[k]);
@@ -175,6 +177,7 @@ __device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c
     char* dst = p3 + (long)(c8 >> 1) * cstride + pp * 64 + (c8 & 1) * 16;
     *reinterpret_cast<h8*>(dst) = hi;
     *reinterpret_cast<h8*>(dst + 32) = lo;
+    if (clamped && sat_count) atomicAdd(sat_count, 1u);       // (never, unless a value lies 64 x beyond eight standard deviations - or is not finite)
 }
 
 template <bool H2>
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
         }
         if (p3) {
             if (H2) {
-                p3h_store(p3, cstride, pp, c8, v, sa);
+                p3h_store(p3, cstride, pp, c8, v, sa, h2.sat_count);
             } else {
                 u32x4 hi, mid, lo;
                 p3_split8(v, hi, mid, lo);
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict
         }
         if (p3) {
             if (H2) {
-                p3h_store(p3, cstride, pp, c8, v, sa);
+                p3h_store(p3, cstride, pp, c8, v, sa, h2.sat_count);
             } else {
                 u32x4 hi, mid, lo;
                 p3_split8(v, hi, mid, lo);

@@ -74,6 +74,12 @@ class _Ctx(object):
         """Per-context switch of the native library (sagen_set_option), e.g. 'materialize_mask'."""
         check(_lib.lib().sagen_set_option(self.handle, name.encode(), int(value)))
 
+    def counter(self, name):
+        """Diagnostic counter of the native context (sagen_counter), e.g. 'fp16x2_saturations'; synchronises the current stream."""
+        v = C.c_uint64(0)
+        check(_lib.lib().sagen_counter(self.handle, name.encode(), C.byref(v), C.c_void_p(torch.cuda.current_stream(self.workspace.device).cuda_stream)))
+        return int(v.value)
+
     def intermediate(self, name):
         l = _lib.lib()
         data, ndim, shape, ps = C.c_void_p(), C.c_int32(), (C.c_int64 * 4)(), C.c_int64()
@@ -258,6 +264,10 @@ class SptAudioGen(object):
 
     def intermediate(self, batch, name):
         return self.context_for(batch).intermediate(name)
+
+    def counter(self, batch, name):
+        """'fp16x2_saturations': activation elements the fp16x2 plane passes had to clamp since the weights were bound (expected: 0)."""
+        return self.context_for(batch).counter(name)
 
     def set_option(self, batch, name, value):
         """'materialize_mask' = 1: the next forwards keep the mask logits ('separation/deconv1') instead of folding the mask into the

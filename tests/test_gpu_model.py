@@ -269,9 +269,35 @@ def test_fp16x2_trunk_planes_hold_over_the_range_of_batch_norm_parameters(T, cas
     o2, o3 = rel_rms_err(got, ref), rel_rms_err(other, ref)
     print('\n[%s] conv5_2 rel err: fp16x2 %.3g, bf16x3 %.3g; output rel err: fp16x2 %.3g, bf16x3 %.3g (output rms %.3g)' % (case, e2, e3, o2, o3, rms(ref)))
     assert np.isfinite(got).all() and np.isfinite(trunk).all()
+    assert net.counter(B, 'fp16x2_saturations') == 0            # no activation had to be clamped: the statistical bounds held
     assert e2 < 1e-4 and o2 < 1e-3, (e2, o2)
     assert e2 <= 1.5 * e3 + 1e-7 and o2 <= 1.5 * o3 + 1e-7, (e2, e3, o2, o3)     # no less accurate than the six-product path
     assert rel_rms_err(trunk, trunk3) < 1e-4
+
+
+def test_fp16x2_saturation_counter_reports_what_the_planes_cannot_hold(T):
+    """The plane passes clamp to +-65000 and COUNT what they clamp (sagen_counter 'fp16x2_saturations'): 0 after ordinary forwards.
+    The scale exponent is limited to 2^+-60, so a batch-norm with gamma = 1e25 (activations of 1e25) cannot be brought into fp16's
+    range: the counter must say so."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    B = 2
+    P = init_weights(variable_specs(enc), seed=3, mode='test')
+    inp = synth_inputs(B, enc, seed=9)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.inference_ops(inp['audio'], inp['video'])
+    net.inference_ops(inp['audio'], inp['video'])
+    assert net.counter(B, 'fp16x2_saturations') == 0
+    P2 = dict(P)
+    P2['video_encoder/conv2_1/conv_1/bn/gamma'] = (P['video_encoder/conv2_1/conv_1/bn/gamma'] * 1e25).astype(np.float32)
+    net2 = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net2.load_variables(P2)
+    net2.inference_ops(inp['audio'], inp['video'])
+    assert net2.counter(B, 'fp16x2_saturations') > 0
+    # (activations of 1e25 are beyond what ANY of the kernels can process: the fp32 (sum, sumsq) statistics of the next batch-norm
+    #  overflow; a scale exponent within +-60 covers bounds up to 6e20, where the squares already leave fp32 - the counter cannot fire
+    #  inside the range in which the fp32 path itself is valid)
 
 
 def test_stride2_block_inputs_run_on_the_plane_fed_gather_kernel(T):
