@@ -5,6 +5,7 @@
 // (channels innermost, C % 4 == 0); per-channel sums are accumulated in registers, reduced through LDS into one row of partials
 // per workgroup, and the rows are added in a fixed order in fp64 by partials_finish_kernel (deterministic; no atomics).
 #include "kernels.h"
+#include "h2_planes.h"
 #include <cstdlib>
 #include <algorithm>
 
@@ -232,9 +233,12 @@ __device__ __forceinline__ float4 masked_sum(const float4* ga, const float4* gb,
     return v;
 }
 
+// MX: also the workgroup's max |dz| and max |xhat| -> mx_part[2 * block + {0, 1}] (the bound of dy, bn_bwd_apply_h2_kernel)
+template <bool MX>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb,
                                                             const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
-                                                            long n4, int C4, float* __restrict__ part, int self_mask) {
+                                                            long n4, int C4, float* __restrict__ part, int self_mask,
+                                                            float* __restrict__ mx_part) {
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 mean, invstd;
     bn_moments4(bn, 4 * C4, c4, mean, invstd);
@@ -243,10 +247,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
     float4 sum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     // two elements per trip: eight 16-byte loads in flight per lane (one element per trip ran at 2.9 TB/s)
     const long stride = (long)gridDim.x * 256;
+    float mx_dz = 0.f, mx_xh = 0.f;
     auto accumulate = [&](const float4& dz, const float4& v) {
         sum[0] = add4(sum[0], dz);
-        sum[1].x = fmaf(dz.x, (v.x - mean.x) * invstd.x, sum[1].x); sum[1].y = fmaf(dz.y, (v.y - mean.y) * invstd.y, sum[1].y);
-        sum[1].z = fmaf(dz.z, (v.z - mean.z) * invstd.z, sum[1].z); sum[1].w = fmaf(dz.w, (v.w - mean.w) * invstd.w, sum[1].w);
+        const float4 xh = make_float4((v.x - mean.x) * invstd.x, (v.y - mean.y) * invstd.y, (v.z - mean.z) * invstd.z, (v.w - mean.w) * invstd.w);
+        sum[1].x = fmaf(dz.x, xh.x, sum[1].x); sum[1].y = fmaf(dz.y, xh.y, sum[1].y);
+        sum[1].z = fmaf(dz.z, xh.z, sum[1].z); sum[1].w = fmaf(dz.w, xh.w, sum[1].w);
+        if (MX) {
+            mx_dz = fmaxf(mx_dz, fmaxf(fmaxf(fabsf(dz.x), fabsf(dz.y)), fmaxf(fabsf(dz.z), fabsf(dz.w))));
+            mx_xh = fmaxf(mx_xh, fmaxf(fmaxf(fabsf(xh.x), fabsf(xh.y)), fmaxf(fabsf(xh.z), fabsf(xh.w))));
+        }
     };
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     for (; i + stride < n4; i += 2 * stride) {
@@ -270,17 +280,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
         accumulate(dz, v);
     }
     channel_partials<2>(sum, C4, part);
+    if (MX) {
+        __shared__ float s_mx[2][4];
+        mx_dz = wave_max_f(mx_dz); mx_xh = wave_max_f(mx_xh);
+        if ((threadIdx.x & 63) == 0) { s_mx[0][threadIdx.x >> 6] = mx_dz; s_mx[1][threadIdx.x >> 6] = mx_xh; }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            mx_part[2 * blockIdx.x + threadIdx.x] = fmaxf(fmaxf(s_mx[threadIdx.x][0], s_mx[threadIdx.x][1]), fmaxf(s_mx[threadIdx.x][2], s_mx[threadIdx.x][3]));
+    }
 }
 
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, float* scratch, hipStream_t s, int self_mask) {
+                         double* acc, float* scratch, hipStream_t s, int self_mask, float* mx_part, int* mx_blocks) {
     if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_reduce: self_mask replaces the activation operand");
     if (!ga || !y || !bn.acc || !acc || !scratch) return fail(SAGEN_ERR_NULL, "bn_bwd_reduce: null argument");
     if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_reduce: C=%d must be 4 * a divisor of 256", C);
     const long n4 = n_pixels * (C / 4);
     const int grid = reduce_grid(n4, C / 4);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
-                       (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask);
+    if (mx_part) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
+                           (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask, mx_part);
+        if (mx_blocks) *mx_blocks = grid;
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
+                           (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask, (float*)nullptr);
+    }
     SAGEN_LAUNCH_CHECK();
     hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, s, scratch, grid, 2 * C, acc, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
@@ -336,6 +360,132 @@ int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, cons
     const long n4 = n_pixels * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(aligned_grid(n4, C / 4)), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
                        (const float4*)act, (const float4*)y, bn, acc, n4, C / 4, (float4*)dy, (float4*)dz_out, dgamma, dbeta, self_mask);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// The same pass for a layer whose dy feeds a stride-1 3x3 data gradient on conv3h_kernel: dy ALSO as two fp16 planes of dy * 2^kd
+// over the padded pixel grid [B*H][W+1] (h2_planes.h; the pad column is written as zeros).  2^kd from a bound every workgroup
+// derives identically from what the reduce pass left: |dy_c| <= |gamma_c invstd_c| (max|dz| + |k0_c| + max|xhat| |k1_c|), scaled
+// into [512, 1024) - an exact bound, so nothing saturates.  Eight channels per thread (one 16-byte store per plane).
+__global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __restrict__ ga, const float* __restrict__ gb,
+                                                              const float* __restrict__ act, const float* __restrict__ y, const BnRef bn,
+                                                              const double* __restrict__ acc, long nrows, int W, int C,
+                                                              float* __restrict__ dy, float* __restrict__ dz_out,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int self_mask,
+                                                              char* __restrict__ planes, const float* __restrict__ mx_part, int mx_blocks,
+                                                              float* __restrict__ a_inv, unsigned* __restrict__ sat_count) {
+    const int C8 = C >> 3;
+    const long total = nrows * (W + 1) * C8;
+    const long cstride = nrows * (W + 1) * 64;
+    const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = (int)(t0 % C8);
+    __shared__ unsigned s_bits[3];
+    if (threadIdx.x < 3) s_bits[threadIdx.x] = 0u;
+    __syncthreads();
+    {
+        float m0 = 0.f, m1 = 0.f;
+        for (int b = threadIdx.x; b < mx_blocks; b += 256) { m0 = fmaxf(m0, mx_part[2 * b]); m1 = fmaxf(m1, mx_part[2 * b + 1]); }
+        m0 = wave_max_f(m0); m1 = wave_max_f(m1);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&s_bits[0], __builtin_bit_cast(unsigned, m0));           // non-negative floats order like their bit patterns
+            atomicMax(&s_bits[1], __builtin_bit_cast(unsigned, m1));
+        }
+    }
+    __syncthreads();
+    const float mx_dz = __builtin_bit_cast(float, s_bits[0]), mx_xh = __builtin_bit_cast(float, s_bits[1]);
+    {
+        float m = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const double mu = bn.acc[c] * bn.inv_count;
+            double var = bn.acc[C + c] * bn.inv_count - mu * mu;
+            var = var < 0.0 ? 0.0 : var;
+            const float gsc = bn.gamma[c] * (float)(1.0 / sqrt(var + (double)bn.eps));
+            m = fmaxf(m, fabsf(gsc) * (mx_dz + fabsf((float)(acc[c] * bn.inv_count)) + mx_xh * fabsf((float)(acc[C + c] * bn.inv_count))));
+        }
+        m = wave_max_f(m);
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_bits[2], __builtin_bit_cast(unsigned, m));
+    }
+    __syncthreads();
+    const float sa = h2_scale_of_bound(__builtin_bit_cast(float, s_bits[2]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) a_inv[0] = 1.f / sa;
+
+    float mean[8], invstd[8], k0[8], k1[8], gs[8], fsc[8], fsh[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 m4, r4, sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+        bn_moments4(bn, C, 2 * c8 + h, m4, r4);
+        if (self_mask) bn_forward_coeffs4(bn, C, 2 * c8 + h, sc4, sh4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 8 * c8 + 4 * h + k;
+            mean[4 * h + k] = (&m4.x)[k]; invstd[4 * h + k] = (&r4.x)[k];
+            fsc[4 * h + k] = (&sc4.x)[k]; fsh[4 * h + k] = (&sh4.x)[k];
+            k0[4 * h + k] = (float)(acc[c] * bn.inv_count);
+            k1[4 * h + k] = (float)(acc[C + c] * bn.inv_count);
+            gs[4 * h + k] = bn.gamma[c] * (&r4.x)[k];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = 8 * c8 + k;
+            if (dbeta) dbeta[c] = (float)acc[c];
+            if (dgamma) dgamma[c] = (float)acc[C + c];
+        }
+    }
+    for (long i = t0; i < total; i += (long)gridDim.x * 256) {
+        const long pp = i / C8;
+        const long row = pp / (W + 1);
+        const int w = (int)(pp - row * (W + 1));
+        float o[8];
+        if (w < W) {
+            const long e = (row * W + w) * C + 8 * c8;
+            float v[8], dz[8];
+            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(y + e);
+            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(y + e + 4);
+            *reinterpret_cast<float4*>(&dz[0]) = *reinterpret_cast<const float4*>(ga + e);
+            *reinterpret_cast<float4*>(&dz[4]) = *reinterpret_cast<const float4*>(ga + e + 4);
+            if (gb) {
+                const float4 b0 = *reinterpret_cast<const float4*>(gb + e), b1 = *reinterpret_cast<const float4*>(gb + e + 4);
+                dz[0] += b0.x; dz[1] += b0.y; dz[2] += b0.z; dz[3] += b0.w; dz[4] += b1.x; dz[5] += b1.y; dz[6] += b1.z; dz[7] += b1.w;
+            }
+            if (act) {
+                float a[8];
+                *reinterpret_cast<float4*>(&a[0]) = *reinterpret_cast<const float4*>(act + e);
+                *reinterpret_cast<float4*>(&a[4]) = *reinterpret_cast<const float4*>(act + e + 4);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dz[k] = a[k] > 0.f ? dz[k] : 0.f;
+            }
+            if (self_mask) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dz[k] = fmaf(v[k], fsc[k], fsh[k]) > 0.f ? dz[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = gs[k] * (dz[k] - k0[k] - (v[k] - mean[k]) * invstd[k] * k1[k]);
+            *reinterpret_cast<float4*>(dy + e) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dy + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            if (dz_out) {
+                *reinterpret_cast<float4*>(dz_out + e) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+                *reinterpret_cast<float4*>(dz_out + e + 4) = make_float4(dz[4], dz[5], dz[6], dz[7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = 0.f;
+        }
+        p3h_store(planes, cstride, pp, c8, o, sa, sat_count);
+    }
+}
+
+int bn_bwd_apply_h2_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
+                           int B, int H, int W, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask,
+                           void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count) {
+    if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_apply_h2: self_mask replaces the activation operand");
+    if (!ga || !y || !bn.acc || !acc || !dy || !planes || !mx_part || !a_inv) return fail(SAGEN_ERR_NULL, "bn_bwd_apply_h2: null argument");
+    if (C % 16 || 256 % (C / 8) || mx_blocks < 1) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_apply_h2: C=%d must be 16 * a divisor of 128", C);
+    const long total = (long)B * H * (W + 1) * (C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, ga, gb, act, y, bn, acc, (long)B * H, W, C,
+                       dy, dz_out, dgamma, dbeta, self_mask, (char*)planes, mx_part, mx_blocks, a_inv, sat_count);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

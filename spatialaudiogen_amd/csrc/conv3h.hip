@@ -26,6 +26,7 @@
 // the 16 lanes of one ds_read_b128 group then cover all 64 banks for ANY slot base (with 96-byte slots conv3p_kernel needs only the
 // half swap).  40 KiB of LDS per 128x64 workgroup: three per CU.
 #include "igemm3_common.h"
+#include "h2_planes.h"
 
 namespace sagen {
 
@@ -393,24 +394,37 @@ int h2_filter_pack_launch(const float* wp, int N, int Kpad, void* w2, unsigned* 
 
 
 // ---- the same for MANY layers in two launches (bind; and once per training step, after the optimiser rewrote the variables) ----
-__global__ __launch_bounds__(256) void h2_absmax_multi_kernel(const H2Job* __restrict__ jobs, int njobs, unsigned* __restrict__ amax) {
+// max |w| per job WITHOUT atomics: one partial per workgroup, then one workgroup per job folds its partials (11 k workgroups each
+// ending in a same-address atomicMax took 109 us for 44 MB in the training step's trace - the L2 serialises them; an atomic-load
+// guard in front of the atomicMax made it 188 us)
+__global__ __launch_bounds__(256) void h2_absmax_multi_kernel(const H2Job* __restrict__ jobs, int njobs, float* __restrict__ part) {
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
     const H2Job job = jobs[j];
-    const long total = (long)job.N * job.Kpad;
-    const long i0 = ((long)blockIdx.x - job.first_block) * 1024 + threadIdx.x;
+    const unsigned total = (unsigned)job.N * (unsigned)job.Kpad;            // (a multiple of 16)
+    const unsigned i = ((unsigned)((int)blockIdx.x - job.first_block) * 256 + threadIdx.x) * 4;
     float m = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const long i = i0 + 256 * k;
-        if (i < total) m = fmaxf(m, fabsf(job.wp[i]));
+    if (i < total) {
+        const float4 v = *reinterpret_cast<const float4*>(job.wp + i);
+        m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    __shared__ unsigned s_m;
-    if (threadIdx.x == 0) s_m = 0u;
+    m = wave_max_f(m);
+    __shared__ float s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
-    atomicMax(&s_m, __builtin_bit_cast(unsigned, m));
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+__global__ __launch_bounds__(256) void h2_absmax_finish_kernel(const H2Job* __restrict__ jobs, int njobs, int nblocks, const float* __restrict__ part,
+                                                               unsigned* __restrict__ amax) {
+    const int j = blockIdx.x;
+    const int b0 = jobs[j].first_block, b1 = j + 1 < njobs ? jobs[j + 1].first_block : nblocks;
+    float m = 0.f;
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) m = fmaxf(m, part[b]);
+    m = wave_max_f(m);
+    __shared__ float s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&amax[j], s_m);
+    if (threadIdx.x == 0) amax[j] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])));
 }
 
 __global__ __launch_bounds__(256) void h2_filter_pack_multi_kernel(const H2Job* __restrict__ jobs, int njobs, const unsigned* __restrict__ amax) {
@@ -439,8 +453,9 @@ __global__ __launch_bounds__(256) void h2_filter_pack_multi_kernel(const H2Job* 
 int h2_filter_pack_multi_launch(const H2Job* jobs_dev, int njobs, int nblocks, unsigned* amax, hipStream_t s) {
     if (njobs <= 0) return SAGEN_OK;
     if (!jobs_dev || !amax) return fail(SAGEN_ERR_NULL, "h2_filter_pack_multi: null argument");
-    SAGEN_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)njobs * sizeof(unsigned), s));
-    hipLaunchKernelGGL(h2_absmax_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs, amax);
+    float* part = reinterpret_cast<float*>(amax + njobs);        // amax holds njobs + nblocks words
+    hipLaunchKernelGGL(h2_absmax_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs, part);
+    hipLaunchKernelGGL(h2_absmax_finish_kernel, dim3(njobs), dim3(256), 0, s, jobs_dev, njobs, nblocks, (const float*)part, amax);
     hipLaunchKernelGGL(h2_filter_pack_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs, amax);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;

@@ -814,8 +814,20 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         const int tn = blk / tiles_k, tk = blk - tn * tiles_k;
         const int n0 = tn * 32, k0 = tk * 32;
         const int nl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+        if ((j.p[2] & 31) == 0 && j.p[5] == 0) {       // the tile lies inside ONE tap (cin_pad % 32 == 0, no tap-row padding): one division per workgroup
+            const int cin_src = j.p[1], cin_pad = j.p[2], cout = j.p[3];
+            const int tap = k0 / cin_pad, c0 = k0 - tap * cin_pad;
+            const bool in = n0 + nl < cout && tap < j.p[0];
+            const float* w = j.src + ((long)tap * cin_src + c0) * cout + n0 + nl;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tile[kl + 8 * r][nl] = pack_source(j, n0 + nl, k0 + kl + 8 * r);
+            for (int r = 0; r < 4; ++r) {
+                const int c = kl + 8 * r;
+                tile[c][nl] = in && c0 + c < cin_src ? w[(long)c * cout] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[kl + 8 * r][nl] = pack_source(j, n0 + nl, k0 + kl + 8 * r);
+        }
         __syncthreads();
         const int n = n0 + (threadIdx.x >> 3), k = k0 + 4 * (threadIdx.x & 7);
         if (n >= j.N || k >= j.Kpad) return;            // (Kpad % 16 == 0: a group of four is inside or outside as a whole)
@@ -825,12 +837,20 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         pack_store4(j, n, k, v);
         return;
     }
-    const long idx = ((long)blk * 256 + threadIdx.x) * 4;
-    if (idx >= (long)j.N * j.Kpad) return;
-    const int n = (int)(idx / j.Kpad), k = (int)(idx - (long)n * j.Kpad);      // Kpad % 16 == 0: the four elements share the row
+    const unsigned idx = ((unsigned)blk * 256 + threadIdx.x) * 4;              // (N * Kpad < 2^31 for every filter of the network)
+    if (idx >= (unsigned)j.N * (unsigned)j.Kpad) return;
+    const int n = (int)(idx / (unsigned)j.Kpad), k = (int)(idx - (unsigned)n * (unsigned)j.Kpad);      // Kpad % 16 == 0: the four elements share the row
     float v[4];
+    if (j.kind == PACK_FLIPT && (j.p[2] & 3) == 0) {            // four consecutive co of one tap: one 16-byte load
+        const int ntaps = j.p[0], cin = j.p[1], cout = j.p[2];
+        const int tap = k / cout, co = k - tap * cout;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < cin && tap < ntaps) q = *reinterpret_cast<const float4*>(j.src + ((long)(ntaps - 1 - tap) * cin + n) * cout + co);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = pack_source(j, n, k + e);
+        for (int e = 0; e < 4; ++e) v[e] = pack_source(j, n, k + e);
+    }
     pack_store4(j, n, k, v);
 }
 

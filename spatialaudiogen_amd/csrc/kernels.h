@@ -136,6 +136,7 @@ struct H2Job {                       // one layer of the batched fp16x2 filter p
     float* w_inv = nullptr;          // out: 2^-kw
     int N = 0, Kpad = 0, first_block = 0, pad_ = 0;
 };
+// amax: scratch of njobs + nblocks words (the per-job maxima and the per-workgroup partials behind them)
 int h2_filter_pack_multi_launch(const H2Job* jobs_dev, int njobs, int nblocks, unsigned* amax, hipStream_t s);
 bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel can run (given planes)
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
@@ -302,10 +303,16 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
 // xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat) (overwritten);
 // scratch >= reduce_scratch_floats(C) floats
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, float* scratch, hipStream_t s, int self_mask = 0);
+                         double* acc, float* scratch, hipStream_t s, int self_mask = 0, float* mx_part = nullptr, int* mx_blocks = nullptr);
+// mx_part (nullable, >= 2 * 512 floats): per-workgroup (max |dz|, max |xhat|); *mx_blocks = the number of workgroups that wrote it
 // dy = gamma*invstd*(dz - acc0/N - xhat*acc1/N) (+ dz to `dz_out`, nullable); writes dgamma = acc1, dbeta = acc0 (nullable)
 int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
                         long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask = 0);
+// ... and dy also as fp16x2 planes [C/16][B*H*(W+1)][2][16] of dy * 2^kd for conv3h_kernel (the stride-1 data gradients), 2^-kd to
+// a_inv[0]; the bound behind kd comes from the reduce pass's mx_part
+int bn_bwd_apply_h2_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
+                           int B, int H, int W, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask,
+                           void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count);
 // self_mask = 1 (act must be null): the ReLU mask is relu(bn(y)) > 0, re-derived from y with the forward's own scale / shift - for a
 // layer whose activation IS relu(bn(y)) (no residual), e.g. conv_1 of a residual block: one tensor less to read in both passes
 // backward of maxpool3x3s2(relu(bn(y0))) (resnet.py:134-135): dz0[b,i,j,c] = (a > 0) * sum over the windows containing (i,j) of

@@ -101,6 +101,10 @@ struct sagen_ctx {
     bool video_u8 = false;                 // this call's video frames are uint8 (sagen_forward_u8): normalisation fused into the pad pass
     bool train_h2 = true;                  // the training step's forward also runs the trunk's stride-1 3x3 convs on the fp16x2 planes (SAGEN_TRAIN_NO_H2=1: bf16x3)
     bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
+    bool train_h2d = true;                 // ... and its backward runs the stride-1 3x3 data gradients on fp16x2 planes of dy, written by the batch-norm backward (SAGEN_TRAIN_NO_H2D=1: bf16x3 on fp32 dy)
+    std::map<std::string, int> h2d_slot;   // per data-gradient filter: index of its 2^-kw in the "t:h2d" table
+    std::vector<H2Job> h2d_jobs;
+    int h2d_blocks = 0;
     std::map<std::string, int> h2_slot;    // per layer: index of its 2^-kw in the "h2s" table
     std::vector<H2Job> h2_jobs;            // the batched fp16x2 filter pack (host copy of the job table)
     int h2_blocks = 0;
@@ -272,7 +276,7 @@ struct Fwd {
         Choice ch;
         const IgemmTile tile = igemm_pick_tile(d);
         ch.tile = (int)tile;
-        const bool can_split = allow_split && dense_out(d) && !d.stats;
+        const bool can_split = allow_split && dense_out(d) && !d.stats && !igemm_tile_p3(tile);     // (the plane-fed kernels do not split K)
         ch.splitk = can_split ? auto_splitk(d, tile) : 1;
         while (ch.splitk > 1 && (size_t)ch.splitk * d.M * d.N > ws_capacity()) --ch.splitk;
         return ch;

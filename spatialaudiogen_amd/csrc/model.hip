@@ -39,6 +39,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
     c->use_h2 = getenv("SAGEN_NO_H2") == nullptr;
     c->train_h2 = getenv("SAGEN_TRAIN_NO_H2") == nullptr;
+    c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
     // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
     // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
     if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;
@@ -112,6 +113,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
 
     // ---- workspace carving ----
     // packed filters
+    size_t h2_pack_blocks = 0;
     for (const auto& vs : c->vars) {
         if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
         size_t n;
@@ -134,12 +136,13 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         if (vs.ndim == 4 && ((vs.shape[0] == 3 && vs.shape[1] == 3) || (vs.shape[0] == 1 && vs.shape[1] == 1)) && vs.shape[2] % 16 == 0 &&
             vs.name.find("_encoder/conv") != std::string::npos) {
             c->alloc("pkh:" + vs.name, n);
+            h2_pack_blocks += n / 1024 + 1;
             const int slot = 8 + (int)c->h2_slot.size();
             c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = slot;
         }
     }
     c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
-    c->alloc("h2:amax", c->h2_slot.size() + 64);
+    c->alloc("h2:amax", c->h2_slot.size() + h2_pack_blocks + 64);      // per-job maxima + per-workgroup partials
     c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [7] saturation counter, [8..] 2^-kw per layer
     c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
     // activations

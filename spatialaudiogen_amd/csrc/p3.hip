@@ -10,6 +10,7 @@
 //   * p3_maxpool_kernel  3x3/2 SAME max-pool of relu(bn(x)) (resnet.py:134-135) -> fp32 NHWC + P3
 // Each thread owns 8 consecutive channels of one pixel: two 16-byte loads, three 16-byte plane stores.
 #include "igemm3_common.h"
+#include "h2_planes.h"
 
 namespace sagen {
 
@@ -68,15 +69,6 @@ size_t p3h_bytes(int B, int H, int W, int C) { return (size_t)(C / 16) * B * H *
 // bound = max_c(bn) + max_c(residual) is scaled into [512, 1024): fp16 overflows at 65504, i.e. 64 x headroom for what lies beyond
 // eight standard deviations, then saturation.  Every block derives the same value; block 0 publishes 2^-ka (read by conv3h_kernel's
 // epilogue) and the bound itself (the residual bound of the next merge).  Without a BnRef the scale is 1.
-
-__device__ __forceinline__ float wave_max_f(float v) {              // max over the wavefront (values >= 0), by DPP / permlane swaps
-    v = fmaxf(v, dpp_mov<0xB1>(v, v)); v = fmaxf(v, dpp_mov<0x4E>(v, v));
-    { float t = dpp_mov<0x104, 0x5>(v, v); t = dpp_mov<0x114, 0xA>(t, v); v = fmaxf(v, t); }
-    { float t = dpp_mov<0x108, 0x3>(v, v); t = dpp_mov<0x118, 0xC>(t, v); v = fmaxf(v, t); }
-    { float a = v, b = v; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); v = fmaxf(a, b); }
-    { float a = v, b = v; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); v = fmaxf(a, b); }
-    return v;
-}
 
 __device__ __forceinline__ float p3h_act_scale(const BnRef& bn, const P3hScale& h, bool has_res, int C, unsigned* s_bits) {
     if (threadIdx.x < 2) s_bits[threadIdx.x] = 0u;
@@ -161,23 +153,6 @@ __device__ __forceinline__ float p3_tables(const float* scale, const float* shif
     if (bn.acc != nullptr && e != 0 && e != 255) sa = __builtin_bit_cast(float, (unsigned)(127 + max(-60, min(60, 127 + 9 - e))) << 23);
     if (blockIdx.x == 0 && threadIdx.x == 0 && h.a_inv) h.a_inv[0] = 1.f / sa;
     return sa;
-}
-
-__device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c8, const float (&v)[8], float sa, unsigned* sat_count) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    h8 hi, lo;
-    bool clamped = false;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        clamped = clamped || !(fabsf(v[k] * sa) <= 65000.f);
-        const float t = fminf(fmaxf(v[k] * sa, -65000.f), 65000.f);
-        hi[k] = (_Float16)t;
-        lo[k] = (_Float16)(t - (float)hi[k]);
-    }
-    char* dst = p3 + (long)(c8 >> 1) * cstride + pp * 64 + (c8 & 1) * 16;
-    *reinterpret_cast<h8*>(dst) = hi;
-    *reinterpret_cast<h8*>(dst + 32) = lo;
-    if (clamped && sat_count) atomicAdd(sat_count, 1u);       // (never, unless a value lies 64 x beyond eight standard deviations - or is not finite)
 }
 
 template <bool H2>

@@ -23,6 +23,9 @@ static inline int ceil16(int x) { return (x + 15) / 16 * 16; }
 
 enum PkdKind { PKD_NONE = 0, PKD_FLIPT, PKD_STRIDED, PKD_DECONV, PKD_ROWS };
 
+// the stride-1 3x3 data gradients of the trunks on fp16x2 planes (needs the plane kernels and the fp16x2 format of the forward)
+static bool h2d_on(const sagen_ctx* c) { return c->train_h2d && c->train_h2 && c->use_h2 && c->use_p3 && !c->fp32_only; }
+
 struct PkdSpec { PkdKind kind = PKD_NONE; int N = 0, K = 0, kh = 0, kw = 0, sh = 1, sw = 1, a = 0, b = 0; };
 
 // how the data-gradient filter of a "/weights" variable is packed
@@ -126,6 +129,10 @@ static void train_carve(sagen_ctx* c) {
         for (int st = 1; st <= 3; ++st) c->talloc("t:S" + std::to_string(st) + x, stage);
         c->talloc("t:dz0" + x, (size_t)B * 112 * 224 * 64);
         c->talloc("t:bnbacc" + x, (size_t)24 * 2 * 512 * 2);
+        if (h2d_on(c)) {                   // dy of a stride-1 3x3 conv as fp16x2 planes (largest: stage 2) + the reduce pass's per-workgroup maxima
+            c->talloc("t:DP" + x, p3h_bytes(B, 56, 112, 64) / sizeof(float));
+            c->talloc("t:mxpart" + x, 2 * 512);
+        }
         c->talloc("t:stemtmp" + x, (size_t)7 * 32 * 64);
         c->talloc("t:g:feat" + x, (size_t)B * 98 * 512);
         c->talloc("t:g:fcred" + x, (size_t)B * 98 * 128);
@@ -133,6 +140,7 @@ static void train_carve(sagen_ctx* c) {
         c->talloc("t:g:vfc" + x, (size_t)B * 512);
         c->talloc("t:dy:vfc" + x, (size_t)B * 512);
     }
+    size_t h2d_pack_blocks = 0;
     for (const auto& vs : c->vars) {
         if (!is_weights(vs.name)) continue;
         const PkdSpec p = pkd_spec(vs);
@@ -144,7 +152,18 @@ static void train_carve(sagen_ctx* c) {
             }
         } else {
             c->talloc("pkd:" + vs.name, packed_split_floats((size_t)p.N * ceil16(p.K)));
+            if (p.kind == PKD_FLIPT && p.kh == 3 && h2d_on(c)) {           // ... and as two fp16 planes for conv3h_kernel
+                c->talloc("pkdh:" + vs.name, (size_t)p.N * ceil16(p.K));
+                h2d_pack_blocks += (size_t)p.N * ceil16(p.K) / 1024 + 1;
+                const int slot = 8 + (int)c->h2d_slot.size();
+                c->h2d_slot[vs.name] = slot;
+            }
         }
+    }
+    if (h2d_on(c)) {
+        c->talloc("t:h2d", 8 + c->h2d_slot.size() + 8);          // [0], [1]: 2^-kd of the video / flow trunk's dy planes; [8..]: 2^-kw per filter
+        c->talloc("t:h2d:jobs", (c->h2d_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
+        c->talloc("t:h2d:amax", c->h2d_slot.size() + h2d_pack_blocks + 64);
     }
     c->talloc("pkd:jobs", (c->vars.size() + 64) * sizeof(PackJob) / sizeof(float) + 64);
 }
@@ -187,7 +206,30 @@ static int repack_dgrad(sagen_ctx* c, hipStream_t s) {
         c->pack_blocks_bwd = sagen_upload_pack_jobs(c->pack_jobs_bwd, c->p("pkd:jobs"), s);
         if (c->pack_blocks_bwd < 0) return fail(SAGEN_ERR_HIP, "pack job upload failed");
     }
-    return pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pkd:jobs")), (int)c->pack_jobs_bwd.size(), c->pack_blocks_bwd, s);
+    int rc = pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pkd:jobs")), (int)c->pack_jobs_bwd.size(), c->pack_blocks_bwd, s);
+    if (rc || !h2d_on(c) || c->h2d_slot.empty()) return rc;
+    // the flipped / transposed 3x3 filters of the stride-1 trunk convs also as fp16x2 planes, from the fp32 packs just written
+    if (c->h2d_jobs.empty()) {
+        int nb = 0;
+        for (const auto& kv : c->h2d_slot) {
+            const VarSpec* vs = nullptr;
+            for (const auto& v : c->vars) if (v.name == kv.first) vs = &v;
+            if (!vs) return fail(SAGEN_ERR_WEIGHTS, "no variable %s", kv.first.c_str());
+            const PkdSpec p = pkd_spec(*vs);
+            H2Job j;
+            j.N = p.N; j.Kpad = ceil16(p.K);
+            j.wp = c->p("pkd:" + vs->name); j.w2 = c->p("pkdh:" + vs->name); j.w_inv = c->p("t:h2d") + kv.second;
+            j.first_block = nb;
+            nb += (int)(((long)j.N * j.Kpad + 1023) / 1024);
+            c->h2d_jobs.push_back(j);
+        }
+        c->h2d_blocks = nb;
+        if (c->h2d_jobs.size() * sizeof(H2Job) > c->tbufs.at("t:h2d:jobs").n * sizeof(float)) return fail(SAGEN_ERR_WORKSPACE, "fp16x2 job table too small");
+        if (hipMemcpyAsync(c->p("t:h2d:jobs"), c->h2d_jobs.data(), c->h2d_jobs.size() * sizeof(H2Job), hipMemcpyHostToDevice, s) != hipSuccess)
+            return fail(SAGEN_ERR_HIP, "fp16x2 job upload failed");
+    }
+    return h2_filter_pack_multi_launch(reinterpret_cast<const H2Job*>(c->p("t:h2d:jobs")), (int)c->h2d_jobs.size(), c->h2d_blocks,
+                                       reinterpret_cast<unsigned*>(c->p("t:h2d:amax")), s);
 }
 
 struct Bwd : Fwd {
@@ -283,10 +325,23 @@ struct Bwd : Fwd {
 
     // ---- data gradients on the forward's contraction kernels ----
     // stride-1 SAME conv (kh x kw odd): dx = conv(dy, flipped / transposed filter)
-    void dgrad_s1(const std::string& name, const float* dy, int H, int W, int Cout, int Cin, float* dx) {
+    // `planes`: dy as fp16x2 planes (bn_bwd wrote them beside the fp32 dy the weight gradient reads) -> conv3h_kernel
+    void dgrad_s1(const std::string& name, const float* dy, int H, int W, int Cout, int Cin, float* dx, const void* planes = nullptr) {
         if (rc) return;
         int Ho, Wo;
         IgemmDesc d = conv_desc(dy, H, W, Cout, Cout, c->p("pkd:" + name + "/weights"), 3, 3, 1, 1, true, Cin, dx, Cin, Ho, Wo);
+        auto hs = c->h2d_slot.find(name + "/weights");
+        if (planes && hs != c->h2d_slot.end()) {
+            d.xp3 = planes;
+            d.p3_np = c->B * H * (W + 1);
+            d.xp3_fmt = 1;
+            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+            d.xp3_bytes = (unsigned)p3h_bytes(c->B, H, W, Cout);
+            d.wh2 = c->p("pkdh:" + name + "/weights");
+            d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+            d.h2_a_inv = h2d_a_inv();
+            d.h2_w_inv = c->p("t:h2d") + hs->second;
+        }
         layer = "dgrad:" + name;
         contract(d, 1, split_ok);
     }
@@ -348,7 +403,31 @@ struct Bwd : Fwd {
     // ---- ResNet18 trunk (resnet.py:123-236) backward; gfeat = dL/d(conv5_2 output) [B,7,14,512] ----
     double* bnb_acc(int li) { return reinterpret_cast<double*>(c->p("t:bnbacc" + sfx)) + (size_t)li * 2 * 512; }
     // training-mode BN of layer `li` backward: dz = (ga + gb) * (act > 0) -> dy (and dz), dgamma, dbeta
-    void bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
+    float* h2d_a_inv() { return c->p("t:h2d") + (sfx.empty() ? 0 : 1); }
+    // (H, W) > 0: dy also as fp16x2 planes in "t:DP" for the stride-1 data gradient that follows (returns them; null otherwise)
+    const void* bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
+                float* dy, float* dz, bool self_mask = false, int H = 0, int W = 0) {
+        if (rc) return nullptr;
+        if (H > 0 && h2d_on(c) && !c->fp32_only && c->h2d_slot.count(bn_name + "/weights")) {
+            const BnRef bn = bn_ref(li, bn_name, npix);
+            double* acc = bnb_acc(li);
+            layer = "bnbwd:" + bn_name;
+            static const bool no_self = getenv("SAGEN_BN_READ_ACT") != nullptr;
+            const int sm = self_mask && !no_self;
+            const float* a = sm ? nullptr : act;
+            float* mx = c->p("t:mxpart" + sfx);
+            void* planes = c->p("t:DP" + sfx);
+            int nb = 0;
+            timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, a, y, bn, npix, C, acc, c->p(redws), s, sm, mx, &nb); });
+            timed("bn_bwd_apply_h2_kernel", 0.0, [&] {
+                return bn_bwd_apply_h2_launch(ga, gb, a, y, bn, acc, c->B, H, W, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s, sm,
+                                              planes, mx, nb, h2d_a_inv(), reinterpret_cast<unsigned*>(c->p("h2s") + 7)); });
+            return planes;
+        }
+        bn_bwd_plain(bn_name, li, ga, gb, act, y, npix, C, dy, dz, self_mask);
+        return nullptr;
+    }
+    void bn_bwd_plain(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
                 float* dy, float* dz, bool self_mask = false) {
         if (rc) return;
         const BnRef bn = bn_ref(li, bn_name, npix);
@@ -386,11 +465,12 @@ struct Bwd : Fwd {
             float* DY1 = c->p(std::string(k & 1 ? "t:DYd1" : "t:DYd0") + sfx);      // dy of conv_1
             const int li1 = 1 + 2 * k, li2 = 2 + 2 * k;
             // out = relu(bn2(y2) + shortcut)
-            bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z);
+            const void* P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo);
             wgrad("wgrad:" + pfx + "/conv_2", wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_2/weights"));
-            dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA);
+            dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA, P2);
             // a1 = relu(bn1(y1))
-            bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr, true);      // a1 > 0 <=> bn1(y1) > 0: a1 is not read
+            const void* P1 = bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr, true,       // a1 > 0 <=> bn1(y1) > 0: a1 is not read
+                                    first ? 0 : Ho, Wo);
             if (first) {
                 wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
                 wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));
@@ -400,7 +480,7 @@ struct Bwd : Fwd {
                 gb = S;
             } else {
                 wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_1/weights"));
-                dgrad_s1(pfx + "/conv_1", DY1, H, W, cout, cin, A);
+                dgrad_s1(pfx + "/conv_1", DY1, H, W, cout, cin, A, P1);
                 gb = Z;
             }
             done[k] = aux_mark();
@@ -595,6 +675,7 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
     if (((uintptr_t)tws) % 256) return fail(SAGEN_ERR_WORKSPACE, "train workspace must be 256-byte aligned");
     c->tws = (float*)tws;
     c->pack_jobs_bwd.clear();
+    c->h2d_jobs.clear();
     std::vector<float*> gp(c->vars.size(), nullptr), mp(c->vars.size(), nullptr);
     for (int pass = 0; pass < 2; ++pass) {
         const sagen_tensor* ts = pass ? moving : grads;

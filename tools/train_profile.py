@@ -21,6 +21,11 @@ if '--tune' in sys.argv:
 for _ in range(3):
     tr.step(*dev)
 torch.cuda.synchronize()
+if '--steps-only' in sys.argv:         # for `rocprofv3 --kernel-trace --stats`: the kernels as they run inside the step (two streams, no events)
+    for _ in range(20):
+        tr.step(*dev)
+    torch.cuda.synchronize()
+    sys.exit(0)
 tr.profile_enable(True)
 agg, layers = {}, []
 N = 3
