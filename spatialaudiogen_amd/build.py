@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libsagen_hip.so')
-SOURCES = ['conv3p.hip', 'conv3h.hip', 'conv3g.hip', 'p3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'stempool.hip', 'stem8.hip', 'igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'train.hip', 'wgrad.hip', 'backward.hip', 'model.hip', 'train_model.hip', 'api.hip']
+SOURCES = ['conv3p.hip', 'conv3h.hip', 'conv3g.hip', 'p3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'stempool.hip', 'stem8.hip', 'igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'train.hip', 'wgrad.hip', 'wgrad3h.hip', 'backward.hip', 'model.hip', 'train_model.hip', 'api.hip']
 HEADERS = [os.path.join(CSRC, h) for h in ('common.h', 'kernels.h', 'wave_reduce.h', 'igemm_common.h', 'igemm3_common.h', 'model.h')] + \
           [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'sagen.h')]
 # -fno-slp-vectorize -fno-vectorize: no packed-fp32 VALU (v_pk_add/mul/fma_f32).  Measured on MI355X: a wave executing packed-fp32 ops gives

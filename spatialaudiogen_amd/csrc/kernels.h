@@ -278,6 +278,13 @@ struct WgradDesc {
     int tsh = 1, tsw = 1;             // tap strides: tap (th, tw) reads G at (i*sh + th*tsh + h0, j*sw + tw*tsw + w0)
     int splitk = 1;
     int defer_reduce = 0;             // 1: wgrad_launch leaves the partials in ws; the caller runs wgrad_reduce_launch (timed separately)
+    // both operands ALSO as fp16x2 planes [C/16][B*Hd*(Wd+1)][2][16] (h2_planes.h) with their 2^-k scales: a dense 3x3 stride-1 SAME
+    // layer then runs wgrad3h_kernel (wgrad3h.hip: three fp16 products per multiply, LDS-DMA fed)
+    const void* gp = nullptr;
+    const void* dp = nullptr;
+    const float* gp_a_inv = nullptr;
+    const float* dp_a_inv = nullptr;
+    unsigned gp_bytes = 0, dp_bytes = 0;      // (filled by wgrad_launch)
     // filled by wgrad_launch
     int P = 0, fold = 1;
     unsigned g_bytes = 0, d_bytes = 0, magic_w = 0, magic_h = 0;
@@ -285,6 +292,7 @@ struct WgradDesc {
 int wgrad_launch(const WgradDesc& d, hipStream_t s);
 int wgrad_pick_splitk(const WgradDesc& d, size_t ws_capacity_floats);
 int wgrad_reduce_launch(const WgradDesc& d, hipStream_t s);
+// "wgrad3h_kernel" (fp16x2 planes of both operands, one filter row per workgroup) |
 // "wgrad3r_kernel" (bf16x3, one filter row per workgroup: dense 3x3 stride-1) | "wgrad3_kernel" (bf16x3, one tap) |
 // "wgrad_kernel" (exact fp32 MFMA) | "wgrad_ref_kernel"
 const char* wgrad_kernel_name(const WgradDesc& d);

@@ -102,6 +102,7 @@ struct sagen_ctx {
     bool train_h2 = true;                  // the training step's forward also runs the trunk's stride-1 3x3 convs on the fp16x2 planes (SAGEN_TRAIN_NO_H2=1: bf16x3)
     bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
     bool train_h2d = true;                 // ... and its backward runs the stride-1 3x3 data gradients on fp16x2 planes of dy, written by the batch-norm backward (SAGEN_TRAIN_NO_H2D=1: bf16x3 on fp32 dy)
+    bool train_h2w = true;                 // ... and the weight gradients of those layers run on the planes too (wgrad3h.hip): the forward retains its activation planes (SAGEN_TRAIN_NO_H2W=1: bf16x3 on the fp32 tensors)
     std::map<std::string, int> h2d_slot;   // per data-gradient filter: index of its 2^-kw in the "t:h2d" table
     std::vector<H2Job> h2d_jobs;
     int h2d_blocks = 0;
@@ -471,7 +472,7 @@ struct Fwd {
     // batch-norm + ReLU applied to the input on the fly
     void conv_bn(const float* x, int Hin, int Win, int Cin, const std::string& name, int k, int stride, int Cout,
                  const BnRef& bn_in, float* y, int& Hout, int& Wout, int bn_index, const std::string& plan_key = "",
-                 const void* planes = nullptr) {
+                 const void* planes = nullptr, const float* planes_a_inv = nullptr) {
         if (rc) return;
         IgemmDesc d = conv_desc(x, Hin, Win, Cin, Cin, c->p("pk:" + name + "/weights"), k, k, stride, stride, true, Cout, y,
                                 Cout, Hout, Wout);
@@ -485,7 +486,7 @@ struct Fwd {
                 d.xp3_bytes = (unsigned)p3h_bytes(c->B, Hin, Win, Cin);
                 d.wh2 = c->p("pkh:" + name + "/weights");
                 d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
-                d.h2_a_inv = h2_a_inv();
+                d.h2_a_inv = planes_a_inv ? planes_a_inv : h2_a_inv();
                 d.h2_w_inv = c->p("h2s") + hs->second;
             } else {
                 d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
@@ -695,8 +696,14 @@ struct Fwd {
     // The same trunk for the training step: every tensor the backward pass reads is retained in the train workspace -
     // raw conv outputs "t:y1:k" / "t:y2:k" (BN backward), conv_2 inputs "t:a1:k" and block outputs "t:out:k" (weight gradients,
     // ReLU masks), the pool output "t:x0"; the raw stem output "y0" and the BN accumulators are never reused anyway.
+    // With train_h2w the planes the forward writes for conv3h_kernel are RETAINED per layer ("t:pl:a1:k": input of block k's conv_2,
+    // "t:pl:x:k": input of block k's stride-1 conv_1; scales in "t:h2a": slot k / 8 + k): the weight gradients contract them (wgrad3h.hip).
+    bool h2w() const { return c->train_mode && c->train_h2w && c->train_h2d && h2() && c->p3_from_stage <= 2 && c->tbufs.count("t:h2a" + sfx) != 0; }
+    void* pl_buf(const char* what, int k) { return c->p(std::string("t:pl:") + what + ":" + std::to_string(k) + sfx); }
+    float* pl_a_inv(int slot) { return c->p("t:h2a" + sfx) + slot; }
     const float* resnet_train(const float* img, const std::string& scope) {
         const int B = c->B;
+        const bool keep = h2w();
         int li = 0;
         if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
@@ -718,7 +725,13 @@ struct Fwd {
             layer = name;
             contract(d);
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
-            timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("t:x0" + sfx), B, H, W, 64, s); });
+            if (keep) {                         // the pooled block input also as (retained) planes: stage 2 runs on planes as well
+                P3hScale hs0 = h2_scale(h2_xbound(0));
+                hs0.a_inv = pl_a_inv(8);
+                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("t:x0" + sfx), pl_buf("x", 0), B, H, W, 64, s, 1, &hs0); });
+            } else {
+                timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("t:x0" + sfx), B, H, W, 64, s); });
+            }
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
         }
@@ -735,7 +748,8 @@ struct Fwd {
                 const int stride = first ? 2 : 1;
                 int Ho = 0, Wo = 0, H2, W2;
                 const float* shortcut = xin;
-                const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage && st + 2 >= 3;   // (the pool writes no planes here)
+                const int kidx = 2 * st + unit - 1;
+                const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage && (st + 2 >= 3 || keep);   // (without retained planes the pool writes none)
                 if (first) {
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
                                             cout, c->p("rsc" + sfx), cout, Ho, Wo);
@@ -744,25 +758,33 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                void* planes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;
+                void* planes = p3_here ? (keep ? pl_buf("a1", kidx) : (void*)c->p("p3" + sfx)) : nullptr;       // of a1
+                const float* planes_ai = keep && p3_here ? pl_a_inv(kidx) : nullptr;
+                // planes of the block input (written by the pool / by unit 1's merge) and where this block's merge writes the next one's
+                void* xplanes = p3_here ? (keep ? pl_buf("x", stride == 1 ? kidx : 0) : (void*)c->p("p3" + sfx)) : nullptr;
+                const float* xplanes_ai = keep && p3_here ? pl_a_inv(8 + kidx) : nullptr;
+                void* nplanes = p3_here && unit == 1 ? (keep ? pl_buf("x", kidx + 1) : (void*)c->p("p3" + sfx)) : nullptr;
                 float* y1 = c->p("t:y1:" + k); float* a1 = c->p("t:a1:" + k); float* y2 = c->p("t:y2:" + k); float* xout = c->p("t:out:" + k);
-                // unit 2 of a plane stage finds the planes of its input written by unit 1's merge
+                // unit 2 of a plane stage finds the planes of its input written by unit 1's merge (stage 2's unit 1: by the pool)
+                const bool x_planes = p3_here && stride == 1 && (unit == 2 || (keep && st == 0));
                 conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), y1, Ho, Wo, li, "",
-                        (stride == 1 && unit == 2) ? planes : nullptr);
+                        x_planes ? xplanes : nullptr, x_planes ? xplanes_ai : nullptr);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 layer = pfx + "/bn1-relu";
-                const P3hScale hs1 = h2_scale();
+                P3hScale hs1 = h2_scale();
+                if (planes_ai) hs1.a_inv = const_cast<float*>(planes_ai);
                 if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y1, nullptr, nullptr, bn1, nullptr, 1, a1, planes, B, Ho, Wo, cout, s, p3_fmt(), &hs1); });
                 else timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(y1, nullptr, nullptr, bn1, nullptr, a1, (long)B * Ho * Wo, cout, s); });
-                conv_bn(a1, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), y2, H2, W2, li, p3_here ? "" : pfx + "/conv_2#mat", planes);
+                conv_bn(a1, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), y2, H2, W2, li, p3_here ? "" : pfx + "/conv_2#mat", planes, planes_ai);
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 ++li;
                 layer = pfx + "/merge";
-                const P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
-                                           : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
+                P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
+                                     : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
+                if (keep && p3_here) hs2.a_inv = pl_a_inv(8 + kidx + 1);
                 if (p3_here) xb_par ^= 1;
-                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y2, nullptr, nullptr, bn2, shortcut, 1, xout, unit == 1 ? planes : nullptr, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
+                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y2, nullptr, nullptr, bn2, shortcut, 1, xout, nplanes, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
                 else timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(y2, nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });
                 xin = xout;
                 H = Ho; W = Wo; cin = cout;

@@ -40,6 +40,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->use_h2 = getenv("SAGEN_NO_H2") == nullptr;
     c->train_h2 = getenv("SAGEN_TRAIN_NO_H2") == nullptr;
     c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
+    c->train_h2w = getenv("SAGEN_TRAIN_NO_H2W") == nullptr;
     // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
     // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
     if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;

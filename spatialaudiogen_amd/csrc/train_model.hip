@@ -25,6 +25,8 @@ enum PkdKind { PKD_NONE = 0, PKD_FLIPT, PKD_STRIDED, PKD_DECONV, PKD_ROWS };
 
 // the stride-1 3x3 data gradients of the trunks on fp16x2 planes (needs the plane kernels and the fp16x2 format of the forward)
 static bool h2d_on(const sagen_ctx* c) { return c->train_h2d && c->train_h2 && c->use_h2 && c->use_p3 && !c->fp32_only; }
+// ... and their weight gradients (wgrad3h.hip; the forward then retains its activation planes)
+static bool h2w_on(const sagen_ctx* c) { return h2d_on(c) && c->train_h2w && c->p3_from_stage <= 2; }
 
 struct PkdSpec { PkdKind kind = PKD_NONE; int N = 0, K = 0, kh = 0, kw = 0, sh = 1, sw = 1, a = 0, b = 0; };
 
@@ -130,8 +132,17 @@ static void train_carve(sagen_ctx* c) {
         c->talloc("t:dz0" + x, (size_t)B * 112 * 224 * 64);
         c->talloc("t:bnbacc" + x, (size_t)24 * 2 * 512 * 2);
         if (h2d_on(c)) {                   // dy of a stride-1 3x3 conv as fp16x2 planes (largest: stage 2) + the reduce pass's per-workgroup maxima
-            c->talloc("t:DP" + x, p3h_bytes(B, 56, 112, 64) / sizeof(float));
+            // (double-buffered over the block parity like the fp32 dy: the weight gradients on the second stream read them too)
+            for (const char* nm : {"t:DPc0", "t:DPc1", "t:DPd0", "t:DPd1"}) c->talloc(nm + x, p3h_bytes(B, 56, 112, 64) / sizeof(float));
             c->talloc("t:mxpart" + x, 2 * 512);
+        }
+        if (h2w_on(c)) {                   // retained activation planes: the input of every stride-1 3x3 conv (model.h: resnet_train)
+            for (int k = 0; k < 8; ++k) {
+                const size_t n = p3h_bytes(B, RS_H[k / 2], RS_W[k / 2], RS_C[k / 2]) / sizeof(float);
+                c->talloc("t:pl:a1:" + std::to_string(k) + x, n);
+                if (k == 0 || (k & 1)) c->talloc("t:pl:x:" + std::to_string(k) + x, n);
+            }
+            c->talloc("t:h2a" + x, 32);
         }
         c->talloc("t:stemtmp" + x, (size_t)7 * 32 * 64);
         c->talloc("t:g:feat" + x, (size_t)B * 98 * 512);
@@ -161,7 +172,7 @@ static void train_carve(sagen_ctx* c) {
         }
     }
     if (h2d_on(c)) {
-        c->talloc("t:h2d", 8 + c->h2d_slot.size() + 8);          // [0], [1]: 2^-kd of the video / flow trunk's dy planes; [8..]: 2^-kw per filter
+        c->talloc("t:h2d", 8 + c->h2d_slot.size() + 8);          // [4 * trunk + 2 * (conv_1) + parity]: 2^-kd of that dy plane buffer; [8..]: 2^-kw per filter
         c->talloc("t:h2d:jobs", (c->h2d_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
         c->talloc("t:h2d:amax", c->h2d_slot.size() + h2d_pack_blocks + 64);
     }
@@ -326,12 +337,13 @@ struct Bwd : Fwd {
     // ---- data gradients on the forward's contraction kernels ----
     // stride-1 SAME conv (kh x kw odd): dx = conv(dy, flipped / transposed filter)
     // `planes`: dy as fp16x2 planes (bn_bwd wrote them beside the fp32 dy the weight gradient reads) -> conv3h_kernel
-    void dgrad_s1(const std::string& name, const float* dy, int H, int W, int Cout, int Cin, float* dx, const void* planes = nullptr) {
+    void dgrad_s1(const std::string& name, const float* dy, int H, int W, int Cout, int Cin, float* dx, const void* planes = nullptr,
+                  const float* planes_a_inv = nullptr) {
         if (rc) return;
         int Ho, Wo;
         IgemmDesc d = conv_desc(dy, H, W, Cout, Cout, c->p("pkd:" + name + "/weights"), 3, 3, 1, 1, true, Cin, dx, Cin, Ho, Wo);
         auto hs = c->h2d_slot.find(name + "/weights");
-        if (planes && hs != c->h2d_slot.end()) {
+        if (planes && planes_a_inv && hs != c->h2d_slot.end()) {
             d.xp3 = planes;
             d.p3_np = c->B * H * (W + 1);
             d.xp3_fmt = 1;
@@ -339,7 +351,7 @@ struct Bwd : Fwd {
             d.xp3_bytes = (unsigned)p3h_bytes(c->B, H, W, Cout);
             d.wh2 = c->p("pkdh:" + name + "/weights");
             d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
-            d.h2_a_inv = h2d_a_inv();
+            d.h2_a_inv = planes_a_inv;
             d.h2_w_inv = c->p("t:h2d") + hs->second;
         }
         layer = "dgrad:" + name;
@@ -403,12 +415,15 @@ struct Bwd : Fwd {
     // ---- ResNet18 trunk (resnet.py:123-236) backward; gfeat = dL/d(conv5_2 output) [B,7,14,512] ----
     double* bnb_acc(int li) { return reinterpret_cast<double*>(c->p("t:bnbacc" + sfx)) + (size_t)li * 2 * 512; }
     // training-mode BN of layer `li` backward: dz = (ga + gb) * (act > 0) -> dy (and dz), dgamma, dbeta
-    float* h2d_a_inv() { return c->p("t:h2d") + (sfx.empty() ? 0 : 1); }
-    // (H, W) > 0: dy also as fp16x2 planes in "t:DP" for the stride-1 data gradient that follows (returns them; null otherwise)
-    const void* bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
-                float* dy, float* dz, bool self_mask = false, int H = 0, int W = 0) {
-        if (rc) return nullptr;
-        if (H > 0 && h2d_on(c) && !c->fp32_only && c->h2d_slot.count(bn_name + "/weights")) {
+    // dy plane buffer `which` (0: of conv_2, 1: of conv_1) of block parity `par`, and where its 2^-kd lives
+    void* dp_buf(int which, int par) { return c->p(std::string(which ? "t:DPd" : "t:DPc") + (par ? "1" : "0") + sfx); }
+    float* dp_a_inv(int which, int par) { return c->p("t:h2d") + (sfx.empty() ? 0 : 4) + 2 * which + par; }
+    // (H, W) > 0: dy also as fp16x2 planes in `planes` (scale to `planes_a_inv`) for the stride-1 data gradient / the weight gradient
+    // that follow (returns true when written)
+    bool bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
+                float* dy, float* dz, bool self_mask = false, int H = 0, int W = 0, void* planes = nullptr, float* planes_a_inv = nullptr) {
+        if (rc) return false;
+        if (H > 0 && planes && h2d_on(c) && c->h2d_slot.count(bn_name + "/weights")) {
             const BnRef bn = bn_ref(li, bn_name, npix);
             double* acc = bnb_acc(li);
             layer = "bnbwd:" + bn_name;
@@ -416,17 +431,22 @@ struct Bwd : Fwd {
             const int sm = self_mask && !no_self;
             const float* a = sm ? nullptr : act;
             float* mx = c->p("t:mxpart" + sfx);
-            void* planes = c->p("t:DP" + sfx);
             int nb = 0;
             timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, a, y, bn, npix, C, acc, c->p(redws), s, sm, mx, &nb); });
             timed("bn_bwd_apply_h2_kernel", 0.0, [&] {
                 return bn_bwd_apply_h2_launch(ga, gb, a, y, bn, acc, c->B, H, W, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s, sm,
-                                              planes, mx, nb, h2d_a_inv(), reinterpret_cast<unsigned*>(c->p("h2s") + 7)); });
-            return planes;
+                                              planes, mx, nb, planes_a_inv, reinterpret_cast<unsigned*>(c->p("h2s") + 7)); });
+            return !rc;
         }
         bn_bwd_plain(bn_name, li, ga, gb, act, y, npix, C, dy, dz, self_mask);
-        return nullptr;
+        return false;
     }
+    // the operands of a stride-1 3x3 weight gradient also as planes (wgrad3h_kernel): G = retained forward planes, D = dy planes
+    WgradDesc with_planes(WgradDesc d, const void* gp, const float* gp_a_inv, const void* dp, const float* dpa) {
+        d.gp = gp; d.gp_a_inv = gp_a_inv; d.dp = dp; d.dp_a_inv = dpa;
+        return d;
+    }
+    bool h2w() const { return h2w_on(c) && c->tbufs.count("t:h2a" + sfx) != 0; }
     void bn_bwd_plain(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
                 float* dy, float* dz, bool self_mask = false) {
         if (rc) return;
@@ -465,12 +485,19 @@ struct Bwd : Fwd {
             float* DY1 = c->p(std::string(k & 1 ? "t:DYd1" : "t:DYd0") + sfx);      // dy of conv_1
             const int li1 = 1 + 2 * k, li2 = 2 + 2 * k;
             // out = relu(bn2(y2) + shortcut)
-            const void* P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo);
-            wgrad("wgrad:" + pfx + "/conv_2", wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_2/weights"));
-            dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA, P2);
+            const bool planes_on = h2d_on(c) && c->tbufs.count("t:DPc0" + sfx) != 0;
+            void* DP2 = planes_on ? dp_buf(0, k & 1) : nullptr;
+            void* DP1 = planes_on ? dp_buf(1, k & 1) : nullptr;
+            const bool P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo, DP2, planes_on ? dp_a_inv(0, k & 1) : nullptr);
+            {
+                WgradDesc w = wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1);
+                if (P2 && h2w()) w = with_planes(w, pl_buf("a1", k), pl_a_inv(k), DP2, dp_a_inv(0, k & 1));
+                wgrad("wgrad:" + pfx + "/conv_2", w, grad(pfx + "/conv_2/weights"));
+            }
+            dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA, P2 ? DP2 : nullptr, P2 ? dp_a_inv(0, k & 1) : nullptr);
             // a1 = relu(bn1(y1))
-            const void* P1 = bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr, true,       // a1 > 0 <=> bn1(y1) > 0: a1 is not read
-                                    first ? 0 : Ho, Wo);
+            const bool P1 = bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr, true,       // a1 > 0 <=> bn1(y1) > 0: a1 is not read
+                                   first ? 0 : Ho, Wo, DP1, planes_on ? dp_a_inv(1, k & 1) : nullptr);
             if (first) {
                 wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
                 wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));
@@ -479,8 +506,10 @@ struct Bwd : Fwd {
                 dgrad_strided(pfx + "/shortcut", Z, Ho, Wo, cout, 1, 1, 2, 2, H, W, cin, S, cin);
                 gb = S;
             } else {
-                wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1), grad(pfx + "/conv_1/weights"));
-                dgrad_s1(pfx + "/conv_1", DY1, H, W, cout, cin, A, P1);
+                WgradDesc w = wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1);
+                if (P1 && h2w()) w = with_planes(w, pl_buf("x", k), pl_a_inv(8 + k), DP1, dp_a_inv(1, k & 1));
+                wgrad("wgrad:" + pfx + "/conv_1", w, grad(pfx + "/conv_1/weights"));
+                dgrad_s1(pfx + "/conv_1", DY1, H, W, cout, cin, A, P1 ? DP1 : nullptr, P1 ? dp_a_inv(1, k & 1) : nullptr);
                 gb = Z;
             }
             done[k] = aux_mark();

@@ -695,9 +695,11 @@ static bool wgrad_exact() {
     return exact;
 }
 static bool wgrad_rowtap(const WgradDesc& d);
+static bool wgrad_planes(const WgradDesc& d);
+int wgrad3h_dispatch(const WgradDesc& d, int bm, unsigned blocks, hipStream_t s);      // (wgrad3h.hip)
 const char* wgrad_kernel_name(const WgradDesc& d) {
     static const bool ref = getenv("SAGEN_WGRAD_REF") != nullptr;
-    return ref ? "wgrad_ref_kernel" : (wgrad_exact() ? "wgrad_kernel" : (wgrad_rowtap(d) ? "wgrad3r_kernel" : "wgrad3_kernel"));
+    return ref ? "wgrad_ref_kernel" : (wgrad_exact() ? "wgrad_kernel" : (wgrad_planes(d) ? "wgrad3h_kernel" : (wgrad_rowtap(d) ? "wgrad3r_kernel" : "wgrad3_kernel")));
 }
 
 static unsigned magic_of(int dv) { return dv <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dv + 1ull); }
@@ -708,6 +710,12 @@ size_t wgrad_ws_floats(const WgradDesc& d, int splitk) { return splitk > 1 ? (si
 static bool wgrad_rowtap(const WgradDesc& d) {
     static const bool off = getenv("SAGEN_WGRAD_NOROW") != nullptr;
     return !off && !wgrad_exact() && d.TW == 3 && d.tsw == 1 && d.sw == 1 && d.w0 == -1 && d.WG == d.Wd && d.Wd >= 12;
+}
+// ... and on fp16x2 planes when the caller has both operands in that form: 3x3, SAME in both directions, channels in whole 32s
+static bool wgrad_planes(const WgradDesc& d) {
+    static const bool off = getenv("SAGEN_WGRAD_NO_H2") != nullptr;
+    return !off && wgrad_rowtap(d) && d.gp && d.dp && d.gp_a_inv && d.dp_a_inv && d.TH == 3 && d.tsh == 1 && d.sh == 1 && d.h0 == -1 &&
+           d.HG == d.Hd && d.Cg % 32 == 0 && d.Cd % 32 == 0;
 }
 struct WgradShape { int bm, bn, fold; long ntile, nchunks; bool row; };
 static WgradShape wgrad_shape(const WgradDesc& d) {
@@ -781,6 +789,13 @@ int wgrad_launch(const WgradDesc& d_in, hipStream_t s) {
         else if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, s, d);
         else if (bn == 128) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, d);
         else hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, s, d);
+    } else if (wgrad_planes(d)) {
+        const size_t pb = (size_t)P * 64;
+        if ((size_t)(d.Cg / 16) * pb >= (1ull << 31) || (size_t)(d.Cd / 16) * pb >= (1ull << 31))
+            return fail(SAGEN_ERR_UNSUPPORTED, "wgrad: plane operand exceeds 2 GiB buffer addressing");
+        d.gp_bytes = (unsigned)((d.Cg / 16) * pb); d.dp_bytes = (unsigned)((d.Cd / 16) * pb);
+        const int rc = wgrad3h_dispatch(d, bm, (unsigned)blocks, s);
+        if (rc) return rc;
     } else if (shp.row) {
         if (bm == 128) hipLaunchKernelGGL((wgrad3r_kernel<128, 64>), grid, dim3(256), 0, s, d);
         else hipLaunchKernelGGL((wgrad3r_kernel<64, 64>), grid, dim3(256), 0, s, d);
