@@ -22,7 +22,7 @@ for _ in range(3):
     tr.step(*dev)
 torch.cuda.synchronize()
 if '--steps-only' in sys.argv:         # for `rocprofv3 --kernel-trace --stats`: the kernels as they run inside the step (two streams, no events)
-    for _ in range(20):
+    for _ in range(int(os.environ.get('STEPS_ONLY', '20'))):
         tr.step(*dev)
     torch.cuda.synchronize()
     sys.exit(0)
