@@ -463,8 +463,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = gs[k] * (dz[k] - k0[k] - (v[k] - mean[k]) * invstd[k] * k1[k]);
-            *reinterpret_cast<float4*>(dy + e) = make_float4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<float4*>(dy + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            if (dy) {                                          // (null: every consumer of this dy reads the planes)
+                *reinterpret_cast<float4*>(dy + e) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(dy + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
             if (dz_out) {
                 *reinterpret_cast<float4*>(dz_out + e) = make_float4(dz[0], dz[1], dz[2], dz[3]);
                 *reinterpret_cast<float4*>(dz_out + e + 4) = make_float4(dz[4], dz[5], dz[6], dz[7]);
@@ -481,7 +483,7 @@ int bn_bwd_apply_h2_launch(const float* ga, const float* gb, const float* act, c
                            int B, int H, int W, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask,
                            void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count) {
     if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_apply_h2: self_mask replaces the activation operand");
-    if (!ga || !y || !bn.acc || !acc || !dy || !planes || !mx_part || !a_inv) return fail(SAGEN_ERR_NULL, "bn_bwd_apply_h2: null argument");
+    if (!ga || !y || !bn.acc || !acc || !planes || !mx_part || !a_inv) return fail(SAGEN_ERR_NULL, "bn_bwd_apply_h2: null argument");
     if (C % 16 || 256 % (C / 8) || mx_blocks < 1) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_apply_h2: C=%d must be 16 * a divisor of 128", C);
     const long total = (long)B * H * (W + 1) * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, ga, gb, act, y, bn, acc, (long)B * H, W, C,

@@ -296,6 +296,8 @@ int wgrad_reduce_launch(const WgradDesc& d, hipStream_t s);
 // "wgrad3r_kernel" (bf16x3, one filter row per workgroup: dense 3x3 stride-1) | "wgrad3_kernel" (bf16x3, one tap) |
 // "wgrad_kernel" (exact fp32 MFMA) | "wgrad_ref_kernel"
 const char* wgrad_kernel_name(const WgradDesc& d);
+bool wgrad_reads_fp32_operands();     // SAGEN_WGRAD_REF: the fp32 dy / activations must exist even where the planes do
+bool wgrad_planes_enabled();          // wgrad3h_kernel not switched off by the environment (exact fp32 / reference / SAGEN_WGRAD_NO_H2)
 
 // -----------------------------------------------------------------------------------------
 // backward elementwise / reductions (backward.hip)
@@ -316,8 +318,8 @@ int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, con
 // dy = gamma*invstd*(dz - acc0/N - xhat*acc1/N) (+ dz to `dz_out`, nullable); writes dgamma = acc1, dbeta = acc0 (nullable)
 int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
                         long n_pixels, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask = 0);
-// ... and dy also as fp16x2 planes [C/16][B*H*(W+1)][2][16] of dy * 2^kd for conv3h_kernel (the stride-1 data gradients), 2^-kd to
-// a_inv[0]; the bound behind kd comes from the reduce pass's mx_part
+// ... and dy also as fp16x2 planes [C/16][B*H*(W+1)][2][16] of dy * 2^kd for conv3h_kernel / wgrad3h_kernel, 2^-kd to a_inv[0]; the
+// bound behind kd comes from the reduce pass's mx_part; dy may be null then (no fp32 copy)
 int bn_bwd_apply_h2_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
                            int B, int H, int W, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask,
                            void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count);

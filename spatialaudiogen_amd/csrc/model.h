@@ -698,7 +698,7 @@ struct Fwd {
     // ReLU masks), the pool output "t:x0"; the raw stem output "y0" and the BN accumulators are never reused anyway.
     // With train_h2w the planes the forward writes for conv3h_kernel are RETAINED per layer ("t:pl:a1:k": input of block k's conv_2,
     // "t:pl:x:k": input of block k's stride-1 conv_1; scales in "t:h2a": slot k / 8 + k): the weight gradients contract them (wgrad3h.hip).
-    bool h2w() const { return c->train_mode && c->train_h2w && c->train_h2d && h2() && c->p3_from_stage <= 2 && c->tbufs.count("t:h2a" + sfx) != 0; }
+    bool h2w() const { return c->train_mode && c->train_h2w && c->train_h2d && h2() && c->p3_from_stage <= 2 && wgrad_planes_enabled() && c->tbufs.count("t:h2a" + sfx) != 0; }
     void* pl_buf(const char* what, int k) { return c->p(std::string("t:pl:") + what + ":" + std::to_string(k) + sfx); }
     float* pl_a_inv(int slot) { return c->p("t:h2a" + sfx) + slot; }
     const float* resnet_train(const float* img, const std::string& scope) {

@@ -26,7 +26,7 @@ enum PkdKind { PKD_NONE = 0, PKD_FLIPT, PKD_STRIDED, PKD_DECONV, PKD_ROWS };
 // the stride-1 3x3 data gradients of the trunks on fp16x2 planes (needs the plane kernels and the fp16x2 format of the forward)
 static bool h2d_on(const sagen_ctx* c) { return c->train_h2d && c->train_h2 && c->use_h2 && c->use_p3 && !c->fp32_only; }
 // ... and their weight gradients (wgrad3h.hip; the forward then retains its activation planes)
-static bool h2w_on(const sagen_ctx* c) { return h2d_on(c) && c->train_h2w && c->p3_from_stage <= 2; }
+static bool h2w_on(const sagen_ctx* c) { return h2d_on(c) && c->train_h2w && c->p3_from_stage <= 2 && wgrad_planes_enabled(); }
 
 struct PkdSpec { PkdKind kind = PKD_NONE; int N = 0, K = 0, kh = 0, kw = 0, sh = 1, sw = 1, a = 0, b = 0; };
 
@@ -344,6 +344,7 @@ struct Bwd : Fwd {
         IgemmDesc d = conv_desc(dy, H, W, Cout, Cout, c->p("pkd:" + name + "/weights"), 3, 3, 1, 1, true, Cin, dx, Cin, Ho, Wo);
         auto hs = c->h2d_slot.find(name + "/weights");
         if (planes && planes_a_inv && hs != c->h2d_slot.end()) {
+            d.x = nullptr;                          // only the plane-fed tiles may run: the fp32 dy need not exist (bn_bwd)
             d.xp3 = planes;
             d.p3_np = c->B * H * (W + 1);
             d.xp3_fmt = 1;
@@ -420,8 +421,10 @@ struct Bwd : Fwd {
     float* dp_a_inv(int which, int par) { return c->p("t:h2d") + (sfx.empty() ? 0 : 4) + 2 * which + par; }
     // (H, W) > 0: dy also as fp16x2 planes in `planes` (scale to `planes_a_inv`) for the stride-1 data gradient / the weight gradient
     // that follow (returns true when written)
+    // planes_only: no fp32 dy at all (the weight gradient reads the planes too)
     bool bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
-                float* dy, float* dz, bool self_mask = false, int H = 0, int W = 0, void* planes = nullptr, float* planes_a_inv = nullptr) {
+                float* dy, float* dz, bool self_mask = false, int H = 0, int W = 0, void* planes = nullptr, float* planes_a_inv = nullptr,
+                bool planes_only = false) {
         if (rc) return false;
         if (H > 0 && planes && h2d_on(c) && c->h2d_slot.count(bn_name + "/weights")) {
             const BnRef bn = bn_ref(li, bn_name, npix);
@@ -434,7 +437,7 @@ struct Bwd : Fwd {
             int nb = 0;
             timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, a, y, bn, npix, C, acc, c->p(redws), s, sm, mx, &nb); });
             timed("bn_bwd_apply_h2_kernel", 0.0, [&] {
-                return bn_bwd_apply_h2_launch(ga, gb, a, y, bn, acc, c->B, H, W, C, dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s, sm,
+                return bn_bwd_apply_h2_launch(ga, gb, a, y, bn, acc, c->B, H, W, C, planes_only ? nullptr : dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s, sm,
                                               planes, mx, nb, planes_a_inv, reinterpret_cast<unsigned*>(c->p("h2s") + 7)); });
             return !rc;
         }
@@ -488,7 +491,7 @@ struct Bwd : Fwd {
             const bool planes_on = h2d_on(c) && c->tbufs.count("t:DPc0" + sfx) != 0;
             void* DP2 = planes_on ? dp_buf(0, k & 1) : nullptr;
             void* DP1 = planes_on ? dp_buf(1, k & 1) : nullptr;
-            const bool P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo, DP2, planes_on ? dp_a_inv(0, k & 1) : nullptr);
+            const bool P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo, DP2, planes_on ? dp_a_inv(0, k & 1) : nullptr, h2w() && !wgrad_reads_fp32_operands());
             {
                 WgradDesc w = wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1);
                 if (P2 && h2w()) w = with_planes(w, pl_buf("a1", k), pl_a_inv(k), DP2, dp_a_inv(0, k & 1));
@@ -497,7 +500,7 @@ struct Bwd : Fwd {
             dgrad_s1(pfx + "/conv_2", DY, Ho, Wo, cout, cout, DA, P2 ? DP2 : nullptr, P2 ? dp_a_inv(0, k & 1) : nullptr);
             // a1 = relu(bn1(y1))
             const bool P1 = bn_bwd(pfx + "/conv_1", li1, DA, nullptr, a1, y1, npix, cout, DY1, nullptr, true,       // a1 > 0 <=> bn1(y1) > 0: a1 is not read
-                                   first ? 0 : Ho, Wo, DP1, planes_on ? dp_a_inv(1, k & 1) : nullptr);
+                                   first ? 0 : Ho, Wo, DP1, planes_on ? dp_a_inv(1, k & 1) : nullptr, h2w() && !wgrad_reads_fp32_operands());
             if (first) {
                 wgrad("wgrad:" + pfx + "/conv_1", wdesc(xin, H, W, cin, cin, DY1, Ho, Wo, cout, cout, 3, 3, 2, 2, 0, 0), grad(pfx + "/conv_1/weights"));
                 wgrad("wgrad:" + pfx + "/shortcut", wdesc(xin, H, W, cin, cin, Z, Ho, Wo, cout, cout, 1, 1, 2, 2, 0, 0), grad(pfx + "/shortcut/weights"));

@@ -712,9 +712,16 @@ static bool wgrad_rowtap(const WgradDesc& d) {
     return !off && !wgrad_exact() && d.TW == 3 && d.tsw == 1 && d.sw == 1 && d.w0 == -1 && d.WG == d.Wd && d.Wd >= 12;
 }
 // ... and on fp16x2 planes when the caller has both operands in that form: 3x3, SAME in both directions, channels in whole 32s
+bool wgrad_planes_enabled() {
+    static const bool off = getenv("SAGEN_WGRAD_NO_H2") != nullptr || getenv("SAGEN_WGRAD_NOROW") != nullptr;
+    return !off && !wgrad_exact();
+}
+bool wgrad_reads_fp32_operands() {          // the reference kernel reads the fp32 tensors whatever planes the descriptor carries
+    static const bool ref = getenv("SAGEN_WGRAD_REF") != nullptr;
+    return ref;
+}
 static bool wgrad_planes(const WgradDesc& d) {
-    static const bool off = getenv("SAGEN_WGRAD_NO_H2") != nullptr;
-    return !off && wgrad_rowtap(d) && d.gp && d.dp && d.gp_a_inv && d.dp_a_inv && d.TH == 3 && d.tsh == 1 && d.sh == 1 && d.h0 == -1 &&
+    return wgrad_planes_enabled() && wgrad_rowtap(d) && d.gp && d.dp && d.gp_a_inv && d.dp_a_inv && d.TH == 3 && d.tsh == 1 && d.sh == 1 && d.h0 == -1 &&
            d.HG == d.Hd && d.Cg % 32 == 0 && d.Cd % 32 == 0;
 }
 struct WgradShape { int bm, bn, fold; long ntile, nchunks; bool row; };

@@ -213,7 +213,10 @@ def test_two_ranks_with_different_batches_follow_adam_on_the_mean_gradient(T, tm
     _, P = _trainer(T, enc, 2, lr=1e-4)
     batches = [next(synthetic_batches(enc, 2, seed=7 + r, pool=1)) for r in range(2)]
     state = {k: (np.asarray(v, np.float64), np.zeros(v.shape), np.zeros(v.shape)) for k, v in P.items() if '/moving_' not in k}
-    tight = ('separation/', 'localization/')                        # no ReLU of the encoders between the loss and these variables
+    tight = ('separation/deconv', 'localization/')                  # no ReLU of the encoders between the loss and these variables
+    # ('separation/fc-feats' has its OWN ReLU on just B rows of 512 units: one pre-activation within rounding distance of zero switches
+    #  differently in fp32 and fp64 and moves that unit's column of the gradient by 1/B - seen on unit 393 of rank 1's batch: 9.8e-3 on
+    #  the whole tensor, every other column at 1e-5.  It is held to the free-running bar.)
     for step in range(2):
         cur = dict(P)
         cur.update({k: v[0] for k, v in state.items()})

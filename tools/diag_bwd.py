@@ -33,7 +33,9 @@ def main():
     keep = ('video_encoder/conv5_2',)
     loss, grads, pred, ig = ref.loss_and_grads(inp['audio'], inp.get('video'), inp.get('flow'), target, None, keep=keep)
     gfeat = np.transpose(ig['video_encoder/conv5_2'], (0, 2, 3, 1)).reshape(-1)
-    settings = [{}, {'SAGEN_ONE_STREAM': '1'}, {'SAGEN_BWD_NOSPLIT': '1'}, {'SAGEN_FP32_ONLY': '1'}, {'SAGEN_NO_P3': '1'}, {'SAGEN_WGRAD_REF': '1'}]
+    settings = [{}, {'SAGEN_TRAIN_NO_H2W': '1'}, {'SAGEN_WGRAD_NO_H2': '1'}, {'SAGEN_TRAIN_NO_H2D': '1'}, {'SAGEN_ONE_STREAM': '1'}, {'SAGEN_BWD_NOSPLIT': '1'}, {'SAGEN_FP32_ONLY': '1'}, {'SAGEN_NO_P3': '1'}, {'SAGEN_WGRAD_REF': '1'}]
+    if os.environ.get('DIAG_SETTINGS'):
+        settings = settings[:int(os.environ['DIAG_SETTINGS'])]
     for st in settings:
         fn = tempfile.mktemp(suffix='.npz')
         env = dict(os.environ); env.update(st)
@@ -48,6 +50,8 @@ def main():
         same = all(np.array_equal(z['0|' + k.replace('/', '|')], z['1|' + k.replace('/', '|')]) for k in names)
         print('== %s: %d bad of %d; max err %.2e; run-to-run identical: %s; g:feat err %.2e (2nd run %.2e)' % (
             st, len(bad), len(errs), max(e for _, e in errs), same, rel_rms_err(z['0|buf|t:g:feat'], gfeat), rel_rms_err(z['1|buf|t:g:feat'], gfeat)))
+        for k, e in bad[:16]:
+            print('  bad  %-55s %.2e' % (k, e))
         order = [k for k in names if 'video_encoder' in k or 'video-fc' in k]
         for k, e in errs:
             if k in order[-14:] or k in order[:3]:
