@@ -73,9 +73,11 @@ def parse():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='av')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the one-in-flight and H2D-inclusive legs (they run after the timed region)')
-    ap.add_argument('--in-flight', type=int, default=2,
+    ap.add_argument('--in-flight', type=int, default=3,
                     help='batches in flight per GPU: steps rotate over this many native contexts, each on its own stream, the streams '
-                         'probed to really run concurrently (DESIGN.md 6.1); 1 = strictly one forward at a time')
+                         'probed to really run concurrently (DESIGN.md 6.1); 1 = strictly one forward at a time (round 4: three, measured '
+                         '2 210 against 2 083-2 131 ambisonic-s/s with two on one box - the fp16x2 kernels leave LDS and registers for a third '
+                         "batch's workgroups; four = three)")
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
     ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
@@ -259,8 +261,9 @@ def main_train(args, cfg):
     dom = max(agg, key=lambda k: agg[k][1])
     n_l, us_l, fl_l = agg[dom]
     achieved = fl_l / (us_l * 1e-6) / 1e12
-    b3 = dom.startswith('igemm3') or dom.startswith('conv3p') or dom.startswith('wgrad3')
-    peak = PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS
+    h2 = dom.startswith('conv3h') or dom.startswith('wgrad3h') or (dom.startswith('conv3g') and dom.rstrip('>').endswith('true'))
+    b3 = not h2 and (dom.startswith('igemm3') or dom.startswith('conv3p') or dom.startswith('wgrad3') or dom.startswith('conv3g'))
+    peak = PEAK_FP16X2_TFLOPS if h2 else (PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS)
     traffic, traffic_src = None, None
     try:     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_train.json')) as f:
@@ -274,16 +277,20 @@ def main_train(args, cfg):
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'frac_of_sustained_mfma_rate': round(achieved / SUSTAINED_BF16X3_TFLOPS, 4) if b3 else None, 'sustained_note': SUSTAINED_NOTE if b3 else None,
-        'peak_basis': ('dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
+        'peak_basis': ('dense fp16 MFMA peak 2500 TF / 3 products per fp32 multiply (fp16x2 planes); algorithmic fp32 FLOPs' if h2 else
+                       'dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
                        if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
+        'fp16x2_families_us_per_step': round(sum(a[1] for k, a in agg.items() if k.startswith(('conv3h', 'wgrad3h')) or (k.startswith('conv3g') and k.rstrip('>').endswith('true'))) / nprof, 1),
+        'bf16x3_families_us_per_step': round(sum(a[1] for k, a in agg.items() if k.startswith(('igemm3', 'conv3p', 'wgrad3_', 'wgrad3r')) or (k.startswith('conv3g') and not k.rstrip('>').endswith('true'))) / nprof, 1),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
         'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
         'share_of_step_time': round(us_l / total_us, 3),
         'phases_us_per_step': {k: round(v[0] / nprof, 1) for k, v in sorted(by_phase.items())},
         'phases_tflops': {k: round(v[1] / (v[0] * 1e-6) / 1e12, 1) for k, v in sorted(by_phase.items()) if v[1] > 0},
         'whole_step': {'achieved': round(step_tflops, 2), 'frac': round(step_tflops / PEAK_BF16X3_TFLOPS, 4),
-                       'frac_basis': 'all launched fp32-equivalent FLOPs of the step / step time, against the six-product bf16x3 roof (417 TFLOP/s) - the '
-                                     'family of the backward kernels; the forward trunk convs run on the three-product fp16x2 kernels',
+                       'frac_basis': 'all launched fp32-equivalent FLOPs of the step / step time, against the six-product bf16x3 roof (417 TFLOP/s); the '
+                                     "stride-1 3x3 trunk convs (forward, data and weight gradients: 39 of the step's contractions) run on "
+                                     'the three-product fp16x2 kernels, the rest on bf16x3',
                        'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                        'gflop_per_window_launched': round(total_fl / nprof / BATCH / 1e9, 2),
                        'gflop_per_window_forward_needed_only': cfg['gflop'],
@@ -293,8 +300,9 @@ def main_train(args, cfg):
         'metric': 'ambisonic seconds trained/sec (0.1 s windows, 224x448 video; one Adam step per batch)',
         'value': round(value, 2), 'unit': 'ambisonic-s/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (forward, data and weight gradients: products on the bf16 matrix cores as a 3-way operand split with fp32 '
-                 'accumulation, fp32-equivalent - tests/test_gpu_backward.py; fp32 Adam state)',
+        'dtype': 'f32 (fp32 in / out / accumulate and fp32 Adam state; products on the 16-bit matrix cores with fp32-equivalent operand splits: '
+                 'two fp16 planes (3 products per multiply) for the forward, data gradient and weight gradient of the stride-1 3x3 trunk convs, '
+                 'three bf16 planes (6 products) elsewhere - every gradient against fp64 autograd in tests/test_gpu_backward.py)',
         'data': 'synthetic',
         'config': {'workload': cfg['workload'], 'name': 'train', 'windows_per_gpu_per_step': BATCH,
                    'windows_per_s': round(BATCH * world * steps / elapsed, 1), 'optimizer': 'Adam (lr 1e-4), fused over %d flat buckets' % len(tr.opt.params),
