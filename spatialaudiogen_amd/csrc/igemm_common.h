@@ -143,7 +143,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)
                 const int m = m0 + row;
                 float v = acc[i][j][e];
                 if (to_ws) {
-                    if (nok && m < d.M) d.splitk_ws[((long)z * d.M + m) * d.N + n] = v;
+                    if (nok && m < d.M) {
+                        float* q = &d.splitk_ws[((long)z * d.M + m) * d.N + n];
+                        if (d.sk_ticket) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (write-through: visible to the other XCDs without an L2 flush)
+                        else *q = v;
+                    }
                 } else {
                     const bool ok = nok && ry < s_row[row].hrem && rx < s_row[row].wrem;
                     if (ok) {
@@ -154,6 +158,50 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)
                         d.y[s_row[row].rowoff + coloff] = v;
                     }
                 }
+            }
+        }
+    }
+    if (to_ws && d.sk_ticket != nullptr) {
+        // ---- last-arriver combine.  The eight XCDs have their own L2s: the partials are written and read with AGENT-scope accesses
+        // (write-through stores, loads that never return a stale line) - a release / acquire FENCE pair instead writes back and
+        // invalidates the whole L2 of the XCD, which cost the other batches in flight more than the reducer launches saved
+        // (2 030 against 2 240 ambisonic-s/s, audio-only 3 200 against 4 800) ----
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's agent-scope stores have been acknowledged
+        __syncthreads();
+        const int tile = (m0 / BM) * ((d.N + BN - 1) / BN) + n0 / BN;
+        if (tid == 0) {
+            const int t = atomicAdd(&d.sk_ticket[tile], 1);
+            s_last = t == d.splitk - 1;
+            if (s_last) d.sk_ticket[tile] = 0;           // re-armed for the next launch on this stream
+        }
+        __syncthreads();
+        if (s_last) {
+            constexpr int C4 = BN / 4;
+            auto ld4 = [](const float* q) {                       // agent-scope loads: never a stale line of this XCD's L2
+                return make_float4(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                   __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            };
+            const long MN = (long)d.M * d.N;
+            for (int idx = tid; idx < BM * C4; idx += 256) {
+                const int r = idx / C4, m = m0 + r, n = n0 + 4 * (idx - r * C4);
+                if (m >= d.M || n >= d.N) continue;
+                const float* p = d.splitk_ws + (long)m * d.N + n;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int zz = 0;
+                for (; zz + 4 <= d.splitk; zz += 4, p += 4 * MN) {      // the reducer's association, four partials in flight
+                    const float4 t0 = ld4(p), t1 = ld4(p + MN);
+                    const float4 t2 = ld4(p + 2 * MN), t3 = ld4(p + 3 * MN);
+                    v.x += (t0.x + t1.x) + (t2.x + t3.x); v.y += (t0.y + t1.y) + (t2.y + t3.y);
+                    v.z += (t0.z + t1.z) + (t2.z + t3.z); v.w += (t0.w + t1.w) + (t2.w + t3.w);
+                }
+                for (; zz < d.splitk; ++zz, p += MN) {
+                    const float4 t = ld4(p);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                if (d.bias) { v.x += d.bias[n]; v.y += d.bias[n + 1]; v.z += d.bias[n + 2]; v.w += d.bias[n + 3]; }
+                if (d.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                for (int rr = 0; rr < d.sk_rep; ++rr) *reinterpret_cast<float4*>(d.y + ((long)m * d.sk_rep + rr) * d.ldy + n) = v;
             }
         }
     }

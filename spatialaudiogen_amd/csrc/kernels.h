@@ -36,6 +36,11 @@ struct IgemmDesc {
     BnRef bn_in;                      // alternative to in_scale/in_shift: derive them in-kernel (Cin <= 512)
     double* stats = nullptr;          // fp64 accumulators [2][N] of (sum, sumsq) of the raw output (atomics), or null
     float* splitk_ws = nullptr;       // [splitk][M][N] when splitk > 1
+    // in-launch combine of the split-K partials (igemm_common.h: igemm_epilogue): one ticket per output tile, zero between launches;
+    // the workgroup that draws the last ticket of its tile adds the partials in the fixed order z = 0 .. splitk-1, applies bias / ReLU
+    // and writes y (each row sk_rep times) - no reducer launch.  Needs N % 4 == 0, 16-byte aligned y rows, a dense plain output.
+    int* sk_ticket = nullptr;
+    int sk_rep = 1;
     int M = 0, N = 0, K = 0, Kpad = 0;
     // output grid
     int Hg = 1, Wg = 1, g_h0 = 0, g_w0 = 0;
@@ -139,6 +144,8 @@ struct H2Job {                       // one layer of the batched fp16x2 filter p
 // amax: scratch of njobs + nblocks words (the per-job maxima and the per-workgroup partials behind them)
 int h2_filter_pack_multi_launch(const H2Job* jobs_dev, int njobs, int nblocks, unsigned* amax, hipStream_t s);
 bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel can run (given planes)
+constexpr int SK_TICKETS = 8192;                      // tiles an in-launch split-K combine can track (IgemmDesc::sk_ticket)
+inline bool igemm_tile_fused_splitk(IgemmTile) { return true; }     // every kernel that writes split-K partials does it through igemm_epilogue
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
 bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it

@@ -102,6 +102,7 @@ struct sagen_ctx {
     bool train_h2 = true;                  // the training step's forward also runs the trunk's stride-1 3x3 convs on the fp16x2 planes (SAGEN_TRAIN_NO_H2=1: bf16x3)
     bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
     bool train_h2d = true;                 // ... and its backward runs the stride-1 3x3 data gradients on fp16x2 planes of dy, written by the batch-norm backward (SAGEN_TRAIN_NO_H2D=1: bf16x3 on fp32 dy)
+    bool sk_fused = false;                 // SAGEN_SK_FUSED=1: split-K partials are combined inside the contraction (last-arriver, igemm_epilogue) instead of by a reducer launch - bit-identical, measured no faster
     bool train_h2w = true;                 // ... and the weight gradients of those layers run on the planes too (wgrad3h.hip): the forward retains its activation planes (SAGEN_TRAIN_NO_H2W=1: bf16x3 on the fp32 tensors)
     std::map<std::string, int> h2d_slot;   // per data-gradient filter: index of its 2^-kw in the "t:h2d" table
     std::vector<H2Job> h2d_jobs;
@@ -263,6 +264,16 @@ struct Fwd {
             IgemmDesc e = d;
             e.splitk = sk;
             e.splitk_ws = c->ws + c->bufs.at(wsname).off;
+            // the partials are combined by the contraction itself (last-arriver, igemm_epilogue) unless statistics ride on the reducer
+            const long tiles = (long)cdiv(d.M, igemm_tile_bm(tile)) * cdiv(d.N, igemm_tile_bn(tile));
+            if (c->sk_fused && sk > 1 && !d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && ((uintptr_t)d.y % 16) == 0 && (!d.bias || ((uintptr_t)d.bias % 16) == 0) &&
+                tiles <= SK_TICKETS && igemm_tile_fused_splitk(tile) && c->bufs.count(wsname + ":tk")) {
+                e.sk_ticket = reinterpret_cast<int*>(c->ws + c->bufs.at(wsname + ":tk").off);
+                e.sk_rep = rep;
+                e.stats = nullptr;
+                timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
+                return 0;
+            }
             e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
             timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
             timed("splitk_reduce_kernel", 0.0, [&] {

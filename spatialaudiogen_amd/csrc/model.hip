@@ -41,6 +41,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->train_h2 = getenv("SAGEN_TRAIN_NO_H2") == nullptr;
     c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
     c->train_h2w = getenv("SAGEN_TRAIN_NO_H2W") == nullptr;
+    c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
     // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
     // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
     if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;
@@ -161,6 +162,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
     }
     c->alloc("splitk_aux", (size_t)8 << 20);          // split-K scratch of the second stream (audio chain / flow FCs)
+    c->alloc("splitk:tk", SK_TICKETS);                // per-tile tickets of the in-launch split-K combine (zero between launches)
+    c->alloc("splitk_aux:tk", SK_TICKETS);
     for (int set = 0; set < 2; ++set) {
         const std::string x = set ? "_b" : "";
         if (set == 0 ? !(c->has_video || c->has_flow) : !(c->has_video && c->has_flow)) continue;   // "_b": flow trunk next to the video trunk
@@ -233,6 +236,8 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
     c->pack_jobs.clear();                 // (the table holds the variables' addresses)
     c->h2_jobs.clear();
     SAGEN_HIP_CHECK(hipMemsetAsync(c->p("h2s"), 0, 256 * sizeof(float), s));       // fp16x2 scales, bounds, saturation counter
+    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("splitk:tk"), 0, SK_TICKETS * sizeof(int), s));
+    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("splitk_aux:tk"), 0, SK_TICKETS * sizeof(int), s));
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     rc = sagen_repack_impl(c, s);

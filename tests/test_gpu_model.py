@@ -363,6 +363,37 @@ def test_full_benchmark_batch_against_the_independent_cpu_reference(T):
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
 
 
+def test_in_launch_split_k_combine_agrees_with_the_reducer(T, monkeypatch):
+    """SAGEN_SK_FUSED=1 (read when a context is created): the workgroup that draws the last ticket of an output tile adds the split-K
+    partials itself in a fixed order - one launch fewer per split layer, the same sums (off by default: measured no faster)."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    for enc, B in ((['audio'], 10), (['audio', 'video'], 4)):
+        P = init_weights(variable_specs(enc), seed=3, mode='test')
+        inp = synth_inputs(B, enc, seed=5)
+        outs, counts = [], []
+        for fused in (False, True):
+            if fused:
+                monkeypatch.setenv('SAGEN_SK_FUSED', '1')
+            else:
+                monkeypatch.delenv('SAGEN_SK_FUSED', raising=False)
+            net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+            net.load_variables(P)
+            for _ in range(2):                         # twice: the tickets must have been re-armed
+                out = net.inference_ops(inp['audio'], inp.get('video')).cpu().numpy()
+            net.profile_enable(B, True)
+            net.inference_ops(inp['audio'], inp.get('video'))
+            counts.append(sum(1 for k, layer, us, fl in net.profile_report(B) if k.startswith('splitk_reduce')))
+            net.profile_enable(B, False)
+            outs.append(out)
+        monkeypatch.delenv('SAGEN_SK_FUSED', raising=False)
+        # (a layer whose reducer also replicates rows without splitting K, or carries batch-norm statistics, or has N % 4 != 0 keeps it)
+        assert counts[0] >= 6 and counts[1] <= 2, counts
+        # the fixed-order sum of the partials is the same set of fp32 additions up to their association (the reducer of a layer with few
+        # outputs and many partials sums in eight interleaved slices): agreement at rounding level, run to run identical
+        assert rel_rms_err(outs[1], outs[0]) < 1e-6
+        assert np.array_equal(outs[1], out)
+
+
 def test_uint8_video_entry_point(T):
     """sagen_forward_u8: frames as the uint8 the decoder produced.
     (a) general kernels (sagen_set_option 'u8_fast_stem' = 0): x/255 - 0.5 (myutils.py:88-89) fused into the device-side pad pass -
