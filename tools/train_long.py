@@ -72,7 +72,9 @@ if __name__ == '__main__':
         out.write(s + '\n')
         out.flush()
     log('configs[4]: %s, batch %d, Adam lr 1e-4 (x0.5 every 250000), %d iterations, non-repeating synthetic stream generated on the device, '
-        'kernels: %s' % ('+'.join(enc), args.batch, args.iters, 'exact fp32 MFMA' if os.environ.get('SAGEN_FP32_ONLY') else 'bf16x3'))
+        'kernels: %s' % ('+'.join(enc), args.batch, args.iters, 'exact fp32 MFMA' if os.environ.get('SAGEN_FP32_ONLY') else
+                       'bf16x3' if (os.environ.get('SAGEN_NO_H2') or os.environ.get('SAGEN_TRAIN_NO_H2')) else
+                       'fp16x2 planes for the stride-1 3x3 trunk convs (forward, data and weight gradients), bf16x3 elsewhere'))
     W = args.log_every
     buf = torch.zeros(W, dtype=torch.float64, device='cuda')
     nan_total = 0
@@ -95,5 +97,9 @@ if __name__ == '__main__':
                 break
     torch.cuda.synchronize()
     dt = time.time() - t0
+    try:
+        log('fp16x2 plane saturations over the whole run (elements clamped to +-65000): %d' % net.counter(args.batch, 'fp16x2_saturations'))
+    except Exception as e:                                                     # (a build without the counter)
+        log('fp16x2 saturation counter unavailable: %s' % e)
     log('done: %d iterations in %.1f s = %.3f ms/iteration incl. the batch generator = %.1f ambisonic-s/s trained; NaN count %d'
         % (it + 1, dt, 1e3 * dt / (it + 1), 0.1 * args.batch * (it + 1) / dt, nan_total))
