@@ -365,6 +365,44 @@ np.savez(sys.argv[1], **{k.replace('/', '|'): tr.grad(k).cpu().numpy() for k in 
             assert np.array_equal(out[0][k], out[1][k]), k
 
 
+def test_gradients_on_planes_and_on_fp32_tensors_agree(T):
+    """The stride-1 3x3 trunk convs run their data and weight gradients on fp16x2 planes (dy planes from the batch-norm backward,
+    retained forward planes: conv3h_kernel / wgrad3h_kernel).  SAGEN_TRAIN_NO_H2W=1 (weight gradients on the fp32 tensors, forward
+    keeps stage 2 off the planes) and SAGEN_TRAIN_NO_H2D=1 (data gradients too) are the bf16x3 fallbacks: every variable's gradient
+    must agree with the default at the level the free-running ReLU switching allows, the decoder side tightly."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_backward import _setup
+from spatialaudiogen_amd.train import Trainer
+net, ref, P, inp, target = _setup(torch, ['audio', 'video'], 3, 9)
+tr = Trainer(net, batch=3)
+tr.forward_backward(inp['audio'], inp.get('video'), None, target)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **{k.replace('/', '|'): tr.grad(k).cpu().numpy() for k in tr.opt.layout})
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ('default', 'SAGEN_TRAIN_NO_H2W', 'SAGEN_TRAIN_NO_H2D'):
+        fn = tempfile.mktemp(suffix='.npz')
+        env = dict(os.environ)
+        if mode != 'default':
+            env[mode] = '1'
+        subprocess.run([sys.executable, '-c', code % (root, os.path.join(root, 'tests')), fn], check=True, env=env, timeout=900)
+        out[mode] = dict(np.load(fn))
+    for mode in ('SAGEN_TRAIN_NO_H2W', 'SAGEN_TRAIN_NO_H2D'):
+        errs = {k: rel_rms_err(out['default'][k], out[mode][k]) for k in out['default']}
+        worst = max(errs, key=errs.get)
+        dec = max(e for k, e in errs.items() if k.startswith(('separation|deconv', 'localization|')))
+        print('\n[%s vs planes] worst %.2e (%s), decoder side %.2e, median %.2e' % (mode, errs[worst], worst, dec, float(np.median(list(errs.values())))))
+        assert dec < 1e-4, (mode, dec)
+        assert errs[worst] < FREE_RUNNING_BAR and np.median(list(errs.values())) < 1.5e-2, (mode, worst, errs[worst])
+
+
 def test_data_gradients_of_the_strided_convs_in_both_forms(T):
     """The stride-2 convs' input gradient runs either as ONE depth-to-space contraction with zero-padded taps or phase by phase over
     the non-zero taps (train_model.hip: dgrad_phased picks by size).  Both forms, forced through the environment, must give the same
