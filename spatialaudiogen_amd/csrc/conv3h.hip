@@ -190,9 +190,6 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
         };
 #pragma unroll
         for (int f = 0; f < NF; ++f) load_frag(0, 0, f);
-#ifdef SAGEN_CONV3H_SETPRIO
-        __builtin_amdgcn_s_setprio(SAGEN_CONV3H_SETPRIO);            // a wave inside its MFMA run outranks waves in prologue / epilogue / wait
-#endif
 #pragma unroll
         for (int t = 0; t < 3 * KC; ++t) {
             const int cb = t & 1;
@@ -218,9 +215,6 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
                     }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef SAGEN_CONV3H_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         stage ^= 1;
     };
 
