@@ -223,6 +223,12 @@ __device__ __forceinline__ float4 self_masked(float4 g, const float4& v, const f
     return g;
 }
 
+// the ReLU mask as one bit per element (P3hScale::relu_bits): float4 index i covers the low / high nibble of byte i / 2
+__device__ __forceinline__ float4 bit_masked(float4 g, const unsigned char* bits, long i) {
+    const unsigned b = (unsigned)bits[i >> 1] >> (4 * (int)(i & 1));
+    g.x = (b & 1u) ? g.x : 0.f; g.y = (b & 2u) ? g.y : 0.f; g.z = (b & 4u) ? g.z : 0.f; g.w = (b & 8u) ? g.w : 0.f;
+    return g;
+}
 __device__ __forceinline__ float4 masked_sum(const float4* ga, const float4* gb, const float4* act, long i) {
     float4 v = ga[i];
     if (gb) v = add4(v, gb[i]);
@@ -238,7 +244,7 @@ template <bool MX>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __restrict__ ga, const float4* __restrict__ gb,
                                                             const float4* __restrict__ act, const float4* __restrict__ y, const BnRef bn,
                                                             long n4, int C4, float* __restrict__ part, int self_mask,
-                                                            float* __restrict__ mx_part) {
+                                                            float* __restrict__ mx_part, const unsigned char* __restrict__ bits) {
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 mean, invstd;
     bn_moments4(bn, 4 * C4, c4, mean, invstd);
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
             dz0.x = a0.x > 0.f ? dz0.x : 0.f; dz0.y = a0.y > 0.f ? dz0.y : 0.f; dz0.z = a0.z > 0.f ? dz0.z : 0.f; dz0.w = a0.w > 0.f ? dz0.w : 0.f;
             dz1.x = a1.x > 0.f ? dz1.x : 0.f; dz1.y = a1.y > 0.f ? dz1.y : 0.f; dz1.z = a1.z > 0.f ? dz1.z : 0.f; dz1.w = a1.w > 0.f ? dz1.w : 0.f;
         }
+        if (bits) { dz0 = bit_masked(dz0, bits, i); dz1 = bit_masked(dz1, bits, i + stride); }
         if (self_mask) { dz0 = self_masked(dz0, v0, fsc, fsh); dz1 = self_masked(dz1, v1, fsc, fsh); }
         accumulate(dz0, v0);
         accumulate(dz1, v1);
@@ -276,6 +283,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
     if (i < n4) {
         const float4 v = y[i];
         float4 dz = masked_sum(ga, gb, act, i);
+        if (bits) dz = bit_masked(dz, bits, i);
         if (self_mask) dz = self_masked(dz, v, fsc, fsh);
         accumulate(dz, v);
     }
@@ -291,19 +299,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float4* __rest
 }
 
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, float* scratch, hipStream_t s, int self_mask, float* mx_part, int* mx_blocks) {
-    if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_reduce: self_mask replaces the activation operand");
+                         double* acc, float* scratch, hipStream_t s, int self_mask, float* mx_part, int* mx_blocks, const unsigned char* relu_bits) {
+    if ((self_mask || relu_bits) && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_reduce: self_mask / relu_bits replace the activation operand");
+    if (relu_bits && C % 8) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_reduce: relu_bits need C %% 8 == 0");
     if (!ga || !y || !bn.acc || !acc || !scratch) return fail(SAGEN_ERR_NULL, "bn_bwd_reduce: null argument");
     if (C % 4 || 256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_reduce: C=%d must be 4 * a divisor of 256", C);
     const long n4 = n_pixels * (C / 4);
     const int grid = reduce_grid(n4, C / 4);
     if (mx_part) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
-                           (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask, mx_part);
+                           (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask, mx_part, relu_bits);
         if (mx_blocks) *mx_blocks = grid;
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(grid), dim3(256), 0, s, (const float4*)ga, (const float4*)gb,
-                           (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask, (float*)nullptr);
+                           (const float4*)act, (const float4*)y, bn, n4, C / 4, scratch, self_mask, (float*)nullptr, relu_bits);
     }
     SAGEN_LAUNCH_CHECK();
     hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, s, scratch, grid, 2 * C, acc, (float*)nullptr);
@@ -374,7 +383,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
                                                               float* __restrict__ dy, float* __restrict__ dz_out,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int self_mask,
                                                               char* __restrict__ planes, const float* __restrict__ mx_part, int mx_blocks,
-                                                              float* __restrict__ a_inv, unsigned* __restrict__ sat_count) {
+                                                              float* __restrict__ a_inv, unsigned* __restrict__ sat_count,
+                                                              const unsigned char* __restrict__ bits) {
     const int C8 = C >> 3;
     const long total = nrows * (W + 1) * C8;
     const long cstride = nrows * (W + 1) * 64;
@@ -457,6 +467,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dz[k] = a[k] > 0.f ? dz[k] : 0.f;
             }
+            if (bits) {
+                const unsigned bm = bits[e >> 3];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dz[k] = (bm >> k) & 1u ? dz[k] : 0.f;
+            }
             if (self_mask) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dz[k] = fmaf(v[k], fsc[k], fsh[k]) > 0.f ? dz[k] : 0.f;
@@ -481,13 +496,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_kernel(const float* __res
 
 int bn_bwd_apply_h2_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
                            int B, int H, int W, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask,
-                           void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count) {
-    if (self_mask && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_apply_h2: self_mask replaces the activation operand");
+                           void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count, const unsigned char* relu_bits) {
+    if ((self_mask || relu_bits) && act) return fail(SAGEN_ERR_SHAPE, "bn_bwd_apply_h2: self_mask / relu_bits replace the activation operand");
     if (!ga || !y || !bn.acc || !acc || !planes || !mx_part || !a_inv) return fail(SAGEN_ERR_NULL, "bn_bwd_apply_h2: null argument");
     if (C % 16 || 256 % (C / 8) || mx_blocks < 1) return fail(SAGEN_ERR_UNSUPPORTED, "bn_bwd_apply_h2: C=%d must be 16 * a divisor of 128", C);
     const long total = (long)B * H * (W + 1) * (C / 8);
     hipLaunchKernelGGL(bn_bwd_apply_h2_kernel, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, ga, gb, act, y, bn, acc, (long)B * H, W, C,
-                       dy, dz_out, dgamma, dbeta, self_mask, (char*)planes, mx_part, mx_blocks, a_inv, sat_count);
+                       dy, dz_out, dgamma, dbeta, self_mask, (char*)planes, mx_part, mx_blocks, a_inv, sat_count, relu_bits);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -231,6 +231,9 @@ struct P3hScale {
     double res_inv_count = 0.0;
     float* bound_out = nullptr;         // out: bound of the tensor written (null: not tracked)
     unsigned* sat_count = nullptr;      // out: incremented once per element that had to be clamped to +-65000 (stays 0 unless the statistics lie)
+    // out (nullable, p3_pack only): the ReLU mask of the tensor written, ONE BIT per element - byte (dense pixel * C/8 + channel octet),
+    // bit k = [channel 8*octet + k > 0]: the training step's batch-norm backward reads it instead of the fp32 activation (1/32 of the bytes)
+    unsigned char* relu_bits = nullptr;
 };
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
                    float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);
@@ -320,7 +323,9 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
 // xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat) (overwritten);
 // scratch >= reduce_scratch_floats(C) floats
 int bn_bwd_reduce_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, long n_pixels, int C,
-                         double* acc, float* scratch, hipStream_t s, int self_mask = 0, float* mx_part = nullptr, int* mx_blocks = nullptr);
+                         double* acc, float* scratch, hipStream_t s, int self_mask = 0, float* mx_part = nullptr, int* mx_blocks = nullptr,
+                         const unsigned char* relu_bits = nullptr);
+// relu_bits (nullable; act must be null then): the ReLU mask as one bit per element (P3hScale::relu_bits) instead of the activation
 // mx_part (nullable, >= 2 * 512 floats): per-workgroup (max |dz|, max |xhat|); *mx_blocks = the number of workgroups that wrote it
 // dy = gamma*invstd*(dz - acc0/N - xhat*acc1/N) (+ dz to `dz_out`, nullable); writes dgamma = acc1, dbeta = acc0 (nullable)
 int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
@@ -329,7 +334,8 @@ int bn_bwd_apply_launch(const float* ga, const float* gb, const float* act, cons
 // bound behind kd comes from the reduce pass's mx_part; dy may be null then (no fp32 copy)
 int bn_bwd_apply_h2_launch(const float* ga, const float* gb, const float* act, const float* y, const BnRef& bn, const double* acc,
                            int B, int H, int W, int C, float* dy, float* dz_out, float* dgamma, float* dbeta, hipStream_t s, int self_mask,
-                           void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count);
+                           void* planes, const float* mx_part, int mx_blocks, float* a_inv, unsigned* sat_count,
+                           const unsigned char* relu_bits = nullptr);
 // self_mask = 1 (act must be null): the ReLU mask is relu(bn(y)) > 0, re-derived from y with the forward's own scale / shift - for a
 // layer whose activation IS relu(bn(y)) (no residual), e.g. conv_1 of a residual block: one tensor less to read in both passes
 // backward of maxpool3x3s2(relu(bn(y0))) (resnet.py:134-135): dz0[b,i,j,c] = (a > 0) * sum over the windows containing (i,j) of

@@ -793,7 +793,10 @@ struct Fwd {
                 layer = pfx + "/merge";
                 P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
                                      : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
-                if (keep && p3_here) hs2.a_inv = pl_a_inv(8 + kidx + 1);
+                if (keep && p3_here) {
+                    hs2.a_inv = pl_a_inv(8 + kidx + 1);
+                    hs2.relu_bits = reinterpret_cast<unsigned char*>(c->p("t:mb:" + k));       // the block output's ReLU mask, one bit per element
+                }
                 if (p3_here) xb_par ^= 1;
                 if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y2, nullptr, nullptr, bn2, shortcut, 1, xout, nplanes, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
                 else timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(y2, nullptr, nullptr, bn2, shortcut, xout, (long)B * Ho * Wo, cout, s); });

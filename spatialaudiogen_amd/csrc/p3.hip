@@ -192,6 +192,12 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
                 *reinterpret_cast<float4*>(y + e) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(y + e + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
+            if (h2.relu_bits) {
+                unsigned bits = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bits |= (v[k] > 0.f ? 1u : 0u) << k;
+                h2.relu_bits[e >> 3] = (unsigned char)bits;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = 0.f;

@@ -140,6 +140,8 @@ static void train_carve(sagen_ctx* c) {
             for (int k = 0; k < 8; ++k) {
                 const size_t n = p3h_bytes(B, RS_H[k / 2], RS_W[k / 2], RS_C[k / 2]) / sizeof(float);
                 c->talloc("t:pl:a1:" + std::to_string(k) + x, n);
+                // the ReLU mask of the block output, one bit per element (written by the merge pass, read by conv_2's batch-norm backward)
+                c->talloc("t:mb:" + std::to_string(k) + x, ((size_t)B * RS_H[k / 2] * RS_W[k / 2] * RS_C[k / 2] / 8 + 3) / 4);
                 if (k == 0 || (k & 1)) c->talloc("t:pl:x:" + std::to_string(k) + x, n);
             }
             c->talloc("t:h2a" + x, 32);
@@ -424,7 +426,7 @@ struct Bwd : Fwd {
     // planes_only: no fp32 dy at all (the weight gradient reads the planes too)
     bool bn_bwd(const std::string& bn_name, int li, const float* ga, const float* gb, const float* act, const float* y, long npix, int C,
                 float* dy, float* dz, bool self_mask = false, int H = 0, int W = 0, void* planes = nullptr, float* planes_a_inv = nullptr,
-                bool planes_only = false) {
+                bool planes_only = false, const unsigned char* relu_bits = nullptr) {
         if (rc) return false;
         if (H > 0 && planes && h2d_on(c) && c->h2d_slot.count(bn_name + "/weights")) {
             const BnRef bn = bn_ref(li, bn_name, npix);
@@ -432,13 +434,13 @@ struct Bwd : Fwd {
             layer = "bnbwd:" + bn_name;
             static const bool no_self = getenv("SAGEN_BN_READ_ACT") != nullptr;
             const int sm = self_mask && !no_self;
-            const float* a = sm ? nullptr : act;
+            const float* a = (sm || relu_bits) ? nullptr : act;     // (the one-bit mask replaces the fp32 activation: 1/32 of its bytes, twice)
             float* mx = c->p("t:mxpart" + sfx);
             int nb = 0;
-            timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, a, y, bn, npix, C, acc, c->p(redws), s, sm, mx, &nb); });
+            timed("bn_bwd_reduce_kernel", 0.0, [&] { return bn_bwd_reduce_launch(ga, gb, a, y, bn, npix, C, acc, c->p(redws), s, sm, mx, &nb, relu_bits); });
             timed("bn_bwd_apply_h2_kernel", 0.0, [&] {
                 return bn_bwd_apply_h2_launch(ga, gb, a, y, bn, acc, c->B, H, W, C, planes_only ? nullptr : dy, dz, grad(bn_name + "/bn/gamma"), grad(bn_name + "/bn/beta"), s, sm,
-                                              planes, mx, nb, planes_a_inv, reinterpret_cast<unsigned*>(c->p("h2s") + 7)); });
+                                              planes, mx, nb, planes_a_inv, reinterpret_cast<unsigned*>(c->p("h2s") + 7), relu_bits); });
             return !rc;
         }
         bn_bwd_plain(bn_name, li, ga, gb, act, y, npix, C, dy, dz, self_mask);
@@ -489,9 +491,11 @@ struct Bwd : Fwd {
             const int li1 = 1 + 2 * k, li2 = 2 + 2 * k;
             // out = relu(bn2(y2) + shortcut)
             const bool planes_on = h2d_on(c) && c->tbufs.count("t:DPc0" + sfx) != 0;
+            static const bool no_relu_bits = getenv("SAGEN_TRAIN_NO_RELU_BITS") != nullptr;      // (A/B: conv_2's batch-norm backward reads the fp32 block output for its ReLU mask)
             void* DP2 = planes_on ? dp_buf(0, k & 1) : nullptr;
             void* DP1 = planes_on ? dp_buf(1, k & 1) : nullptr;
-            const bool P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo, DP2, planes_on ? dp_a_inv(0, k & 1) : nullptr, h2w() && !wgrad_reads_fp32_operands());
+            const bool P2 = bn_bwd(pfx + "/conv_2", li2, ga, gb, out, y2, npix, cout, DY, Z, false, Ho, Wo, DP2, planes_on ? dp_a_inv(0, k & 1) : nullptr, h2w() && !wgrad_reads_fp32_operands(),
+                                   h2w() && !no_relu_bits ? reinterpret_cast<const unsigned char*>(c->p("t:mb:" + ks)) : nullptr);
             {
                 WgradDesc w = wdesc(a1, Ho, Wo, cout, cout, DY, Ho, Wo, cout, cout, 3, 3, 1, 1, -1, -1);
                 if (P2 && h2w()) w = with_planes(w, pl_buf("a1", k), pl_a_inv(k), DP2, dp_a_inv(0, k & 1));
