@@ -797,15 +797,17 @@ __device__ __forceinline__ void pack_store4(const PackJob& j, int n, int k, cons
     *reinterpret_cast<bf16x4_t*>(w3 + o + (long)j.N * 32) = bf16x4_t{l[0], l[1], l[2], l[3]};
 }
 
-__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    // job of this block: the last one whose first_block <= blockIdx.x (wave-uniform binary search)
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs, int block0) {
+    // job of this block: the last one whose first_block <= block (wave-uniform binary search); block0: a launch over a suffix / prefix
+    // of the table keeps the table's block numbering
+    const int block = (int)blockIdx.x + block0;
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (jobs[mid].first_block <= block) lo = mid; else hi = mid - 1;
     }
     const PackJob j = jobs[lo];
-    const int blk = (int)blockIdx.x - j.first_block;
+    const int blk = block - j.first_block;
     if (j.kind == PACK_CONV) {
         // HWIO -> [N][K] is a transpose: a 32 (k) x 32 (n) tile per block, read along n (the source's fast index: 128-byte runs;
         // thread-per-destination-element reads fetched 335 MB for 123 MB of variables), written along k
@@ -854,9 +856,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
     pack_store4(j, n, k, v);
 }
 
-int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s) {
+int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s, int block0) {
     if (!jobs_dev || njobs <= 0 || nblocks <= 0) return fail(SAGEN_ERR_NULL, "pack_multi: no jobs");
-    hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, njobs, block0);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

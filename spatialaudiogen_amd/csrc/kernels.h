@@ -179,7 +179,8 @@ struct PackJob {
 inline int pack_job_blocks(int kind, long N, long Kpad) {
     return kind == PACK_CONV ? (int)(((N + 31) / 32) * ((Kpad + 31) / 32)) : (int)((N * Kpad + 1023) / 1024);
 }
-int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s);
+// block0: the launch covers blocks [block0, block0 + nblocks) of the table's numbering (jobs_dev / njobs = the jobs those blocks belong to)
+int pack_multi_launch(const PackJob* jobs_dev, int njobs, int nblocks, hipStream_t s, int block0 = 0);
 // deconv as depth-to-space conv: n = (ry, rx, o), k = (dp, dq, c);
 // Wp[n][k] = W[ry + sh*dp][rx + sw*dq][o][c] (0 when outside the kh x kw kernel)
 int pack_deconv_launch(const float* w_hwoi, int kh, int kw, int cout, int cin, int sh, int sw,

@@ -65,7 +65,9 @@ struct sagen_ctx {
     hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;
     // second, context-owned stream: the audio chain (and the flow trunk) run under the video trunk
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stft = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_stft = nullptr, ev_pack = nullptr;
+    int pack_early_jobs = 0, pack_early_blocks = 0;     // the stems' jobs come first in the pack table: the training step packs them on the caller's stream, the rest on the second stream under the stem (late_repack)
+    bool late_repack = false;
     // optional per-launch HIP-event profiler (sagen_profile_enable)
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -212,6 +214,8 @@ static inline int auto_splitk(const IgemmDesc& d, IgemmTile tile) {
 
 
 int sagen_repack_impl(sagen_ctx* c, hipStream_t s);
+int sagen_repack_part(sagen_ctx* c, hipStream_t s, int part);     // 0: all; 1: the stems' packs; 2: the rest + fp16x2 planes (model.hip)
+bool sagen_forward_forks(const sagen_ctx* c);
 int sagen_upload_pack_jobs(std::vector<PackJob>& jobs, void* dev, hipStream_t s);
 int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
 
@@ -225,6 +229,7 @@ struct Fwd {
     std::string wsname = "splitk";   // split-K scratch of this launch stream
     std::string sfx;                 // suffix of the trunk buffers this stream owns ("" or "_b")
     hipEvent_t wait_before_mfma = nullptr;   // event the first contraction of this stream has to wait for (see forward)
+    hipEvent_t wait_packs = nullptr;         // training step: the filter packs of everything behind the stem (second stream, sagen_forward_impl)
 
     hipEvent_t next_event() {
         if (c->events_used == c->event_pool.size()) {
@@ -745,6 +750,10 @@ struct Fwd {
             }
             ++li;
             H = (H + 1) / 2; W = (W + 1) / 2;
+        }
+        if (!rc && wait_packs) {                 // everything from here on reads filters the second stream packed meanwhile
+            if (hipStreamWaitEvent(s, wait_packs, 0) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "hipStreamWaitEvent failed");
+            wait_packs = nullptr;
         }
         const float* xin = c->p("t:x0" + sfx);
         int cin = 64;

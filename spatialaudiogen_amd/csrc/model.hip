@@ -196,6 +196,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         c->aux = nullptr;      // no device / no stream: forward falls back to a single stream (and fails at launch)
@@ -288,17 +289,29 @@ int sagen_upload_pack_jobs(std::vector<PackJob>& jobs, void* dev, hipStream_t s)
     return nb;
 }
 
-int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
+// part 0: everything; 1: only the stems' packs (first in the table); 2: the rest + the fp16x2 planes (the training step runs 1 on
+// the caller's stream and 2 on the second stream, under the stem)
+int sagen_repack_part(sagen_ctx* c, hipStream_t s, int part) {
     if (c->pack_jobs.empty()) {          // first call after bind: build the table from the bound variables and ship it
-        for (const auto& vs : c->vars) {
-            if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
-            c->pack_jobs.push_back(forward_pack_job(c, vs));
+        for (int pass = 0; pass < 2; ++pass) {
+            for (const auto& vs : c->vars) {
+                if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
+                const bool stem = vs.name.find("/conv1/conv/") != std::string::npos;
+                if (stem == (pass == 0)) c->pack_jobs.push_back(forward_pack_job(c, vs));
+            }
+            if (pass == 0) c->pack_early_jobs = (int)c->pack_jobs.size();
         }
         if (c->pack_jobs.size() * sizeof(PackJob) > c->bufs.at("pk:jobs").n * sizeof(float)) return fail(SAGEN_ERR_WORKSPACE, "pack job table too small");
         c->pack_blocks = sagen_upload_pack_jobs(c->pack_jobs, c->p("pk:jobs"), s);
         if (c->pack_blocks < 0) return fail(SAGEN_ERR_HIP, "pack job upload failed");
+        c->pack_early_blocks = c->pack_early_jobs < (int)c->pack_jobs.size() ? c->pack_jobs[c->pack_early_jobs].first_block : c->pack_blocks;
     }
-    int rc = pack_multi_launch(reinterpret_cast<const PackJob*>(c->p("pk:jobs")), (int)c->pack_jobs.size(), c->pack_blocks, s);
+    const PackJob* jobs = reinterpret_cast<const PackJob*>(c->p("pk:jobs"));
+    const int ne = c->pack_early_jobs, be = c->pack_early_blocks, n = (int)c->pack_jobs.size();
+    int rc = SAGEN_OK;
+    if (part == 1) return ne > 0 ? pack_multi_launch(jobs, ne, be, s) : SAGEN_OK;
+    if (part == 2) rc = n > ne ? pack_multi_launch(jobs + ne, n - ne, c->pack_blocks - be, s, be) : SAGEN_OK;
+    else rc = pack_multi_launch(jobs, n, c->pack_blocks, s);
     if (rc || c->fp32_only || !c->use_p3) return rc;
     // the fp16x2 filter planes of the trunks' 3x3 convs and 1x1 projections, from the fp32 packs just written: two launches for all
     // of them (bind; every training step)
@@ -323,6 +336,12 @@ int sagen_repack_impl(sagen_ctx* c, hipStream_t s) {
     return h2_filter_pack_multi_launch(reinterpret_cast<const H2Job*>(c->p("h2:jobs")), (int)c->h2_jobs.size(), c->h2_blocks,
                                        reinterpret_cast<unsigned*>(c->p("h2:amax")), s);
 }
+int sagen_repack_impl(sagen_ctx* c, hipStream_t s) { return sagen_repack_part(c, s, 0); }
+// does sagen_forward_impl fork onto the context's second stream?  (the training step's split repack relies on it)
+bool sagen_forward_forks(const sagen_ctx* c) {
+    static const bool one_stream = getenv("SAGEN_ONE_STREAM") != nullptr;
+    return c->aux && !c->tuning && !one_stream && (c->has_video || c->has_flow);
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -341,8 +360,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // (context-owned) carries the independent audio chain and, with three encoders, the flow trunk.  They fork at
     // entry and join before the localisation FCs.  While autotuning, or without visual encoders, everything
     // stays on the caller's stream.
-    static const bool one_stream = getenv("SAGEN_ONE_STREAM") != nullptr;
-    const bool forked = c->aux && !c->tuning && !one_stream && (c->has_video || c->has_flow);
+    const bool forked = sagen_forward_forks(c);
     Fwd f{c, s};
     Fwd g{c, forked ? c->aux : s};
     // error exit: work may still be queued on the context's stream, reading the caller's tensors / the workspace - the caller's
@@ -368,6 +386,14 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         // (open): the first matrix launch of the main stream waits for the STFT (it overlaps the pad kernel).
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_stft, c->aux));
         f.wait_before_mfma = c->ev_stft;
+    }
+    if (c->late_repack) {            // training step: every filter pack but the stems', here - under the stem of the main stream
+        c->late_repack = false;
+        if (!forked) return bail(fail(SAGEN_ERR_UNSUPPORTED, "late repack without a second stream"));
+        const int rc = sagen_repack_part(c, c->aux, 2);
+        if (rc) return bail(rc);
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_pack, c->aux));
+        f.wait_packs = c->ev_pack;
     }
 
     // audio encoder (model.py:161-187): conv l writes the encoder half of concat buffer l
@@ -500,6 +526,7 @@ void sagen_destroy_impl(sagen_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_stft) (void)hipEventDestroy(c->ev_stft);
+    if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     delete c;
 }

@@ -750,16 +750,26 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
                           const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s) {
     if (!c || !audio || !target) return fail(SAGEN_ERR_NULL, "sagen_train_step: null argument");
     if (!c->train_ready) return fail(SAGEN_ERR_WORKSPACE, "sagen_train_step: call sagen_train_bind first");
-    int rc = sagen_repack_impl(c, s);                  // the optimiser updated the variables in place
+    // the optimiser updated the variables in place: re-pack the filters.  With two streams only the stems' packs run here; the rest
+    // (123 MB of variables -> 430 MB of packs, ~190 us) runs on the second stream behind the STFT, under pad + stem + pool of this one
+    static const bool no_split_repack = getenv("SAGEN_NO_SPLIT_REPACK") != nullptr;
+    const bool split_repack = !no_split_repack && c->ev_pack && c->ev_fork && !c->profiling && sagen_forward_forks(c) && c->train_ready;
+    int rc = split_repack ? sagen_repack_part(c, s, 1) : sagen_repack_impl(c, s);
+    c->late_repack = split_repack && !rc;
     // the data-gradient packs are first needed after the forward: on the second stream, under it
     static const bool one_stream_pack = getenv("SAGEN_BWD_ONE_STREAM") != nullptr;
     const bool pack_aux = c->aux && c->ev_fork && !one_stream_pack && !c->tuning && !c->profiling;
-    if (!rc && pack_aux) {
+    // ... enqueued BEHIND the forward's own work on that stream: the main stream's first matrix launch waits for the STFT of the
+    // second stream, and with the packs in front of it the stem started 0.2 ms late
+    static const bool packs_first = getenv("SAGEN_DGRAD_PACKS_FIRST") != nullptr;      // (A/B: the round-3 order)
+    if (!rc && pack_aux && packs_first) {
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
         SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         rc = repack_dgrad(c, c->aux);
-    } else if (!rc) {
+    } else if (!rc && !pack_aux) {
         rc = repack_dgrad(c, s);
+    } else if (!rc) {
+        SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));     // the optimiser's update of the variables (a forward that does not fork never re-records it)
     }
     if (rc) return rc;
     float* pred = pred_out ? pred_out : c->p("t:pred");
@@ -768,6 +778,11 @@ int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, 
     c->train_mode = false;
     if (rc) return rc;
     if (pack_aux) {                                    // (the forward joins the second stream only when it forked)
+        if (!packs_first) {
+            SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));      // (a forked forward has long passed a later record of it)
+            rc = repack_dgrad(c, c->aux);
+            if (rc) return rc;
+        }
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
         SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
