@@ -10,13 +10,13 @@
 //
 // Workgroup = (filter row th, BM channels of G, BN of D, a range of 16-pixel K steps).  Per step both tiles go global -> LDS by
 // LDS-DMA (1 KiB per wave-instruction: 16 pixels x 32 channels of one plane), into a RING of five steps per (32-channel pair,
-// plane): 80 pixel rows x 64 B, contiguous in the pixel index; the chunk of step c + 4 is issued during step c (a round trip to HBM
-// is several steps long: with a lead of one step every step waited for it - 60 us per layer instead of 4x).  G is staged ONCE for the three horizontal taps, as the stream
-// u -> G[u + (th-1)(W+1) - 1]: tap tw of step c reads stream rows 16c + tw .. + 15, i.e. two rows into the NEXT step's chunk, which
+// plane): 80 pixel rows x 64 B, contiguous in the pixel index; the chunk of step c + 4 is issued during step c and the step waits
+// with vmcnt(2 chunks' worth) - a round trip to memory is several 16-pixel steps long.  G is staged ONCE for the three horizontal
+// taps, as the stream u -> G[u + (th-1)(W+1) - 1]: tap tw of step c reads stream rows 16c + tw .. + 15, i.e. two rows into the NEXT step's chunk, which
 // the ring keeps adjacent (the wrap at the last row is a per-lane constant).  The matrix cores want 8 consecutive pixels of one channel
 // per lane: ds_read_b64_tr_b16 delivers them from the [pixel][channel] image (lane mapping: wgrad.hip, tools/probe/tr16.py); a
 // lane group reads THREE 4-pixel blocks (12 rows) per operand tile and step, and the fragments of taps 1 and 2 are cut out of
-// those registers (v_alignbit for the odd shift) instead of being read again.  The product is scaled by 2^-(ka + kd) in the
+// those registers (one v_perm per dword for the odd shift) instead of being read again.  The product is scaled by 2^-(ka + kd) in the
 // epilogue (exact).  Split-K partials and their fixed-order reduction as in wgrad.hip.
 #include "igemm3_common.h"
 
