@@ -190,6 +190,9 @@ def main_train(args, cfg):
     net.load_variables(P)
     tr = Trainer(net, batch=BATCH, lr=1e-4, lr_iters=250000, lr_decay=0.5)     # train.py defaults
     dev = [torch.as_tensor(inp[k]).cuda() if k in inp else None for k in ('audio', 'video', 'flow')] + [torch.as_tensor(target).cuda()]
+    if dev[1] is not None and not args.float_frames:
+        # frames as the training feeder decodes them (uint8; x / 255 - 0.5 on the device, sagen_train_step_u8): the default entry point
+        dev[1] = torch.round((dev[1].double() + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
 
     # launch plan: tuned on rank 0, broadcast, so that every rank runs the same kernels
     plan = []
@@ -305,6 +308,7 @@ def main_train(args, cfg):
                  'three bf16 planes (6 products) elsewhere - every gradient against fp64 autograd in tests/test_gpu_backward.py)',
         'data': 'synthetic',
         'config': {'workload': cfg['workload'], 'name': 'train', 'windows_per_gpu_per_step': BATCH,
+                   'video_frames': 'float32' if args.float_frames else 'uint8 as decoded (x / 255 - 0.5 applied on the device), sagen_train_step_u8',
                    'windows_per_s': round(BATCH * world * steps / elapsed, 1), 'optimizer': 'Adam (lr 1e-4), fused over %d flat buckets' % len(tr.opt.params),
                    'gradient_exchange': 'sum all-reduce of %d buckets (%.0f MB) per step over %d rank(s), %s' % (
                        len(tr.opt.grads), sum(g.numel() for g in tr.opt.grads) * 4 / 1e6, world, backend if world > 1 else 'none'),

@@ -265,6 +265,11 @@ int sagen_train_bind(sagen_ctx* ctx, const sagen_tensor* grads, int n_grads, con
                      void* train_workspace, size_t train_workspace_bytes, void* stream);
 int sagen_train_step(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
                      const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream);
+/* The same with the video frames as the training feeder decodes them (feeder.py:222-260: uint8 [B,224,448,3], normalised
+ * x / 255 - 0.5 by myutils.py:88-89 - here on the device, as in sagen_forward_u8): the stem's forward runs on the exact one-plane
+ * operand u - 128 (three matrix products per multiply instead of six). */
+int sagen_train_step_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video_u8, const float* flow, const float* target_yzx,
+                        const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream);
 /* sagen_autotune for the training step: one step on these inputs in which every contraction (forward and data gradients) times
  * its launch candidates; the plan is stored in the ctx.  The gradients it leaves behind are not meaningful.  Synchronises. */
 int sagen_train_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,

@@ -77,6 +77,7 @@ SIGNATURES = {
     'sagen_train_workspace_bytes': (_SZ, [_P]),
     'sagen_train_bind': (C.c_int, [_P, C.POINTER(SagenTensor), _I, C.POINTER(SagenTensor), _I, _P, _SZ, _P]),
     'sagen_train_step': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    'sagen_train_step_u8': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     'sagen_train_autotune': (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'sagen_train_get_buffer': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_SZ)]),
     'sagen_train_set_grad_events': (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), _I, C.POINTER(_P), _I]),

@@ -26,6 +26,8 @@ int sagen_counter_impl(sagen_ctx* c, const char* name, uint64_t* value, hipStrea
 size_t sagen_train_workspace_bytes_impl(sagen_ctx* c);
 int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving, void* tws,
                           size_t tws_bytes, hipStream_t s);
+int sagen_train_step_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video_u8, const float* flow, const float* target,
+                             const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s);
 int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
                           const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s);
 int sagen_train_get_buffer_impl(const sagen_ctx* c, const char* name, const float** data, size_t* n);
@@ -408,6 +410,11 @@ int sagen_train_step(sagen_ctx* ctx, const float* audio, const float* video, con
                      const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream) {
     if (loss && ((uintptr_t)loss) % 8) return fail(SAGEN_ERR_SHAPE, "sagen_train_step: loss must be 8-byte aligned");
     return guarded([&] { return sagen_train_step_impl(ctx, audio, video, flow, target_yzx, mask, pred_yzx, loss, update_moving_averages, (hipStream_t)stream); });
+}
+int sagen_train_step_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video_u8, const float* flow, const float* target_yzx,
+                        const float* mask, float* pred_yzx, double* loss, int update_moving_averages, void* stream) {
+    if (loss && ((uintptr_t)loss) % 8) return fail(SAGEN_ERR_SHAPE, "sagen_train_step_u8: loss must be 8-byte aligned");
+    return guarded([&] { return sagen_train_step_u8_impl(ctx, audio, video_u8, flow, target_yzx, mask, pred_yzx, loss, update_moving_averages, (hipStream_t)stream); });
 }
 int sagen_train_autotune(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, const float* target_yzx,
                          const float* mask, void* stream) {

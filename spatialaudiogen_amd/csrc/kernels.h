@@ -210,6 +210,7 @@ int stempool_launch(const float* xpad, const float* wp, const float* gamma, floa
 size_t stem8_plane_bytes(int B);
 int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s);
 int stem8pool_launch(const void* plane, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
+int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats, int B, hipStream_t s);      // no pool: the raw output (training step)
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);

@@ -729,17 +729,31 @@ struct Fwd {
         else
             timed("pad_nhwc3to4_kernel", 0.0, [&] { return pad_nhwc3to4_launch(img, c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         int H = 0, W = 0;
+        // uint8 frames (sagen_train_step_u8): the stem's forward on the exact one-plane operand (stem8.hip, RAW: y0 is kept for the
+        // backward); the float xpad above is still what the stem's weight gradient contracts
+        const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && c->tbufs.count("t:s8plane" + sfx) != 0;
+        if (fast8) {
+            layer = scope + "/plane";
+            timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("t:s8plane" + sfx), B, s); });
+        }
         if (!rc && wait_before_mfma) {
             if (hipStreamWaitEvent(s, wait_before_mfma, 0) != hipSuccess) rc = fail(SAGEN_ERR_HIP, "hipStreamWaitEvent failed");
             wait_before_mfma = nullptr;
         }
         {
             const std::string name = scope + "/conv1/conv";
-            IgemmDesc d = conv_desc(c->p("xpad" + sfx), 229, 454, 4, 4, c->p("pk:" + name + "/weights"), 7, 8, 2, 2, false, 64,
-                                    c->p("y0" + sfx), 64, H, W);
-            d.stats = bn_acc(li);
-            layer = name;
-            contract(d);
+            if (fast8) {
+                H = 112; W = 224;
+                layer = name;
+                timed("stem8pool_kernel<raw>", 2.0 * B * H * W * 64 * 224, [&] {
+                    return stem8raw_launch(c->p("t:s8plane" + sfx), c->p("pk:" + name + "/weights"), c->p("y0" + sfx), bn_acc(li), B, s); });
+            } else {
+                IgemmDesc d = conv_desc(c->p("xpad" + sfx), 229, 454, 4, 4, c->p("pk:" + name + "/weights"), 7, 8, 2, 2, false, 64,
+                                        c->p("y0" + sfx), 64, H, W);
+                d.stats = bn_acc(li);
+                layer = name;
+                contract(d);
+            }
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
             if (keep) {                         // the pooled block input also as (retained) planes: stage 2 runs on planes as well
                 P3hScale hs0 = h2_scale(h2_xbound(0));

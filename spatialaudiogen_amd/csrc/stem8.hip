@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
     }
 }
 
+// RAW: no pool - the owned 16 x 14 raw outputs of every patch go to y0 [B,112,224,64] (the training step keeps the raw stem output for
+// the batch-norm backward and pools it in the pass that also writes the planes of the pooled tensor)
+template <bool RAW>
 __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
                                                                   const char* __restrict__ wplanes, const float* __restrict__ gamma,
                                                                   float* __restrict__ pooled, double* __restrict__ stats, int B) {
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     const int pch4 = tid & 7;                        // pooling: this thread's 4 channels, max or min per channel
     bool use_min[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) use_min[k] = gamma[nh * S8_NH + 4 * pch4 + k] < 0.f;
+    for (int k = 0; k < 4; ++k) use_min[k] = RAW ? false : gamma[nh * S8_NH + 4 * pch4 + k] < 0.f;
     // statistics straight from the accumulators: which of this lane's 16 tile rows are pixels the patch OWNS (16 x 14 of the 17 x 15;
     // the halo row / column belongs to the neighbour) - the same for every patch
     unsigned own = 0;
@@ -173,6 +176,15 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
             ssq = fmaf(vo, vo, ssq);
         }
         __syncthreads();
+        if (RAW) {
+            // the patch's own pixels, 128 contiguous bytes (this half's 32 channels) per pixel
+            for (int it = tid; it < 2 * S8_PH * 2 * S8_PW * 8; it += S8_THREADS) {
+                const int p = it >> 3, q4 = it & 7;
+                const int r = p / (2 * S8_PW), cc = p - r * (2 * S8_PW);
+                *reinterpret_cast<float4*>(pooled + (((long)b * 112 + R0 + r) * 224 + C0 + cc) * 64 + nh * S8_NH + 4 * q4) =
+                    *reinterpret_cast<const float4*>(ct + (r * S8_RW + cc) * S8_NH + 4 * q4);
+            }
+        } else
         // pool 3x3 / 2 (TF SAME: nothing before, one row / column after -> clipped at the image edge): one item per thread
         if (tid < S8_PH * S8_PW * 8) {
             const int p = tid >> 3;
@@ -229,13 +241,29 @@ int stem8pool_launch(const void* plane, const float* wp, const float* gamma, flo
     if (!plane || !wp || !gamma || !pooled || !stats) return fail(SAGEN_ERR_NULL, "stem8pool: null argument");
     static bool attr_set = false;
     if (!attr_set) {
-        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
+    hipLaunchKernelGGL(stem8pool_kernel<false>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
                        pooled, stats, B);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// the same contraction without the pool: y0 [B,112,224,64] = the raw stem output (training step), statistics as above
+int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats, int B, hipStream_t s) {
+    if (!plane || !wp || !y0 || !stats) return fail(SAGEN_ERR_NULL, "stem8raw: null argument");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        attr_set = true;
+    }
+    const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
+    const int npatch = B * 7 * 16;
+    hipLaunchKernelGGL(stem8pool_kernel<true>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
+                       (const float*)nullptr, y0, stats, B);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

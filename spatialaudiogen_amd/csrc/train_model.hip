@@ -130,6 +130,7 @@ static void train_carve(sagen_ctx* c) {
         // phase (0, 0) and relies on the other three being zero since bind (a shared buffer would keep another stage's values there)
         for (int st = 1; st <= 3; ++st) c->talloc("t:S" + std::to_string(st) + x, stage);
         c->talloc("t:dz0" + x, (size_t)B * 112 * 224 * 64);
+        if (set == 0 && c->has_video) c->talloc("t:s8plane" + x, stem8_plane_bytes(B) / sizeof(float) + 64);     // uint8 frames: the centred bf16 plane (stem8.hip)
         c->talloc("t:bnbacc" + x, (size_t)24 * 2 * 512 * 2);
         if (h2d_on(c)) {                   // dy of a stride-1 3x3 conv as fp16x2 planes (largest: stage 2) + the reduce pass's per-workgroup maxima
             // (double-buffered over the block parity like the fp32 dy: the weight gradients on the second stream read them too)
@@ -746,6 +747,18 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
     return SAGEN_OK;
 }
 
+int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
+                          const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s);
+// uint8 frames (sagen_train_step_u8): the pad pass normalises them for the stem's weight gradient, the stem's forward reads u - 128
+int sagen_train_step_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video_u8, const float* flow, const float* target,
+                             const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s) {
+    if (!c) return fail(SAGEN_ERR_NULL, "sagen_train_step_u8: null ctx");
+    if (!c->has_video) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_train_step_u8: the video encoder is not enabled");
+    c->video_u8 = true;
+    const int rc = sagen_train_step_impl(c, audio, reinterpret_cast<const float*>(video_u8), flow, target, mask, pred_out, loss_out, update_moving, s);
+    c->video_u8 = false;
+    return rc;
+}
 int sagen_train_step_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, const float* target,
                           const float* mask, float* pred_out, double* loss_out, int update_moving, hipStream_t s) {
     if (!c || !audio || !target) return fail(SAGEN_ERR_NULL, "sagen_train_step: null argument");

@@ -270,12 +270,15 @@ class Trainer(object):
         arr_e = (C.c_void_p * nb)(*[e.cuda_event for e in self.bucket_events])
         check(_lib.lib().sagen_train_set_grad_events(self.ctx.handle, arr_n, arr_b, len(names), arr_e, nb))
 
-    def _prep(self, t, tail):
+    def _prep(self, t, tail, keep_u8=False):
         import torch
         if t is None:
             return None
         t = torch.as_tensor(np.asarray(t)) if not isinstance(t, torch.Tensor) else t
-        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if keep_u8 and t.dtype == torch.uint8:          # frames as decoded: normalised on the device (sagen_train_step_u8)
+            t = t.to(device=self.device).contiguous()
+        else:
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
         if tuple(t.shape) != (self.batch,) + tail:
             raise ValueError('expected shape %s, got %s' % ((self.batch,) + tail, tuple(t.shape)))
         return t
@@ -287,13 +290,14 @@ class Trainer(object):
         from ._lib import check
         from .definitions import VIDEO, FLOW
         a = self._prep(audio, (52799, 1))
-        v = self._prep(video, (1, 224, 448, 3)) if VIDEO in self.net.encoders else None
+        v = self._prep(video, (1, 224, 448, 3), keep_u8=True) if VIDEO in self.net.encoders else None
         f = self._prep(flow, (1, 224, 448, 3)) if FLOW in self.net.encoders else None
         t = self._prep(target, (4800, 3))
         mk = channel_mask(mask, self.batch, self.device)
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(_lib.lib().sagen_train_step(self.ctx.handle, p(a), p(v), p(f), p(t), p(mk), p(self.pred), p(self.loss), int(update_moving), stream))
+        step = _lib.lib().sagen_train_step_u8 if (v is not None and v.dtype == torch.uint8) else _lib.lib().sagen_train_step
+        check(step(self.ctx.handle, p(a), p(v), p(f), p(t), p(mk), p(self.pred), p(self.loss), int(update_moving), stream))
         return self.loss
 
     def step(self, audio, video, flow, target, mask=None, comm_timing=None):
@@ -362,6 +366,8 @@ class Trainer(object):
         from ._lib import check
         from .definitions import VIDEO, FLOW
         a = self._prep(audio, (52799, 1))
+        if isinstance(video, torch.Tensor) and video.dtype == torch.uint8:     # (the tuning step takes float frames: x / 255 - 0.5)
+            video = video.to(torch.float32) / 255.0 - 0.5
         v = self._prep(video, (1, 224, 448, 3)) if VIDEO in self.net.encoders else None
         f = self._prep(flow, (1, 224, 448, 3)) if FLOW in self.net.encoders else None
         t = self._prep(target, (4800, 3))

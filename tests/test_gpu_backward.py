@@ -365,6 +365,36 @@ np.savez(sys.argv[1], **{k.replace('/', '|'): tr.grad(k).cpu().numpy() for k in 
             assert np.array_equal(out[0][k], out[1][k]), k
 
 
+def test_uint8_frames_train_step_matches_the_float_entry_point(T):
+    """sagen_train_step_u8: frames as the feeder decodes them.  The stem's forward runs on the exact one-plane operand u - 128
+    (stem8.hip, RAW variant: y0 is kept for the backward) - against the float entry point on x = u / 255 - 0.5 the loss must agree to
+    fp32 rounding, the decoder-side gradients tightly, the rest at the free-running bar (the stem's output differs by the rounding of x)."""
+    net, ref, P, inp, target = _setup(T, ['audio', 'video'], 2, 4)
+    from spatialaudiogen_amd.train import Trainer
+    tr = Trainer(net, batch=2)
+    v = T.as_tensor(inp['video']).cuda()
+    u8 = T.round((v.double() + 0.5) * 255.0).clamp(0, 255).to(T.uint8)
+    vf = (u8.to(T.float32) / 255.0 - 0.5)
+    out = []
+    for frames in (vf, u8):
+        loss = tr.forward_backward(inp['audio'], frames, None, target, update_moving=False)
+        T.cuda.synchronize()
+        out.append((float(loss), {k: tr.grad(k).cpu().numpy().copy() for k in tr.opt.layout}))
+    tr.profile_enable(True)
+    tr.forward_backward(inp['audio'], u8, None, target, update_moving=False)
+    kernels = [k for k, layer, us, fl in tr.profile_report()]
+    tr.profile_enable(False)
+    assert any(k.startswith('stem8pool_kernel') for k in kernels), 'the uint8 stem did not run'
+    # (the float entry point convolves the ROUNDED float32 x = u / 255 - 0.5, the uint8 one the exact (u - 127.5) / 255: measured 4.7e-6)
+    assert abs(out[0][0] - out[1][0]) <= 2e-5 * abs(out[0][0]), (out[0][0], out[1][0])
+    errs = {k: rel_rms_err(out[1][1][k], out[0][1][k]) for k in out[0][1]}
+    dec = max(e for k, e in errs.items() if k.startswith(('separation/deconv', 'localization/')))
+    worst = max(errs, key=errs.get)
+    print('\n[uint8 vs float frames] loss %.9g / %.9g, decoder side %.2e, worst %.2e (%s)' % (out[0][0], out[1][0], dec, errs[worst], worst))
+    assert dec < 1e-4, dec
+    assert errs[worst] < FREE_RUNNING_BAR, (worst, errs[worst])
+
+
 def test_gradients_on_planes_and_on_fp32_tensors_agree(T):
     """The stride-1 3x3 trunk convs run their data and weight gradients on fp16x2 planes (dy planes from the batch-norm backward,
     retained forward planes: conv3h_kernel / wgrad3h_kernel).  SAGEN_TRAIN_NO_H2W=1 (weight gradients on the fp32 tensors, forward
