@@ -16,6 +16,8 @@ tgt = (inp['audio'][:, 24000:28800, :] * np.array([0.5, 0.25, -0.5], np.float32)
 net = SptAudioGen(1, encoders=enc, separation='unet_mask'); net.load_variables(P)
 tr = Trainer(net, batch=B)
 dev = [torch.as_tensor(inp[k]).cuda() if k in inp else None for k in ('audio', 'video', 'flow')] + [torch.as_tensor(tgt).cuda()]
+if dev[1] is not None and os.environ.get('U8', '1') == '1':       # frames as decoded (uint8): the default entry point of the training feeder / bench
+    dev[1] = torch.round((dev[1].double() + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
 if '--tune' in sys.argv:
     tr.autotune(*dev)
 for _ in range(3):
