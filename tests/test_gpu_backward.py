@@ -297,6 +297,50 @@ def test_every_variable_gradient_matches_fp64_autograd(T, encoders, B, seed):
                                                                              max(rows, key=lambda t: t[1])[0]))
 
 
+@pytest.mark.parametrize('mode', ['tiny', 'huge', 'mixed'])
+def test_fp16x2_gradient_planes_hold_over_the_range_of_batch_norm_parameters(T, mode):
+    """The training step's fp16x2 planes take their scales from the data: the forward's from the batch-norm statistics, dy's from an
+    exact bound the batch-norm backward derives (max |dz|, max |xhat|, gamma * invstd).  With the trunk's gammas / betas scaled by
+    1e-4, by 1e+4, or alternately by both, every variable's gradient must still match fp64 autograd (device ReLU pattern) at the bar of
+    the unscaled test, and nothing may have been clamped."""
+    from spatialaudiogen_amd.model import SptAudioGen, SptAudioGenParams
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    from spatialaudiogen_amd.train import Trainer
+    from oracle.torch_ref import TorchRef
+    enc, B = ['audio', 'video'], 2
+    P = dict(init_weights(variable_specs(enc), seed=6, mode='test'))
+    n = 0
+    for k in sorted(P):
+        if k.startswith('video_encoder/') and (k.endswith('/bn/gamma') or k.endswith('/bn/beta')):
+            layer = k.rsplit('/bn/', 1)[0]
+            f = {'tiny': 1e-4, 'huge': 1e4}.get(mode) or (1e-4 if (sum(map(ord, layer)) & 1) else 1e4)
+            P[k] = (np.asarray(P[k], np.float32) * np.float32(f)).astype(np.float32)
+            n += 1
+    assert n == 2 * 17
+    inp = synth_inputs(B, enc, seed=77)
+    target = (0.2 * rng(5).normal(size=(B, 4800, 3))).astype(np.float32)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask', params=SptAudioGenParams())
+    net.load_variables(P)
+    tr = Trainer(net, batch=B)
+    loss = tr.forward_backward(inp['audio'], inp['video'], None, target, update_moving=False)
+    T.cuda.synchronize()
+    ref = TorchRef(P, enc, dtype=T.float64)
+    ref.relu_masks = _device_relu_masks(tr, net, enc, B)
+    loss_ref, grads_ref, _, _ = ref.loss_and_grads(inp['audio'], inp['video'], None, target, None)
+    assert abs(float(loss) - loss_ref) <= 1e-4 * abs(loss_ref), (float(loss), loss_ref)
+    rows = _grad_table(tr, grads_ref)
+    # 'mixed' puts activations eight decades apart into one fp32 accumulation (the stride-2 conv after a block whose two branches were
+    # scaled 1e-4 and 1e+4: measured 1.25e-4 on conv3_1/conv_1/weights, an fp32-operand kernel; every plane-fed layer below 3e-5)
+    bar = 3e-4 if mode == 'mixed' else 1e-4
+    bad = [(k, e, m) for k, e, m in rows if not (e <= bar)]
+    errs = sorted(e for _, e, _ in rows)
+    report = '\n'.join('%-60s err %.2e  rms %.2e' % r_ for r_ in rows)
+    assert not bad, 'gradient mismatch in %d of %d variables\n%s' % (len(bad), len(rows), report)
+    assert errs[len(errs) // 2] <= 3e-5, report
+    assert tr.net is net and tr.ctx.counter('fp16x2_saturations') == 0
+    print('\n[%s] gradient rel-RMS error vs fp64 autograd: median %.2e  max %.2e' % (mode, errs[len(errs) // 2], errs[-1]))
+
+
 def test_full_size_gradients_are_affine_in_the_target(T):
     """BASELINE configs[4] at its real size (B = 32, audio+video: the tiles, split-K factors and workgroup counts the bench runs),
     where fp64 autograd on the CPU would take minutes: a size-independent property instead.  With the inputs and weights fixed the
