@@ -784,23 +784,38 @@ struct Fwd {
                 const float* shortcut = xin;
                 const int kidx = 2 * st + unit - 1;
                 const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage && (st + 2 >= 3 || keep);   // (without retained planes the pool writes none)
+                void* planes = p3_here ? (keep ? pl_buf("a1", kidx) : (void*)c->p("p3" + sfx)) : nullptr;       // of a1
+                const float* planes_ai = keep && p3_here ? pl_a_inv(kidx) : nullptr;
+                // planes of the block input (written by the pool / by the previous block's merge) and where this block's merge writes the next one's
+                void* xplanes = p3_here ? (keep ? pl_buf("x", kidx) : (void*)c->p("p3" + sfx)) : nullptr;
+                const float* xplanes_ai = keep && p3_here ? pl_a_inv(8 + kidx) : nullptr;
+                // (with retained planes the last block of stages 2-4 writes them too: the stride-2 conv_1 + 1x1 shortcut of the next
+                //  stage's first block run conv3g_kernel on them, as in inference)
+                const bool to_next_stage = keep && unit == 2 && st < 3 && c->use_p3g;
+                void* nplanes = p3_here && (unit == 1 || to_next_stage) ? (keep ? pl_buf("x", kidx + 1) : (void*)c->p("p3" + sfx)) : nullptr;
+                // unit 2 of a plane stage finds the planes of its input written by unit 1's merge (stage 2's unit 1: by the pool)
+                const bool x_planes = p3_here && (stride == 1 ? (unit == 2 || (keep && st == 0)) : (keep && c->use_p3g));
                 if (first) {
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
                                             cout, c->p("rsc" + sfx), cout, Ho, Wo);
+                    auto hsc = c->h2_slot.find(pfx + "/shortcut");
+                    if (x_planes && hsc != c->h2_slot.end()) {       // the projection on the planes of the block input (conv3g_kernel)
+                        d.xp3 = xplanes;
+                        d.p3_np = B * H * (W + 1);
+                        d.xp3_fmt = 1;
+                        d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+                        d.xp3_bytes = (unsigned)p3h_bytes(B, H, W, cin);
+                        d.wh2 = c->p("pkh:" + pfx + "/shortcut/weights");
+                        d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+                        d.h2_a_inv = xplanes_ai;
+                        d.h2_w_inv = c->p("h2s") + hsc->second;
+                    }
                     if (h2() && p3_here) d.stats = bn_acc(20 + st);      // the projection's (sum, sumsq): the residual bound of the merge's fp16 scale
                     layer = pfx + "/shortcut";
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                void* planes = p3_here ? (keep ? pl_buf("a1", kidx) : (void*)c->p("p3" + sfx)) : nullptr;       // of a1
-                const float* planes_ai = keep && p3_here ? pl_a_inv(kidx) : nullptr;
-                // planes of the block input (written by the pool / by unit 1's merge) and where this block's merge writes the next one's
-                void* xplanes = p3_here ? (keep ? pl_buf("x", stride == 1 ? kidx : 0) : (void*)c->p("p3" + sfx)) : nullptr;
-                const float* xplanes_ai = keep && p3_here ? pl_a_inv(8 + kidx) : nullptr;
-                void* nplanes = p3_here && unit == 1 ? (keep ? pl_buf("x", kidx + 1) : (void*)c->p("p3" + sfx)) : nullptr;
                 float* y1 = c->p("t:y1:" + k); float* a1 = c->p("t:a1:" + k); float* y2 = c->p("t:y2:" + k); float* xout = c->p("t:out:" + k);
-                // unit 2 of a plane stage finds the planes of its input written by unit 1's merge (stage 2's unit 1: by the pool)
-                const bool x_planes = p3_here && stride == 1 && (unit == 2 || (keep && st == 0));
                 conv_bn(xin, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), y1, Ho, Wo, li, "",
                         x_planes ? xplanes : nullptr, x_planes ? xplanes_ai : nullptr);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);

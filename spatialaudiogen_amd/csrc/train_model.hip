@@ -143,7 +143,10 @@ static void train_carve(sagen_ctx* c) {
                 c->talloc("t:pl:a1:" + std::to_string(k) + x, n);
                 // the ReLU mask of the block output, one bit per element (written by the merge pass, read by conv_2's batch-norm backward)
                 c->talloc("t:mb:" + std::to_string(k) + x, ((size_t)B * RS_H[k / 2] * RS_W[k / 2] * RS_C[k / 2] / 8 + 3) / 4);
-                if (k == 0 || (k & 1)) c->talloc("t:pl:x:" + std::to_string(k) + x, n);
+                {   // the block input (stride-2 first blocks: the previous stage's geometry)
+                    const int ki = (k > 0 && !(k & 1)) ? k - 1 : k;
+                    c->talloc("t:pl:x:" + std::to_string(k) + x, p3h_bytes(B, RS_H[ki / 2], RS_W[ki / 2], RS_C[ki / 2]) / sizeof(float));
+                }
             }
             c->talloc("t:h2a" + x, 32);
         }
