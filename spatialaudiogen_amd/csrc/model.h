@@ -823,9 +823,13 @@ struct Fwd {
                 layer = pfx + "/bn1-relu";
                 P3hScale hs1 = h2_scale();
                 if (planes_ai) hs1.a_inv = const_cast<float*>(planes_ai);
-                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y1, nullptr, nullptr, bn1, nullptr, 1, a1, planes, B, Ho, Wo, cout, s, p3_fmt(), &hs1); });
+                // with retained planes nobody reads the fp32 a1: conv_2 and its weight gradient take the planes, conv_1's batch-norm
+                // backward re-derives the ReLU mask from y1 (unless a debugging switch asks for the fp32 tensor)
+                static const bool a1_wanted = getenv("SAGEN_BN_READ_ACT") != nullptr || getenv("SAGEN_TRAIN_KEEP_A1") != nullptr;
+                float* a1w = (keep && p3_here && !a1_wanted && !wgrad_reads_fp32_operands()) ? nullptr : a1;
+                if (p3_here) timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(y1, nullptr, nullptr, bn1, nullptr, 1, a1w, planes, B, Ho, Wo, cout, s, p3_fmt(), &hs1); });
                 else timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(y1, nullptr, nullptr, bn1, nullptr, a1, (long)B * Ho * Wo, cout, s); });
-                conv_bn(a1, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), y2, H2, W2, li, p3_here ? "" : pfx + "/conv_2#mat", planes, planes_ai);
+                conv_bn(p3_here ? a1w : a1, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), y2, H2, W2, li, p3_here ? "" : pfx + "/conv_2#mat", planes, planes_ai);
                 const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                 ++li;
                 layer = pfx + "/merge";

@@ -218,6 +218,7 @@ def _grad_table(tr, grads_ref):
 def _device_relu_masks(tr, net, encoders, B):
     """ReLU masks of the device's own forward for the layers where an fp32 / fp64 switch is statistically certain: the ResNet
     trunk (1.6M-element tensors behind up to 17 batch-norm layers) and the FC that reads it.  See TorchRef.relu_masks."""
+    import torch
     masks = {}
     RS = [(56, 112, 64), (28, 56, 128), (14, 28, 256), (7, 14, 512)]
     for e, enc in enumerate([x for x in encoders if x != 'audio']):
@@ -226,7 +227,12 @@ def _device_relu_masks(tr, net, encoders, B):
             h, w, c = RS[k // 2]
             name = '%s_encoder/conv%d_%d' % (enc, k // 2 + 2, k % 2 + 1)
             nchw = lambda t: t.reshape(B, h, w, c).permute(0, 3, 1, 2).cpu().numpy() > 0
-            masks[name + '/conv_1'] = nchw(tr.buffer('t:a1:%d%s' % (k, sfx)))
+            try:        # with retained fp16x2 planes the fp32 a1 is not written: the hi plane of [C/16][B*h*(w+1)][2][16] has its sign
+                pl = tr.buffer('t:pl:a1:%d%s' % (k, sfx))
+                hi = pl[:c // 16 * B * h * (w + 1) * 16].view(torch.float16).reshape(c // 16, B, h, w + 1, 2, 16)[:, :, :, :w, 0, :]
+                masks[name + '/conv_1'] = hi.permute(1, 0, 4, 2, 3).reshape(B, c, h, w).cpu().numpy() > 0
+            except Exception:
+                masks[name + '/conv_1'] = nchw(tr.buffer('t:a1:%d%s' % (k, sfx)))
             masks[name] = nchw(tr.buffer('t:out:%d%s' % (k, sfx)))
         masks['bottleneck/%s-fc-red' % enc] = tr.buffer('fcred' + sfx).reshape(B, 7, 14, 128).cpu().numpy() > 0
     return masks
