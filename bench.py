@@ -78,6 +78,9 @@ def parse():
                          'probed to really run concurrently (DESIGN.md 6.1); 1 = strictly one forward at a time (round 4: three, measured '
                          '2 210 against 2 083-2 131 ambisonic-s/s with two on one box - the fp16x2 kernels leave LDS and registers for a third '
                          "batch's workgroups; four = three)")
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='default run (config av, one GPU): skip the short legs of the other BASELINE configurations (a, avf, eval, train) that '
+                         'follow the headline, each a fresh process of this script whose line is attached as `leg_<config>`')
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
     ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
@@ -135,6 +138,38 @@ def cpu_baseline_train(P, inputs, target, budget_s, encoders, batch):
             'sample': '%d timed training iterations (forward + loss + autograd backward, no optimiser) of %d windows, same synthetic %s '
                       'batch, fp32, median %.2f s/iteration, warm-up %.2f s; torch-CPU/oneDNN stand-in for the TF1 CPU path'
                       % (len(times), batch, '+'.join(encoders), med, warm)}
+
+
+def other_config_legs(args):
+    """BASELINE configs[0], [2], [3], [4] next to the headline (configs[1]) in the default one-GPU run: each leg is `bench.py --config X`
+    in a fresh process AFTER the headline's timed region and extra legs (nothing of this process is running on the GPU any more), with
+    its own warm-up / autotune / timed region under the same contract; its line is reduced to value, ms_per_step, steps and roofline.
+    A leg that fails is recorded as such - the headline never depends on it."""
+    import subprocess
+    legs = {}
+    plan = {'a': (60, 10), 'avf': (20, 5), 'eval': (60, 5), 'train': (12, 3)}
+    for name, (steps, warm) in plan.items():
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--config', name, '--steps', str(steps), '--warmup', str(warm),
+               '--no-cpu-baseline', '--no-extra-legs', '--no-other-configs'] + (['--no-autotune'] if args.no_autotune else [])
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            if r.returncode != 0 or not line:
+                legs['leg_' + name] = {'error': 'exit code %d: %s' % (r.returncode, (r.stderr or r.stdout)[-400:])}
+                continue
+            doc = json.loads(line[-1])
+            rf = doc.get('roofline', {})
+            legs['leg_' + name] = {
+                'metric': doc['metric'], 'value': doc['value'], 'unit': doc['unit'], 'ms_per_step': doc['ms_per_step'], 'steps': doc['steps'],
+                'warmup': doc['warmup'], 'scaling': doc['scaling'], 'workload': doc['config']['workload'],
+                'batches_in_flight': doc['config'].get('batches_in_flight'), 'windows_per_gpu_per_step': doc['config'].get('windows_per_gpu_per_step'),
+                'roofline': {k: rf.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'launches_per_step',
+                                                    'share_of_step_time', 'whole_step')},
+                'wall_s': round(time.time() - t0, 1)}
+        except Exception as e:                                    # noqa: BLE001 (a leg must never take the headline down)
+            legs['leg_' + name] = {'error': repr(e)[:400]}
+    return legs
 
 
 def init_ranks(dist, world, rank):
@@ -661,6 +696,9 @@ def main():
         cb = cpu_baseline(P, sample, args.cpu_seconds, ENCODERS, BATCH)
         cb['gpu_over_cpu'] = round(value / cb['value'], 1)
         result['cpu_baseline'] = cb
+    if rank == 0 and world == 1 and args.config == 'av' and not args.no_other_configs and not args.no_extra_legs:
+        torch.cuda.synchronize()
+        result.update(other_config_legs(args))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -15,7 +15,8 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libsagen_hip.so')
 SOURCES = ['conv3p.hip', 'conv3h.hip', 'conv3g.hip', 'p3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'stempool.hip', 'stem8.hip', 'igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'train.hip', 'wgrad.hip', 'wgrad3h.hip', 'backward.hip', 'model.hip', 'train_model.hip', 'api.hip']
-HEADERS = [os.path.join(CSRC, h) for h in ('common.h', 'kernels.h', 'wave_reduce.h', 'igemm_common.h', 'igemm3_common.h', 'model.h')] + \
+# every header of csrc/ (the listing source_digest() hashes) + the public one: editing any of them rebuilds every object
+HEADERS = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')) + \
           [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'sagen.h')]
 # -fno-slp-vectorize -fno-vectorize: no packed-fp32 VALU (v_pk_add/mul/fma_f32).  Measured on MI355X: a wave executing packed-fp32 ops gives
 # wrong results while a wave of another kernel issues v_mfma_f32_32x32x16_bf16 on the same SIMD (the LDS FFT kernels next to the
@@ -80,7 +81,7 @@ def build(force=False, verbose=True):
             raise RuntimeError('hipcc failed for %s:\n%s' % (s, r.stderr))
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, max(1, len(jobs)))) as ex:
         for err in ex.map(compile_one, jobs):
             if verbose and err.strip():
                 print(err)

@@ -21,10 +21,13 @@ __device__ __forceinline__ void p3h_store(char* p3, long cstride, long pp, int c
     bool clamped = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        clamped = clamped || !(fabsf(v[k] * sa) <= 65000.f);
-        const float t = fminf(fmaxf(v[k] * sa, -65000.f), 65000.f);
-        hi[k] = (_Float16)t;
-        lo[k] = (_Float16)(t - (float)hi[k]);
+        const float sv = v[k] * sa;
+        clamped = clamped || !(fabsf(sv) <= 65000.f);
+        const float t = fminf(fmaxf(sv, -65000.f), 65000.f);
+        // a NaN / Inf must stay one (fmaxf(NaN, x) = x would launder it into a finite plane value and the loss would stay finite):
+        // the hi plane carries an fp16 NaN, every product with it is NaN, and the caller's NaN check (train.py:212) fires
+        hi[k] = __builtin_isfinite(sv) ? (_Float16)t : __builtin_bit_cast(_Float16, (unsigned short)0x7e00);
+        lo[k] = __builtin_isfinite(sv) ? (_Float16)(t - (float)hi[k]) : (_Float16)0.f;
     }
     char* dst = p3 + (long)(c8 >> 1) * cstride + pp * 64 + (c8 & 1) * 16;
     *reinterpret_cast<h8*>(dst) = hi;

@@ -165,15 +165,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)
         // ---- last-arriver combine.  The eight XCDs have their own L2s: the partials are written and read with AGENT-scope accesses
         // (write-through stores, loads that never return a stale line) - a release / acquire FENCE pair instead writes back and
         // invalidates the whole L2 of the XCD, which cost the other batches in flight more than the reducer launches saved
-        // (2 030 against 2 240 ambisonic-s/s, audio-only 3 200 against 4 800) ----
+        // (2 030 against 2 240 ambisonic-s/s, audio-only 3 200 against 4 800).
+        // MEMORY MODEL: the partial stores, the ticket and the partial loads are all RELAXED agent-scope atomics, i.e. there is no
+        // release / acquire edge between them in the HIP / LLVM model - the ordering relied on is gfx950's: agent-scope stores are
+        // write-through and `s_waitcnt vmcnt(0)` returns only after they have been acknowledged by memory; agent-scope loads bypass
+        // the XCD's L2.  That is a property of THIS hardware, not of the language: the path is an opt-in experiment
+        // (SAGEN_SK_FUSED=1, measured no faster) and is not part of any supported configuration; the default is the reducer launch ----
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's agent-scope stores have been acknowledged
         __syncthreads();
         const int tile = (m0 / BM) * ((d.N + BN - 1) / BN) + n0 / BN;
         if (tid == 0) {
-            const int t = atomicAdd(&d.sk_ticket[tile], 1);
+            const int t = __hip_atomic_fetch_add(&d.sk_ticket[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = t == d.splitk - 1;
-            if (s_last) d.sk_ticket[tile] = 0;           // re-armed for the next launch on this stream
+            if (s_last) __hip_atomic_store(&d.sk_ticket[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch on this stream
         }
         __syncthreads();
         if (s_last) {

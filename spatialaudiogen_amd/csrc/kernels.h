@@ -226,12 +226,13 @@ int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B,
 size_t p3_bytes(int B, int H, int W, int C);
 // y = [relu](x*scale + shift [+ residual]) -> fp32 NHWC `y` (or null) and / or planes `p3` (or null)
 // fmt 0: three bf16 planes (conv3p / conv3g); fmt 1: two fp16 planes of v * 2^ka (conv3h.hip) - ka from the statistics in `h2`
+constexpr int H2_RIG_OFF = 240;         // the rigorous (Samuelson) bound of a tracked tensor lives this many floats behind its statistical bound
 struct P3hScale {
     float* a_inv = nullptr;             // out: 2^-ka
-    const float* res_bound = nullptr;   // in: bound of the residual tensor (identity shortcut), or null
+    const float* res_bound = nullptr;   // in: bound of the residual tensor (identity shortcut), or null; [H2_RIG_OFF] behind it: its rigorous bound
     const double* res_acc = nullptr;    // in: fp64 (sum, sumsq) [2][C] of the residual tensor (1x1 shortcut conv), or null
     double res_inv_count = 0.0;
-    float* bound_out = nullptr;         // out: bound of the tensor written (null: not tracked)
+    float* bound_out = nullptr;         // out: bound of the tensor written (null: not tracked); [H2_RIG_OFF] behind it: the rigorous bound (p3.hip)
     unsigned* sat_count = nullptr;      // out: incremented once per element that had to be clamped to +-65000 (stays 0 unless the statistics lie)
     // out (nullable, p3_pack only): the ReLU mask of the tensor written, ONE BIT per element - byte (dense pixel * C/8 + channel octet),
     // bit k = [channel 8*octet + k > 0]: the training step's batch-norm backward reads it instead of the fp32 activation (1/32 of the bytes)

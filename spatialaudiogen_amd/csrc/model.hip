@@ -145,7 +145,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     }
     c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
     c->alloc("h2:amax", c->h2_slot.size() + h2_pack_blocks + 64);      // per-job maxima + per-workgroup partials
-    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [7] saturation counter, [8..] 2^-kw per layer
+    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [7] saturation counter, [8..] 2^-kw per layer, [2 + H2_RIG_OFF ..] the rigorous bounds behind [2..5] (p3.hip)
     c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
     // activations
     c->alloc("mag", (size_t)B * 127 * 1024);

@@ -67,48 +67,28 @@ size_t p3h_bytes(int B, int H, int W, int C) { return (size_t)(C / 16) * B * H *
 //   * the residual branch of a block merge: either the bound of the block input, tracked from pass to pass in device memory
 //     (`h.res_bound`), or - first block of a stage - the (sum, sumsq) of the 1x1 shortcut conv's output: |mean_c| + 8 std_c.
 // bound = max_c(bn) + max_c(residual) is scaled into [512, 1024): fp16 overflows at 65504, i.e. 64 x headroom for what lies beyond
-// eight standard deviations, then saturation.  Every block derives the same value; block 0 publishes 2^-ka (read by conv3h_kernel's
+// eight standard deviations.  Every block derives the same value; block 0 publishes 2^-ka (read by conv3h_kernel's
 // epilogue) and the bound itself (the residual bound of the next merge).  Without a BnRef the scale is 1.
-
-__device__ __forceinline__ float p3h_act_scale(const BnRef& bn, const P3hScale& h, bool has_res, int C, unsigned* s_bits) {
-    if (threadIdx.x < 2) s_bits[threadIdx.x] = 0u;
-    __syncthreads();
-    if (bn.acc != nullptr) {
-        float m = 0.f, mr = 0.f;
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const double mean = bn.acc[c] * bn.inv_count;
-            double var = bn.acc[C + c] * bn.inv_count - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            m = fmaxf(m, fabsf(bn.beta[c]) + 8.f * fabsf(bn.gamma[c]) * (float)sqrt(var / (var + (double)bn.eps)));
-            if (has_res && h.res_acc != nullptr) {
-                const double rm = h.res_acc[c] * h.res_inv_count;
-                double rv = h.res_acc[C + c] * h.res_inv_count - rm * rm;
-                rv = rv < 0.0 ? 0.0 : rv;
-                mr = fmaxf(mr, (float)(fabs(rm) + 8.0 * sqrt(rv)));
-            }
-        }
-        atomicMax(&s_bits[0], __builtin_bit_cast(unsigned, m));            // non-negative floats order like their bit patterns
-        atomicMax(&s_bits[1], __builtin_bit_cast(unsigned, mr));
-    }
-    __syncthreads();
-    float bound = __builtin_bit_cast(float, s_bits[0]) + __builtin_bit_cast(float, s_bits[1]);
-    if (has_res && h.res_acc == nullptr && h.res_bound != nullptr) bound += h.res_bound[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && h.bound_out != nullptr) h.bound_out[0] = bound;
-    const unsigned b = __builtin_bit_cast(unsigned, bound);
-    const int e = (int)((b >> 23) & 0xff);
-    if (bn.acc == nullptr || e == 0 || e == 255) return 1.f;
-    const int k = max(-60, min(60, 127 + 9 - e));
-    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
-}
+//
+// NOTHING CAN SATURATE (round 5): next to the statistical bound the pass carries a RIGOROUS one.  The batch statistics are those of
+// the very tensor being normalised, and no sample of N values lies further than sqrt(N - 1) standard deviations from their mean
+// (Samuelson's inequality), so |bn(y)_c| <= |beta_c| + sqrt(N) |gamma_c| sqrt(var_c / (var_c + eps)) for EVERY element, whatever the
+// distribution; a 1x1 projection's output obeys |mean_c| + sqrt(N) std_c the same way, and an identity residual inherits the rigorous
+// bound of the block input (tracked like the statistical one, H2_RIG_OFF floats behind it).  ka = min(ka of the statistical bound,
+// the largest k with rigorous_bound * 2^k <= 64000): wherever sqrt(N) / 8 < 64 - every pass of the network at batch 32 except the
+// stem's pool (N = B * 112 * 224) - that is the statistical ka unchanged; the stem's planes give up one bit (of 34) at batch 32.
+// The saturation counter is therefore an assertion (0 unless an input was not finite - which p3h_store turns into NaN, not a clamp).
 
 // Both tables in ONE pass over the channels (one round trip to the statistics, two barriers): the batch-norm coefficients and, for
-// the fp16x2 format, the activation scale (p3h_act_scale above is the same computation on its own).
+// the fp16x2 format, the activation scale.
 template <bool H2>
 __device__ __forceinline__ float p3_tables(const float* scale, const float* shift, const BnRef& bn, const P3hScale& h, bool has_res, int C,
                                            float (*tab)[P3_MAX_C], unsigned* s_bits) {
-    if (H2 && threadIdx.x < 2) s_bits[threadIdx.x] = 0u;
+    if (H2 && threadIdx.x < 4) s_bits[threadIdx.x] = 0u;
     if (H2) __syncthreads();
-    float m = 0.f, mr = 0.f;
+    float m = 0.f, mr = 0.f, mg = 0.f, mrg = 0.f;             // statistical bounds (bn branch, residual branch) and the rigorous ones
+    const float sqn = H2 && bn.acc != nullptr ? (float)sqrt(1.0 / bn.inv_count) : 0.f;
+    const float sqn_r = H2 && has_res && h.res_acc != nullptr ? (float)sqrt(1.0 / h.res_inv_count) : 0.f;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float sc = 1.f, sh = 0.f;
         if (bn.acc != nullptr) {
@@ -120,12 +100,15 @@ __device__ __forceinline__ float p3_tables(const float* scale, const float* shif
             sc = (float)a;
             sh = (float)((double)bn.beta[c] - mean * a);
             if (H2) {
-                m = fmaxf(m, fabsf(bn.beta[c]) + 8.f * fabsf(bn.gamma[c]) * (float)(sqrt(var) * inv));
+                const float gs = fabsf(bn.gamma[c]) * (float)(sqrt(var) * inv);
+                m = fmaxf(m, fabsf(bn.beta[c]) + 8.f * gs);
+                mg = fmaxf(mg, fabsf(bn.beta[c]) + sqn * gs);
                 if (has_res && h.res_acc != nullptr) {
                     const double rm = h.res_acc[c] * h.res_inv_count;
                     double rv = h.res_acc[C + c] * h.res_inv_count - rm * rm;
                     rv = rv < 0.0 ? 0.0 : rv;
                     mr = fmaxf(mr, (float)(fabs(rm) + 8.0 * sqrt(rv)));
+                    mrg = fmaxf(mrg, (float)(fabs(rm) + (double)sqn_r * sqrt(rv)));
                 }
             }
         } else if (scale != nullptr) {
@@ -136,21 +119,30 @@ __device__ __forceinline__ float p3_tables(const float* scale, const float* shif
         tab[1][c] = sh;
     }
     if (H2 && bn.acc != nullptr) {
-        m = wave_max_f(m); mr = wave_max_f(mr);
+        m = wave_max_f(m); mr = wave_max_f(mr); mg = wave_max_f(mg); mrg = wave_max_f(mrg);
         if ((threadIdx.x & 63) == 0) {
             atomicMax(&s_bits[0], __builtin_bit_cast(unsigned, m));        // non-negative floats order like their bit patterns
             atomicMax(&s_bits[1], __builtin_bit_cast(unsigned, mr));
+            atomicMax(&s_bits[2], __builtin_bit_cast(unsigned, mg));
+            atomicMax(&s_bits[3], __builtin_bit_cast(unsigned, mrg));
         }
     }
     __syncthreads();
     if (!H2) return 1.f;
     float bound = __builtin_bit_cast(float, s_bits[0]) + __builtin_bit_cast(float, s_bits[1]);
-    if (has_res && h.res_acc == nullptr && h.res_bound != nullptr) bound += h.res_bound[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && h.bound_out != nullptr) h.bound_out[0] = bound;
+    float rig = __builtin_bit_cast(float, s_bits[2]) + __builtin_bit_cast(float, s_bits[3]);
+    if (has_res && h.res_acc == nullptr && h.res_bound != nullptr) { bound += h.res_bound[0]; rig += h.res_bound[H2_RIG_OFF]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && h.bound_out != nullptr) { h.bound_out[0] = bound; h.bound_out[H2_RIG_OFF] = rig; }
     const unsigned b = __builtin_bit_cast(unsigned, bound);
     const int e = (int)((b >> 23) & 0xff);
     float sa = 1.f;
-    if (bn.acc != nullptr && e != 0 && e != 255) sa = __builtin_bit_cast(float, (unsigned)(127 + max(-60, min(60, 127 + 9 - e))) << 23);
+    if (bn.acc != nullptr && e != 0 && e != 255) {
+        int k = 127 + 9 - e;                                                // statistical bound -> [512, 1024)
+        const float q = 64000.f / rig;                                      // rigorous bound * 2^k <= 64000 < 65504
+        const int eq = (int)((__builtin_bit_cast(unsigned, q) >> 23) & 0xff);
+        if (eq != 0 && eq != 255) k = min(k, eq - 127);                     // (floor(log2 q); rig = 0 or not finite: no constraint)
+        sa = __builtin_bit_cast(float, (unsigned)(127 + max(-60, min(60, k))) << 23);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && h.a_inv) h.a_inv[0] = 1.f / sa;
     return sa;
 }
@@ -163,7 +155,7 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
     const int C8 = C >> 3;
     const long total = nrows * (W + 1) * C8;             // padded pixels x channel octets (the grid stride is a multiple of C8)
     const long cstride = nrows * (W + 1) * (H2 ? 64 : 96);
-    __shared__ unsigned s_bits[2];
+    __shared__ unsigned s_bits[4];
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
@@ -252,7 +244,7 @@ __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict
     const long nrows = (long)B * Ho;
     const long total = nrows * (Wo + 1) * C8;
     const long cstride = nrows * (Wo + 1) * (H2 ? 64 : 96);
-    __shared__ unsigned s_bits[2];
+    __shared__ unsigned s_bits[4];
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];

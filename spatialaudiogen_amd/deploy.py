@@ -130,6 +130,7 @@ class ClipArrays(object):
 class W2XYZ(object):
     batch_size = 10            # deploy.py:50
     duration = 0.1             # deploy.py:49
+    on_saturation = 'rerun'    # fp16x2 guard (SptAudioGen.inference_ops_checked): 'rerun' on bf16 planes | 'raise'
 
     def __init__(self, model_dir=None, params=None, variables=None, device=None):
         if params is None:
@@ -167,10 +168,12 @@ class W2XYZ(object):
         p = self.params
         if isinstance(source, ClipArrays):
             return source.windowed(deploy_start, deploy_duration)
-        from .feeder import SampleReader, img_prep_fcn
+        from .feeder import SampleReader
+        # img_prep=None: frames stay the uint8 the JPEG decoder produced; x/255 - 0.5 (myutils.py:88-89) runs on the device
+        # (sagen_forward_u8), bit-identical to img_prep_fcn() + float32 cast, at a quarter of the H2D bytes
         return SampleReader(source, ambi_order=p.ambi_order, audio_rate=p.audio_rate, video_rate=p.video_rate,
                             context=p.context, duration=self.duration, return_video=VIDEO in p.encoders,
-                            img_prep=img_prep_fcn(), return_flow=FLOW in p.encoders, start_time=deploy_start,
+                            img_prep=None, return_flow=FLOW in p.encoders, start_time=deploy_start,
                             sample_duration=deploy_duration, skip_silence_thr=None, shuffle=False,
                             random_rotations=False, skip_rate=None)                   # deploy.py:91-105
 
@@ -179,7 +182,7 @@ class W2XYZ(object):
         [n_windows*snd_dur, 4] = W,Y,Z,X."""
         import torch
         from . import ops
-        from .feeder import BatchPrefetcher
+        from .feeder import BatchPrefetcher, frames_to_float
         p, m = self.params, self.model
         reader = self._reader(input_folder, deploy_start, deploy_duration)
         if not reader.chunks_t:
@@ -205,9 +208,13 @@ class W2XYZ(object):
                 out['audio'] = audio
                 for key, on in (('video', use_v), ('flow', use_f)):
                     if on:
-                        x = np.zeros((self.batch_size, 1, 224, 448, 3), np.float32)
-                        x[:n] = np.stack([b[key] for b in batch], 0)
-                        out[key] = x
+                        clip = np.stack([b[key] for b in batch], 0)
+                        if clip.dtype == np.uint8 and n == self.batch_size:
+                            out[key] = clip                                   # decoded frames as they are (sagen_forward_u8)
+                        else:                       # a partial batch is padded with 0.0 AFTER normalisation: float frames
+                            x = np.zeros((self.batch_size, 1, 224, 448, 3), np.float32)
+                            x[:n] = frames_to_float(clip)
+                            out[key] = x
                 yield out
 
         src = BatchPrefetcher(batches(), depth=2, pin=True) if prefetch else batches()
@@ -215,7 +222,8 @@ class W2XYZ(object):
         for b in src:
             to_dev = lambda k: torch.as_tensor(b[k]).to(m.device, non_blocking=True) if k in b else None
             a_dev = to_dev('audio')
-            pred = m.inference_ops(a_dev, to_dev('video'), to_dev('flow'))             # deploy.py:141
+            # deploy.py:141 - with the fp16x2 guard: a batch whose trunk planes clamped anything is re-run on bf16 planes
+            pred = m.inference_ops_checked(a_dev, to_dev('video'), to_dev('flow'), on_saturation=self.on_saturation)
             wyzx = ops.assemble_wyzx(a_dev[:, :, 0].contiguous(), pred, m.snd_contx)   # deploy.py:143-152
             outs.append(wyzx[:b['n']].reshape(b['n'] * m.snd_dur, 4).cpu().numpy())
         return np.concatenate(outs, 0)

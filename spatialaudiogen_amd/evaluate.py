@@ -78,10 +78,14 @@ class Evaluator(object):
         windows are dropped from the metrics but do enter the batch-norm statistics."""
         import torch
         n = ambix.shape[0]
+        from .feeder import frames_to_float
+        if n != BATCH_SIZE and video is not None:
+            video = frames_to_float(video)              # the padding windows are 0.0 AFTER normalisation: no uint8 pixel maps to it
         pad = lambda x: x if x is None or n == BATCH_SIZE else np.concatenate([x, np.zeros((BATCH_SIZE - n,) + x.shape[1:], x.dtype)], 0)
         dev = self.net.device
         a = torch.as_tensor(pad(ambix)).to(dev)
-        pred = self.net.inference_ops(a[:, :, :1].contiguous(), pad(video), pad(flow))
+        # (fp16x2 guard: a batch whose trunk planes clamped anything is re-run on bf16 planes - SptAudioGen.inference_ops_checked)
+        pred = self.net.inference_ops_checked(a[:, :, :1].contiguous(), pad(video), pad(flow))
         target = a[:, self.ss:self.ss + self.t, 1:].contiguous()
         m = torch.as_tensor(pad(masks.astype(np.float32))).to(dev)
         _, stft_ps, lsd_ps, mse_ps, snr_ps = self.net.evaluation_ops(pred, target, None, m[:, 1:])
@@ -134,7 +138,7 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
              partial_batch='drop', power_maps=False):
     import torch
     from .deploy import load_params, W2XYZ
-    from .feeder import SampleReader, img_prep_fcn
+    from .feeder import SampleReader
     rank, world = init_process_group()
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
@@ -148,14 +152,18 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
     lo, hi, n_batches = batch_shard(len(plan), rank, world, partial_batch)
     readers = _ReaderCache(lambda yid: SampleReader(
         os.path.join(db_dir, yid), ambi_order=params.ambi_order, audio_rate=params.audio_rate, video_rate=params.video_rate,
-        context=params.context, duration=0.1, return_video=VIDEO in params.encoders, img_prep=img_prep_fcn(),
+        context=params.context, duration=0.1, return_video=VIDEO in params.encoders, img_prep=None,      # frames stay uint8 (sagen_forward_u8)
         return_flow=FLOW in params.encoders, skip_silence_thr=None, shuffle=False, random_rotations=False,
         skip_rate=SKIP_RATE))                                              # feeder.py:373-396 (for_eval)
     ev = Evaluator(net, params, power_maps=power_maps)
     for b in range(lo, hi):
         wins = plan[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
         samples = [readers.get(yid).sample_at(t) for yid, t in wins]
-        stack = lambda k: np.stack([smp[k] for smp in samples], 0).astype(np.float32) if k in samples[0] else None
+        def stack(k):
+            if k not in samples[0]:
+                return None
+            x = np.stack([smp[k] for smp in samples], 0)
+            return x if (k == 'video' and x.dtype == np.uint8) else x.astype(np.float32)
         ev.run_batch([smp['id'] for smp in samples], stack('ambix'), stack('video'), stack('flow'),
                      np.stack([layouts.get(yid, np.ones(4)) for yid, _ in wins], 0))
 
@@ -184,6 +192,10 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
         if short:        # the means above are np.mean over all samples (eval.py:223): a non-finite sample shows there; say how many
             print('EVAL | non-finite per-sample values: ' + ', '.join('%s %d/%d finite (finite-only mean %.6g)' % (k, c, count, red.finite_means[k])
                                                                      for k, c in sorted(short.items())))
+        ev_sat = getattr(net, 'saturation_events', [])
+        if ev_sat:
+            print('EVAL | fp16x2 guard: %d batches clamped activation-plane elements (%d in all) and were re-run on bf16 planes'
+                  % (len(ev_sat), sum(c for _, c in ev_sat)))
         dropped = len(plan) - count
         if dropped:
             print('EVAL | %d trailing windows (a partial batch of %d) were not evaluated' % (dropped, BATCH_SIZE))

@@ -76,6 +76,18 @@ def img_prep_fcn():
     return lambda x: x / 255. - 0.5
 
 
+def frames_to_float(frames):
+    """Decoded uint8 frames -> the float32 tensor the reference's feeder hands to the graph (img_prep_fcn in double precision, then the
+    float32 cast of the batch assembly).  The readers of this package keep video frames as decoded (uint8: a quarter of the H2D bytes;
+    sagen_forward_u8 / sagen_train_step_u8 apply the same normalisation on the device, bit-identical) - this is the host-side form
+    for the one case that needs float frames: a zero-padded partial batch, whose padding is 0.0 AFTER normalisation (deploy.py:125-127),
+    a value no uint8 pixel maps to."""
+    frames = np.asarray(frames)
+    if frames.dtype != np.uint8:
+        return frames.astype(np.float32)
+    return (frames.astype(np.float64) / 255. - 0.5).astype(np.float32)
+
+
 # ------------------------------------------------------------------------------------------------
 # window table: the pinned arithmetic, vectorised over the window times
 # ------------------------------------------------------------------------------------------------

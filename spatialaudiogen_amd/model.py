@@ -218,6 +218,38 @@ class SptAudioGen(object):
         check(fwd(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
         return out
 
+    def inference_ops_checked(self, audio, video=None, flow=None, on_saturation='rerun', out=None):
+        """inference_ops + the guard of the fp16x2 trunk arithmetic (what deploy.py / evaluate.py call).
+
+        The ResNet trunks' activation planes are scaled per layer from batch-norm STATISTICS (|beta_c| + 8 sigma_c, fp16 range 64 x
+        beyond that: csrc/conv3h.hip); an element beyond that range is clamped and counted on the device.  With weights nobody has
+        seen a heavy-tailed channel could get there, so the hosts look: after the forward the counter is read (4 bytes D2H; the
+        callers synchronise per batch anyway) and, if this batch clamped anything, the batch is run again with the trunk on three
+        bf16 planes (fp32's exponent range, nothing to saturate; `on_saturation='rerun'`) or the call raises (`'raise'`).
+        `self.saturation_events` = [(batch size, clamped elements)] of every batch that was re-run."""
+        y = self.inference_ops(audio, video, flow, out=out)
+        B = y.shape[0]
+        ctx = self.context_for(B)
+        if not hasattr(self, '_sat_seen'):
+            self._sat_seen, self.saturation_events = {}, []
+        now = ctx.counter('fp16x2_saturations')
+        clamped = now - self._sat_seen.get(B, 0)
+        self._sat_seen[B] = now
+        if clamped <= 0:
+            return y
+        if on_saturation == 'raise':
+            raise FloatingPointError('fp16x2 activation planes saturated (%d elements clamped in this batch): run with '
+                                     "set_option(batch, 'fp16x2', 0) / SAGEN_NO_H2=1" % clamped)
+        import warnings
+        warnings.warn('fp16x2 activation planes clamped %d elements of this batch: re-running it on three bf16 planes' % clamped)
+        self.saturation_events.append((B, clamped))
+        ctx.set_option('fp16x2', 0)
+        try:
+            y = self.inference_ops(audio, video, flow, out=y)
+        finally:
+            ctx.set_option('fp16x2', 1)
+        return y
+
     # ---- evaluation metrics (model.py:110-154) -----------------------------------------------------
     def evaluation_ps(self, preds_t, targets_t):
         """Device-only part of evaluation_ops: (ps [4, B, 3] = per-sample stft distance, lsd, mse, snr; pw [2] fp64 power sums),

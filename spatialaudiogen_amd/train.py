@@ -296,7 +296,8 @@ class Trainer(object):
         mk = channel_mask(mask, self.batch, self.device)
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        step = _lib.lib().sagen_train_step_u8 if (v is not None and v.dtype == torch.uint8) else _lib.lib().sagen_train_step
+        self.last_entry = 'sagen_train_step_u8' if (v is not None and v.dtype == torch.uint8) else 'sagen_train_step'
+        step = getattr(_lib.lib(), self.last_entry)
         check(step(self.ctx.handle, p(a), p(v), p(f), p(t), p(mk), p(self.pred), p(self.loss), int(update_moving), stream))
         return self.loss
 
@@ -366,8 +367,10 @@ class Trainer(object):
         from ._lib import check
         from .definitions import VIDEO, FLOW
         a = self._prep(audio, (52799, 1))
-        if isinstance(video, torch.Tensor) and video.dtype == torch.uint8:     # (the tuning step takes float frames: x / 255 - 0.5)
-            video = video.to(torch.float32) / 255.0 - 0.5
+        if video is not None:
+            video = video if isinstance(video, torch.Tensor) else torch.as_tensor(np.asarray(video))
+            if video.dtype == torch.uint8:                  # (the tuning step takes float frames: x / 255 - 0.5, whatever the container)
+                video = (video.to(torch.float64) / 255.0 - 0.5).to(torch.float32)
         v = self._prep(video, (1, 224, 448, 3)) if VIDEO in self.net.encoders else None
         f = self._prep(flow, (1, 224, 448, 3)) if FLOW in self.net.encoders else None
         t = self._prep(target, (4800, 3))
@@ -538,7 +541,7 @@ def folder_batches(db_dir, ids, params, batch, layouts=None, seed=0, samples_per
     shuffled windows, silence skipping and random rotations about z, `samples_per_clip` (NUM_SAMPLING = 5) windows of each; the
     sample stream is cut into batches.  Yields (audio [B,n,1], video, flow, target [B,4800,3], channel mask [B,4])."""
     import random
-    from .feeder import SampleReader, img_prep_fcn
+    from .feeder import SampleReader
     from .definitions import VIDEO, FLOW
     rnd = random.Random(seed)
     thr = silence_threshold(subset_fn if subset_fn is not None else getattr(params, 'subset_fn', None), db_dir)
@@ -550,14 +553,18 @@ def folder_batches(db_dir, ids, params, batch, layouts=None, seed=0, samples_per
         for yid in order:
             reader = SampleReader(os.path.join(db_dir, yid), ambi_order=params.ambi_order, audio_rate=params.audio_rate,
                                   video_rate=params.video_rate, context=params.context, duration=0.1,
-                                  return_video=VIDEO in params.encoders, img_prep=img_prep_fcn(), return_flow=FLOW in params.encoders,
+                                  return_video=VIDEO in params.encoders, img_prep=None, return_flow=FLOW in params.encoders,     # video frames stay uint8: Trainer dispatches to sagen_train_step_u8
                                   skip_silence_thr=thr, shuffle=True, random_rotations=True)
             for smp in reader.loop_chunks(samples_per_clip):
                 smp['mask'] = np.asarray((layouts or {}).get(yid, np.ones(4)), np.float32)
                 buf.append(smp)
                 if len(buf) == batch:
                     amb = np.stack([s_['ambix'] for s_ in buf], 0).astype(np.float32)
-                    st = lambda k: np.stack([s_[k] for s_ in buf], 0).astype(np.float32) if k in buf[0] else None
+                    def st(k):
+                        if k not in buf[0]:
+                            return None
+                        x = np.stack([s_[k] for s_ in buf], 0)
+                        return x if (k == 'video' and x.dtype == np.uint8) else x.astype(np.float32)    # decoded frames as they are
                     yield (amb[:, :, :1], st('video'), st('flow'), np.ascontiguousarray(amb[:, ss:ss + t, 1:]),
                            np.stack([s_['mask'] for s_ in buf], 0))       # train.py:107-111: input W, target Y,Z,X of the centre window
                     buf = []
@@ -576,25 +583,42 @@ def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_
     history = []
     t_last, n_last = time.time(), init_step
     step = init_step
+    # tf.train.Saver(max_to_keep=1) across --resume: the previous run's periodic bundle is the one to drop at the next periodic save
     last_periodic = None
+    stale = []
+    if rank == 0 and os.path.isdir(model_dir):
+        import re
+        found = [(int(m.group(1)), os.path.join(model_dir, m.group(0)[:-len('.index')]))
+                 for m in (re.match(r'model\.ckpt-(\d+)\.index$', f) for f in os.listdir(model_dir)) if m]
+        stale = [pfx for _, pfx in sorted(found)]
     flag = None
+    sat_seen = tr.ctx.counter('fp16x2_saturations') if hasattr(tr, 'ctx') else 0
     try:
         for step in range(init_step, n_iters):
             audio, video, flow, target, mask = next(batches)
             loss, lr = tr.step(audio, video, flow, target, mask)
             if step % log_every == 0:
+                # fp16x2 guard: elements the activation / gradient plane passes had to clamp since the last look (expected 0; a non-finite
+                # value counts and also poisons the planes with NaN, h2_planes.h) - read at the log step's synchronisation
+                sat_now = tr.ctx.counter('fp16x2_saturations') if hasattr(tr, 'ctx') else 0
+                sat_new, sat_seen = sat_now - sat_seen, sat_now
                 if multi:
                     # every rank learns about a NaN on ANY rank in the same step (sum of [loss, isnan]) and raises with the others - a
                     # rank that left alone would leave the rest hanging in the next bucket all-reduce; the logged loss is the global mean
-                    flag = torch.stack([loss.detach().double().reshape(()), torch.isnan(loss.detach()).double().reshape(())])
+                    flag = torch.stack([loss.detach().double().reshape(()), torch.isnan(loss.detach()).double().reshape(()),
+                                        torch.tensor(float(sat_new), dtype=torch.float64, device=loss.device)])
                     dist.all_reduce(flag)
                     lv = float(flag[0]) / dist.get_world_size()
                     bad = float(flag[1]) > 0 or math.isnan(lv)
+                    sat_new = int(flag[2])
                 else:
                     lv = float(loss)                                        # the only host synchronisation of the loop
                     bad = math.isnan(lv)
                 if bad:
                     raise ValueError('Training produced a NaN metric or loss.')
+                if sat_new > 0:
+                    raise FloatingPointError('fp16x2 planes clamped %d elements since step %d (statistical range bound exceeded): '
+                                             'restart with SAGEN_TRAIN_NO_H2=1 SAGEN_TRAIN_NO_H2D=1 (bf16 planes)' % (sat_new, max(step - log_every, init_step)))
                 now = time.time()
                 rate = tr.batch * max(step - n_last, 1) / max(now - t_last, 1e-9)
                 t_last, n_last = now, step
@@ -603,10 +627,11 @@ def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_
                     log('TRAIN | step %d | stft/mse %.6g | lr %.3g | %.1f samples/s per GPU' % (step, lv, lr, rate))
             if step % ckpt_every == 0 and step != 0 and rank == 0:
                 prefix = tr.save(model_dir, global_step=tr.opt.step)
-                if last_periodic and last_periodic != prefix:               # tf.train.Saver(max_to_keep=1), train.py:176
-                    from .checkpoint import remove_checkpoint
-                    remove_checkpoint(last_periodic)
-                last_periodic = prefix
+                from .checkpoint import remove_checkpoint
+                for old in stale + ([last_periodic] if last_periodic else []):     # tf.train.Saver(max_to_keep=1), train.py:176
+                    if old != prefix:
+                        remove_checkpoint(old)
+                stale, last_periodic = [], prefix
                 log('=' * 60 + '\nCheckpoint saved\n' + '=' * 60)
     finally:
         if torch.cuda.is_available():

@@ -238,6 +238,8 @@ def test_training_feeder_cuts_rotated_samples_into_batches(tmp_path):
     it = folder_batches(root, ['c0', 'c1'], prm, batch=4, seed=3, subset_fn='meta/subsets/REC-Street.train.1.lst')
     a, v, f, tgt, mask = next(it)
     assert a.shape == (4, 52799, 1) and v.shape == (4, 1, 224, 448, 3) and f is None and tgt.shape == (4, 4800, 3) and mask.shape == (4, 4)
+    # frames stay as decoded: Trainer.forward_backward dispatches uint8 frames to sagen_train_step_u8 (pixel normalisation on the device)
+    assert v.dtype == np.uint8 and a.dtype == np.float32 and tgt.dtype == np.float32
     # every window is a window of one of the two clips: W and Z (not rotated) identify it
     for i in range(4):
         w_centre = a[i, 24000:28800, 0]

@@ -44,6 +44,14 @@ def test_bench_configs_emit_the_contract_line(config, batch):
     assert r['config']['name'] == config and r['config']['workload'].startswith('configs[')
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(r['roofline'])
     assert 0 < r['h2d_inclusive']['value'] and 0 < r['one_in_flight']['value']
+    if config == 'av':       # the default run carries the other BASELINE configurations as short legs (fresh processes after the headline)
+        for name, batch_l in (('a', 10), ('avf', 32), ('eval', 16), ('train', 32)):
+            leg = r['leg_' + name]
+            assert 'error' not in leg, leg
+            assert leg['value'] > 0 and leg['ms_per_step'] > 0 and leg['steps'] > 0 and leg['windows_per_gpu_per_step'] == batch_l
+            assert leg['roofline']['kernel'] and 0 < leg['roofline']['frac'] < 1 and leg['roofline']['peak'] > 0
+    else:
+        assert not any(k.startswith('leg_') for k in r)
 
 
 def test_bench_eval_config_two_ranks_match_one_rank():

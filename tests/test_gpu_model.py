@@ -495,3 +495,46 @@ def test_fused_stem_pool_with_negative_gammas(T):
     subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, SAGEN_NO_STEMPOOL='1'), timeout=600)
     unfused = np.load(fn + '.out.npy')
     assert rms(got - unfused) <= 2e-5 * max(rms(unfused), 1e-9) + 1e-6
+
+
+def test_full_benchmark_batch_of_uint8_frames_against_the_independent_cpu_reference(T):
+    """The headline's exact kernel set - sagen_forward_u8 -> stem8pool_kernel on ONE operand plane - at its real size (32 windows)
+    directly against oracle/torch_ref.py in fp64 (it was held against the float-frame kernels only, a two-link chain)."""
+    import torch
+    from oracle.torch_ref import TorchRef
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    B = 32
+    P = init_weights(variable_specs(enc), seed=13, mode='test')
+    inp = synth_inputs(B, enc, seed=78)
+    u8 = np.round((inp['video'].astype(np.float64) + 0.5) * 255.0).astype(np.uint8)
+    assert np.array_equal((u8.astype(np.float64) / 255. - 0.5).astype(np.float32), inp['video'])      # the same frames, as decoded
+    ref = TorchRef(P, enc, dtype=torch.float64).forward(inp['audio'], inp['video'])
+    ref = ref.numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.profile_enable(B, True)
+    got = net.inference_ops(inp['audio'], u8).cpu().numpy()
+    kernels = {k for k, layer, us, fl in net.profile_report(B)}
+    net.profile_enable(B, False)
+    assert 'stem8pool_kernel' in kernels, kernels
+    check_out(got, ref)
+    assert net.counter(B, 'fp16x2_saturations') == 0
+
+
+def test_three_stream_batch_at_full_size_against_the_independent_cpu_reference(T):
+    """BASELINE configs[2] at its real size: audio + video + flow, 32 windows, against fp64 oracle/torch_ref.py (it was compared with
+    the oracle at B = 2 and through properties at B = 32 only)."""
+    import torch
+    from oracle.torch_ref import TorchRef
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video', 'flow']
+    B = 32
+    P = init_weights(variable_specs(enc), seed=14, mode='test')
+    inp = synth_inputs(B, enc, seed=79)
+    ref = TorchRef(P, enc, dtype=torch.float64).forward(inp['audio'], inp['video'], inp['flow'])
+    ref = ref.numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    check_out(net.inference_ops(inp['audio'], inp['video'], inp['flow']).cpu().numpy(), ref)
+    assert net.counter(B, 'fp16x2_saturations') == 0

@@ -127,6 +127,39 @@ def test_train_loop_keeps_one_periodic_checkpoint(tmp_path):
     assert int(load_checkpoint(latest_checkpoint(d))['step']) == 9
 
 
+def test_resume_prunes_the_previous_runs_periodic_checkpoints(tmp_path):
+    """max_to_keep=1 across --resume: the periodic bundles a previous process left behind go at the first periodic save of this one."""
+    from spatialaudiogen_amd.checkpoint import save_checkpoint
+    d = str(tmp_path)
+    for n in (3, 5):                                                 # left by an earlier run (two: e.g. one that died mid-prune)
+        save_checkpoint(os.path.join(d, 'model.ckpt-%d' % n), {'step': np.asarray(n, np.int32), 'w': np.zeros(6, np.float32)})
+    tr = _FakeTrainer()
+    tr.opt.step = 5
+    T.train_loop(tr, _endless(), d, n_iters=9, init_step=5, log_every=2, ckpt_every=2, log=lambda *_: None)
+    files = sorted(f for f in os.listdir(d) if f.endswith('.index'))
+    assert files == ['model.ckpt-9.index', 'model.ckpt.index'], files
+
+
+class _FakeCtx(object):
+    def __init__(self, jump_at):
+        self.reads, self.jump_at = 0, jump_at
+
+    def counter(self, name):
+        assert name == 'fp16x2_saturations'
+        self.reads += 1
+        return 0 if self.reads <= self.jump_at else 17
+
+
+def test_train_loop_stops_when_the_fp16x2_planes_saturate(tmp_path):
+    """The fp16x2 activation / gradient planes clamp (and count) elements beyond their statistical range bound; the loop reads the
+    counter at every log step and refuses to go on training on clamped values."""
+    tr = _FakeTrainer()
+    tr.ctx = _FakeCtx(jump_at=3)                                     # read 1: at loop entry; reads 2, 3: log steps 0, 2; read 4: step 4
+    with pytest.raises(FloatingPointError, match='clamped 17 elements'):
+        T.train_loop(tr, _endless(), str(tmp_path), n_iters=20, log_every=2, ckpt_every=1000, log=lambda *_: None)
+    assert tr.opt.step == 5
+
+
 def test_checkpoint_write_is_atomic(tmp_path, monkeypatch):
     """A writer that dies between the data file and the state file must leave --resume pointing at the previous complete bundle."""
     from spatialaudiogen_amd import checkpoint as C
