@@ -400,7 +400,8 @@ class BatchPrefetcher(object):
             for batch in make_batches:
                 if self.pin:
                     import torch
-                    batch = {k: (torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).pin_memory()
+                    # (decoded frames stay uint8 - the device normalises them; everything else travels as float32)
+                    batch = {k: (torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint8 if v.dtype == np.uint8 else np.float32)).pin_memory()
                                  if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
                 if not self._put(batch):
                     return

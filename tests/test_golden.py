@@ -13,6 +13,12 @@ import make_golden as G          # noqa: E402  (case table + probe list)
 from util import rms             # noqa: E402
 
 GOLD = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v1.npz'))
+# What TensorFlow 1.4 computed with the REFERENCE's own model.py on the same weights and inputs (tools/tf1_pin_inputs.py +
+# tools/tf1_dump_golden.py on a TF1 machine; README "Pinning parity against TF1").  Absent in this image: parity is then UNPINNED
+# against the reference itself and the tests below say so instead of passing vacuously.
+TF1_FN = os.path.join(ROOT, 'tests', 'golden', 'tf1_v1.npz')
+TF1 = np.load(TF1_FN) if os.path.exists(TF1_FN) else None
+UNPINNED = 'parity UNPINNED against TF1: tests/golden/tf1_v1.npz absent (python2 tools/tf1_dump_golden.py <reference checkout> tf1_pin_inputs.npz tests/golden/tf1_v1.npz)'
 
 
 @pytest.mark.parametrize('name', ['a_b2_s0', 'av_b2_s1'])
@@ -48,3 +54,60 @@ def test_hip_path_reproduces_golden(name):
     ref = GOLD[name + '/ambix']
     err = rms(got - ref)
     assert err <= 1e-4 and err <= 1e-3 * rms(ref), (name, err, rms(ref))
+
+
+@pytest.mark.parametrize('name', sorted(G.CASES))
+def test_oracle_matches_what_tf1_computed(name):
+    """The pin: the numpy oracle against the outputs of the reference's own graph (BASELINE.json: <= 1e-4 RMS vs TF1)."""
+    if TF1 is None:
+        pytest.skip(UNPINNED)
+    out = G.run_case(name)
+    ref = TF1[name + '/ambix'].astype(np.float64)
+    err = rms(out[name + '/ambix'].astype(np.float64) - ref)
+    assert err <= 1e-4 and err <= 1e-3 * rms(ref), (name, err, rms(ref))
+    for p in ('video_encoder/conv5_2', 'flow_encoder/conv5_2', 'decoder/ambix'):
+        k = '%s/chk/%s' % (name, p)
+        if k in TF1.files and k in out:                     # [sum, sumsq, 16 probes]: the trunk output and the final mix
+            scale = np.sqrt(TF1[k][1] / max(np.prod(TF1['%s/shape/%s' % (name, p)]), 1))
+            assert np.allclose(out[k][2:], TF1[k][2:], atol=1e-3 * scale + 1e-6), (k, out[k][2:6], TF1[k][2:6])
+            assert abs(out[k][1] - TF1[k][1]) <= 2e-3 * TF1[k][1] + 1e-9, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', sorted(G.CASES))
+def test_hip_path_matches_what_tf1_computed(name):
+    if TF1 is None:
+        pytest.skip(UNPINNED)
+    import torch
+    from spatialaudiogen_amd.model import SptAudioGen
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    assert torch.cuda.is_available()
+    enc, B, ws, ins = G.CASES[name]
+    P = init_weights(variable_specs(enc), seed=ws, mode='test')
+    inp = synth_inputs(B, enc, seed=ins)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    got = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow')).cpu().numpy()
+    ref = TF1[name + '/ambix'].astype(np.float64)
+    err = rms(got - ref)
+    assert err <= 1e-4 and err <= 1e-3 * rms(ref), (name, err, rms(ref))
+
+
+def test_pin_kit_inputs_carry_every_variable_under_its_checkpoint_name():
+    """tools/tf1_pin_inputs.py (step 1 of the pin kit): every variable of a case under '<case>/var/<TF name>', the inputs under
+    '<case>/in/*' - what tools/tf1_dump_golden.py assigns by name on the TF1 side (audio-only case: small)."""
+    import tf1_pin_inputs as K
+    from spatialaudiogen_amd.weights import variable_specs
+    saved = dict(G.CASES)
+    try:
+        for k in list(G.CASES):
+            if k != 'a_b2_s0':
+                del G.CASES[k]
+        d = K.build()
+    finally:
+        G.CASES.clear(); G.CASES.update(saved)
+    specs = variable_specs(['audio'])
+    for k, shape in specs.items():
+        assert tuple(d['a_b2_s0/var/' + k].shape) == tuple(shape) and d['a_b2_s0/var/' + k].dtype == np.float32
+    assert d['a_b2_s0/in/audio'].shape == (2, 52799, 1) and str(d['a_b2_s0/encoders']) == 'audio'
+    assert sum(1 for k in d if k.startswith('a_b2_s0/var/')) == len(specs)

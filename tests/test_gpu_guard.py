@@ -212,5 +212,8 @@ def test_training_feeder_batches_reach_the_uint8_training_entry(T, tmp_path):
     lossf = float(tr.forward_backward(a, frames_to_float(v), None, tgt, mask))
     assert tr.last_entry == 'sagen_train_step'
     gf = tr.grad('video_encoder/conv2_1/conv_1/weights').cpu().numpy()
-    assert np.isfinite(loss8) and abs(loss8 - lossf) <= 1e-5 * abs(lossf)
-    assert rel_rms_err(g8, gf) < 1e-4
+    from test_gpu_backward import FREE_RUNNING_BAR
+    # (the uint8 stem convolves the exact (u - 127.5) / 255, the float one the rounded float32 x: the loss agrees to fp32 rounding, a trunk
+    #  gradient at the level the free-running ReLU switching of a batch of 2 allows - tests/test_gpu_backward.py holds the same bars)
+    assert np.isfinite(loss8) and abs(loss8 - lossf) <= 2e-5 * abs(lossf)
+    assert rel_rms_err(g8, gf) < FREE_RUNNING_BAR
