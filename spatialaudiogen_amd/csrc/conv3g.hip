@@ -29,7 +29,9 @@ constexpr int conv3g_wgs_per_cu(int BM, int BN, int KS, bool H2) {
     return 3 * lds <= 160 * 1024 ? 3 : (2 * lds <= 160 * 1024 ? 2 : 1);
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool H2>
+// EPI 0: dense NHWC rows (+ bias / ReLU / batch-norm statistics); EPI 1: the fused decoder tail of deconv1 (igemm_epilogue_maskmix:
+// sigmoid + track-weighted sums per mask bin, IgemmDesc::mm_*) on the depth-to-space tile
+template <int BM, int BN, int WM, int WN, int KS, bool H2, int EPI = 0>
 __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g_kernel(const IgemmDesc d) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int Wp = d.Win + 1;
+    const int HinP = d.xp3_rows > 0 ? d.xp3_rows : d.Hin;        // image rows held by the planes (from row xp3_row0 on)
     const int nchunk = d.Cin >> 4;
     const int NKT = d.ntaps * nchunk;
     const int G = (NKT + KS - 1) / KS;
@@ -95,13 +98,14 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
             const int wo = m - (int)row * d.Wg;
             const unsigned b = __umulhi(row, d.p3_magic_h);                            // row / Hg
             const int ho = (int)row - (int)b * d.Hg;
-            const int hi = ho * d.in_sh + d.tap_h0, wi = wo * d.in_sw + d.tap_w0;
-            const int pix = ((int)b * d.Hin + hi) * Wp + wi;                           // may be -1 at the very first pixel: wraps to an out-of-range offset
+            // (the output grid may start at (g_h0, g_w0); the planes may hold only the image rows from xp3_row0 on)
+            const int hi = (d.g_h0 + ho) * d.in_sh + d.tap_h0 - d.xp3_row0, wi = (d.g_w0 + wo) * d.in_sw + d.tap_w0;
+            const int pix = ((int)b * HinP + hi) * Wp + wi;                           // may be -1 at the very first pixel: wraps to an out-of-range offset
             a_base[j] = (unsigned)(pix * SB + unit * 16);
             unsigned bad = 0;
             for (int th = 0; th * d.TW < d.ntaps; ++th) {
                 const int hh = hi + th * d.tap_sh;
-                if (hh < 0 || hh >= d.Hin) bad |= 1u << th;
+                if (hh < 0 || hh >= HinP) bad |= 1u << th;
             }
             a_bad[j] = bad;
         }
@@ -236,12 +240,25 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
     lds_barrier();
     group(std::false_type{});
 
-    // ---- epilogue through the (now idle) ring (conv3p.hip): 16-byte row-contiguous stores, bias / ReLU,
-    //      batch-norm statistics of the raw output ----
-    const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
     float osc = 1.f;
     if constexpr (H2) osc = d.h2_a_inv[0] * d.h2_w_inv[0];
     lds_barrier();                                           // every wave is done with the last group's fragments: the whole ring is free
+    if constexpr (EPI == 1) {
+        // ---- fused decoder tail: the tile (one mask frame of one window: conv3g_ok) through the ring a wave-row at a time ----
+        if constexpr (H2) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] *= osc;            // 2^-(ka + kw): exact
+        }
+        igemm_epilogue_maskmix<BM, BN, WM, WN, SMEM_BYTES / 4>(d, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+        return;
+    }
+    // ---- epilogue through the (now idle) ring (conv3p.hip): 16-byte row-contiguous stores, bias / ReLU,
+    //      batch-norm statistics of the raw output ----
+    const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
     char* const epi = smem;
     float* const tile = reinterpret_cast<float*>(epi);                       // [WM][BN]
     float* const red = reinterpret_cast<float*>(epi + EPI_TILE);             // [2][RPP][BN]
@@ -305,11 +322,11 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool H2>
+template <int BM, int BN, int WM, int WN, int KS, bool H2, int EPI = 0>
 static int launch_conv3g(const IgemmDesc& d, hipStream_t s) {
     const int per = (cdiv(d.M, BM) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
-    hipLaunchKernelGGL((conv3g_kernel<BM, BN, WM, WN, KS, H2>), dim3(grid), dim3(256), 0, s, d);
+    hipLaunchKernelGGL((conv3g_kernel<BM, BN, WM, WN, KS, H2, EPI>), dim3(grid), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -317,11 +334,18 @@ static int launch_conv3g(const IgemmDesc& d, hipStream_t s) {
 // can conv3g_kernel run this problem (given the planes)?  dense NHWC output, taps whose horizontal reach stays on the plane row +
 // its pad pixel, at most 32 filter rows, 16-channel chunks
 bool conv3g_ok(const IgemmDesc& d) {
-    if (d.dsh * d.dsw != 1 || d.g_h0 != 0 || d.g_w0 != 0 || d.Cin % 16 || d.K != d.ntaps * d.Cin || d.Kpad != d.K) return false;
+    if (d.Cin % 16 || d.K != d.ntaps * d.Cin || d.Kpad != d.K) return false;
     if (d.ntaps < 1 || d.TW < 1 || d.ntaps % d.TW || d.ntaps / d.TW > 32) return false;
-    if (d.y_rstride != (long)d.Wg * d.ldy || (d.M > d.Hg * d.Wg && d.y_bstride != (long)d.Hg * d.Wg * d.ldy)) return false;
-    if (d.mm_out != nullptr || d.in_scale != nullptr || d.bn_in.acc != nullptr) return false;
-    const int w_lo = d.tap_w0, w_hi = (d.Wg - 1) * d.in_sw + (d.TW - 1) * d.tap_sw + d.tap_w0;
+    if (d.in_scale != nullptr || d.bn_in.acc != nullptr) return false;
+    if (d.mm_out != nullptr) {       // the fused decoder tail: a depth-to-space tile of 64 grid columns x (4 pixels x 32 tracks) = one mask frame of one window
+        if (d.xp3_fmt != 1 || d.Cout != 32 || d.dsh * d.dsw <= 1 || d.Wg % 64 || (d.dsw * d.Cout) % 128 || d.splitk != 1 || !d.mm_coeffs) return false;
+    } else {
+        if (d.dsh * d.dsw != 1 || d.g_h0 != 0 || d.g_w0 != 0 || d.xp3_row0 != 0 || d.xp3_rows != 0) return false;
+        if (d.y_rstride != (long)d.Wg * d.ldy || (d.M > d.Hg * d.Wg && d.y_bstride != (long)d.Hg * d.Wg * d.ldy)) return false;
+    }
+    // horizontal reach of the taps over the whole grid: the pad pixel closing every plane row is column -1 and column Win
+    const int t_lo = std::min(0, (d.TW - 1) * d.tap_sw), t_hi = std::max(0, (d.TW - 1) * d.tap_sw);
+    const int w_lo = d.g_w0 * d.in_sw + d.tap_w0 + t_lo, w_hi = (d.g_w0 + d.Wg - 1) * d.in_sw + d.tap_w0 + t_hi;
     return w_lo >= -1 && w_hi <= d.Win;
 }
 
@@ -334,7 +358,9 @@ int conv3g_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: too many pixels for 32-bit index arithmetic");
     if ((long)d.p3_np * 96 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the activation planes exceed 2 GiB buffer addressing (use a smaller batch)");
-    const bool h2 = tile == TILE_P3GH_128x64_K3 || tile == TILE_P3GH_64x64_K4 || tile == TILE_P3GH_128x128_K2 || tile == TILE_P3GH_64x128_K3;
+    const bool mm = tile == TILE_P3GH_MM_64x128_K2 || tile == TILE_P3GH_MM_64x128_K4;
+    if (mm != (d.mm_out != nullptr)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the fused decoder tail and the tile do not match");
+    const bool h2 = mm || tile == TILE_P3GH_128x64_K3 || tile == TILE_P3GH_64x64_K4 || tile == TILE_P3GH_128x128_K2 || tile == TILE_P3GH_64x128_K3;
     if (h2 != (d.xp3_fmt == 1)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the planes' format does not match the tile");
     if (h2 && (!d.wh2 || !d.h2_a_inv || !d.h2_w_inv)) return fail(SAGEN_ERR_NULL, "conv3g: the fp16x2 filter planes / scales are missing");
     d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)d.Wg) + 1u;      // (reused fields: here the divisors are the OUTPUT grid's Wg, Hg)
@@ -348,6 +374,8 @@ int conv3g_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         case TILE_P3GH_64x64_K4: return launch_conv3g<64, 64, 32, 32, 4, true>(d, s);
         case TILE_P3GH_128x128_K2: return launch_conv3g<128, 128, 64, 64, 2, true>(d, s);
         case TILE_P3GH_64x128_K3: return launch_conv3g<64, 128, 32, 64, 3, true>(d, s);
+        case TILE_P3GH_MM_64x128_K2: return launch_conv3g<64, 128, 32, 64, 2, true, 1>(d, s);
+        case TILE_P3GH_MM_64x128_K4: return launch_conv3g<64, 128, 32, 64, 4, true, 1>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: bad tile id %d", (int)tile);
     }
 }

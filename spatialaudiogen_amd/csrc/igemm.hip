@@ -331,6 +331,7 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "conv3g_kernel<128,128,64,64,2,true>", true, false, false, true, true, true}, {64, 128, 16, "conv3g_kernel<64,128,32,64,3,true>", true, false, false, true, true, true},
     {128, 64, 32, "conv3h_kernel<128,64,64,32,2>", true, true, false, true, false, true}, {64, 64, 32, "conv3h_kernel<64,64,32,32,2>", true, true, false, true, false, true},
     {64, 64, 64, "conv3h_kernel<64,64,32,32,4>", true, true, false, true, false, true},
+    {64, 128, 16, "conv3g_kernel<64,128,32,64,2,true,1>", true, false, false, true, true, true}, {64, 128, 16, "conv3g_kernel<64,128,32,64,4,true,1>", true, false, false, true, true, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -363,7 +364,9 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     const int bk = kTiles[t].bk;
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
-    if (d.mm_out != nullptr) {              // fused decoder tail: igemm3_kernel tiles holding one mask frame of one window
+    const bool mm_tile = t == TILE_P3GH_MM_64x128_K2 || t == TILE_P3GH_MM_64x128_K4;      // conv3g_kernel with the fused decoder tail as epilogue
+    if (mm_tile != (d.mm_out != nullptr && kTiles[t].g)) return false;
+    if (d.mm_out != nullptr && !mm_tile) {  // fused decoder tail: igemm3_kernel tiles holding one mask frame of one window
         const bool b3 = kTiles[t].split && !kTiles[t].dw3 && !kTiles[t].s2 && !kTiles[t].p3;
         if (!b3 || kTiles[t].bm > 128 || kTiles[t].bn > 128 || d.Cout != 32 || d.dsh * d.dsw <= 1 || d.Wg % kTiles[t].bm ||
             (d.dsw * d.Cout) % kTiles[t].bn || d.splitk != 1 || d.in_scale || d.bn_in.acc || !d.mm_coeffs)
@@ -384,7 +387,7 @@ IgemmTile igemm_pick_tile(const IgemmDesc& d) {
     static const char* force = getenv("SAGEN_FORCE_TILE");               // tuning knob: IgemmTile index
     if (force && d.M > 128 && d.N >= 64 && igemm_tile_ok(d, (IgemmTile)atoi(force))) return (IgemmTile)atoi(force);
     static const bool fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
-    if (d.mm_out != nullptr) return TILE_B3_64x128;
+    if (d.mm_out != nullptr) return (d.xp3 != nullptr && d.xp3_fmt == 1 && d.wh2 != nullptr && conv3g_ok(d)) ? TILE_P3GH_MM_64x128_K2 : TILE_B3_64x128;
     auto blocks = [&](IgemmTile t) { return (long)cdiv(d.M, tile_bm(t)) * cdiv(d.N, tile_bn(t)) * d.splitk; };
     const long want = 2 * 256;                 // >= 2 workgroups per CU
     if (d.w_split && !fp32_only) {             // the bf16x3 kernels are the faster family wherever their planes exist
@@ -661,6 +664,53 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
         hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv((long)M * N, 256)), dim3(256), 0, s, ws, splitk, M, N, bias, relu,
                            y, ldy, rep);
     }
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// stride-1 conv2d_transpose in SCATTER form (tf.nn.conv2d_transpose, core.py:96-153; the mask decoder's deconv5 / deconv4,
+// model.py:302-305): out[b, y+p, x+q, o] += in[b, y, x, c] * W[p, q, o, c].  As a stride-1 conv over the OUTPUT grid (igemm's depth-to-space
+// form) every output pixel contracts all kh*kw taps, of which only those landing inside the small input are non-zero - 5.4 of 15 for
+// deconv5 (3x6 -> 5x10), 7.7 of 15 for deconv4: the rest multiplies padding.  The scatter form contracts each INPUT pixel once,
+//     T[m = (b, y, x)][n = (p, q, o)] = sum_c in[m][c] * W[p][q][o][c]          (a plain GEMM: M = B*Hin*Win, K = Cin, N = kh*kw*Cout)
+// and this pass gathers out[b, y', x', o] = act(bias[o] + sum_z sum_{p, q valid} T_z[(b, y'-p, x'-q)][(p, q, o)]) in a fixed order -
+// it IS the split-K reducer of that GEMM.  36 % / 51 % of the matrix work and of the filter streaming of the conv form.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restrict__ ws, int splitk, int B, int Hin, int Win, int kh, int kw,
+                                                            int Cout, const float* __restrict__ bias, int relu, float* __restrict__ y, int ldy) {
+    const int Hout = Hin + kh - 1, Wout = Win + kw - 1, C4 = Cout >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * Hout * Wout * C4) return;
+    const int c4 = (int)(idx % C4);
+    const long pix = idx / C4;
+    const int xo = (int)(pix % Wout), yo = (int)((pix / Wout) % Hout), b = (int)(pix / ((long)Wout * Hout));
+    const long M = (long)B * Hin * Win, N = (long)kh * kw * Cout;
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < kh; ++p) {
+        const int yi = yo - p;
+        if ((unsigned)yi >= (unsigned)Hin) continue;
+        for (int q = 0; q < kw; ++q) {
+            const int xi = xo - q;
+            if ((unsigned)xi >= (unsigned)Win) continue;
+            const float* t = ws + (((long)b * Hin + yi) * Win + xi) * N + (long)(p * kw + q) * Cout + 4 * c4;
+            for (int z = 0; z < splitk; ++z, t += M * N) {
+                const float4 v = *reinterpret_cast<const float4*>(t);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(y + pix * ldy + 4 * c4) = acc;
+}
+
+int deconv_gather_launch(const float* ws, int splitk, int B, int Hin, int Win, int kh, int kw, int Cout, const float* bias, int relu,
+                         float* y, int ldy, hipStream_t s) {
+    if (!ws || !y) return fail(SAGEN_ERR_NULL, "deconv_gather: null argument");
+    if (Cout % 4 || ldy % 4 || ((uintptr_t)y % 16) || (bias && ((uintptr_t)bias % 16)))
+        return fail(SAGEN_ERR_UNSUPPORTED, "deconv_gather: Cout / ldy must be multiples of 4 and the pointers 16-byte aligned");
+    const long total = (long)B * (Hin + kh - 1) * (Win + kw - 1) * (Cout / 4);
+    hipLaunchKernelGGL(deconv_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, ws, splitk, B, Hin, Win, kh, kw, Cout, bias, relu, y, ldy);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -2,6 +2,7 @@
 // per-row geometry tables, batch-norm coefficient setup, LDS-DMA helpers and the output epilogue.
 #pragma once
 #include "kernels.h"
+#include "h2_planes.h"
 
 namespace sagen {
 
@@ -104,6 +105,14 @@ __device__ __forceinline__ void igemm_setup(const IgemmDesc& d, int m0, int tid,
 
 }
 
+// IgemmDesc::amax_out: the wave's maximum of |stored value| into a zeroed word (non-negative floats order like their bit patterns).
+// (fmaxf drops NaNs: a non-finite output does not show in the maximum - the pack pass that reads the tensor meets the value itself and
+//  p3h_store keeps it a NaN in the planes)
+__device__ __forceinline__ void igemm_publish_amax(float* amax_out, float v) {
+    v = wave_max_f(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, v));
+}
+
 // ---- epilogue: bias / ReLU / depth-to-space scatter, split-K partials, batch-norm statistics ----
 // acc: MFMA 32x32 C/D layout per (i, j) sub-tile; `red` = scratch of >= 2 * (BM / WM) * BN floats (the tile ring)
 template <int BM, int BN, int WM, int WN>
@@ -120,6 +129,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)
     const int dswC = d.dsw * d.Cout;
     const bool to_ws = d.splitk_ws != nullptr;     // raw partials for the split-K / replicate reduce
     float csum[NT], csq[NT];
+    float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         csum[j] = 0.f;
@@ -156,11 +166,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmDesc& d, f32x16 (&acc)
                         v += bias;
                         if (d.relu_out) v = fmaxf(v, 0.f);
                         d.y[s_row[row].rowoff + coloff] = v;
+                        amax = fmaxf(amax, fabsf(v));
                     }
                 }
             }
         }
     }
+    if (d.amax_out != nullptr && !to_ws) igemm_publish_amax(d.amax_out, amax);
     if (to_ws && d.sk_ticket != nullptr) {
         // ---- last-arriver combine.  The eight XCDs have their own L2s: the partials are written and read with AGENT-scope accesses
         // (write-through stores, loads that never return a stale line) - a release / acquire FENCE pair instead writes back and
@@ -268,6 +280,7 @@ __device__ __forceinline__ bool igemm_epilogue_rows(const IgemmDesc& d, f32x16 (
             bias.z = n + 2 < d.N ? d.bias[n + 2] : 0.f; bias.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
         }
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
+        float amax = 0.f;
 #pragma unroll
         for (int part = 0; part < WAVES_M; ++part) {
             if (wm == part) {
@@ -307,9 +320,12 @@ __device__ __forceinline__ bool igemm_epilogue_rows(const IgemmDesc& d, f32x16 (
                     if (n + 2 < d.N) dst[2] = v.z;
                     if (n + 3 < d.N) dst[3] = v.w;
                 }
+                amax = fmaxf(amax, fmaxf(fmaxf(n < d.N ? fabsf(v.x) : 0.f, n + 1 < d.N ? fabsf(v.y) : 0.f),
+                                         fmaxf(n + 2 < d.N ? fabsf(v.z) : 0.f, n + 3 < d.N ? fabsf(v.w) : 0.f)));
             }
             if (part + 1 < WAVES_M) __syncthreads();
         }
+        if (d.amax_out != nullptr) igemm_publish_amax(d.amax_out, amax);
         if (d.stats != nullptr) {
             *reinterpret_cast<float4*>(part_sums + (0 * RPP + rg) * BN + 4 * c4) = cs;
             *reinterpret_cast<float4*>(part_sums + (1 * RPP + rg) * BN + 4 * c4) = cq;

@@ -35,6 +35,9 @@ struct IgemmDesc {
     const float* in_shift = nullptr;
     BnRef bn_in;                      // alternative to in_scale/in_shift: derive them in-kernel (Cin <= 512)
     double* stats = nullptr;          // fp64 accumulators [2][N] of (sum, sumsq) of the raw output (atomics), or null
+    // exact max |y| over everything this launch stores (after bias / ReLU), atomicMax of the bit pattern into a zeroed word, or null:
+    // the scale of the fp16x2 planes a consumer's pack pass makes of the tensor (h2_pack_rows_launch) - exact, so nothing can saturate
+    float* amax_out = nullptr;
     float* splitk_ws = nullptr;       // [splitk][M][N] when splitk > 1
     // in-launch combine of the split-K partials (igemm_common.h: igemm_epilogue): one ticket per output tile, zero between launches;
     // the workgroup that draws the last ticket of its tile adds the partials in the fixed order z = 0 .. splitk-1, applies bias / ReLU
@@ -68,6 +71,7 @@ struct IgemmDesc {
     unsigned xp3_bytes = 0, xp3_cstride = 0;
     int p3_np = 0;
     int xp3_fmt = 0;                  // 0: three bf16 planes (96 B per pixel and chunk); 1: two fp16 planes of v * 2^ka (64 B; conv3h.hip)
+    int xp3_row0 = 0, xp3_rows = 0;   // conv3g_kernel: the planes hold image rows [xp3_row0, xp3_row0 + xp3_rows) only (xp3_rows = 0: all Hin rows)
     const void* wh2 = nullptr;        // conv3h_kernel: the filter as two fp16 planes of w * 2^kw, [Kpad/16][2][N][16]
     unsigned wh2_bytes = 0;
     const float* h2_a_inv = nullptr;  // device scalars 2^-ka (written by the plane producer) and 2^-kw (written by the filter pack)
@@ -117,6 +121,8 @@ enum IgemmTile {
     TILE_P3GH_128x64_K3, TILE_P3GH_64x64_K4, TILE_P3GH_128x128_K2, TILE_P3GH_64x128_K3,
     // conv3h_kernel with two / four 16-channel chunks per barrier step (the deep, latency-bound layers)
     TILE_P3H_128x64_C2, TILE_P3H_64x64_C2, TILE_P3H_64x64_C4,
+    // conv3g_kernel on fp16x2 planes with the fused decoder tail as its epilogue (deconv1 at inference: IgemmDesc::mm_out), 2 / 4 K tiles per group
+    TILE_P3GH_MM_64x128_K2, TILE_P3GH_MM_64x128_K4,
     TILE_AUTO
 };
 
@@ -154,6 +160,11 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation
 constexpr int SPLITK_RB = 16;
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
                          float* y, int ldy, int rep, double* stats, hipStream_t s);
+
+// stride-1 conv2d_transpose in scatter form (igemm.hip): gathers act(bias + sum_z sum_taps T_z[(b, y'-p, x'-q)][(p, q, o)]) from the
+// partials ws[splitk][B*Hin*Win][kh*kw*Cout] of the GEMM over the INPUT pixels into y[b, y', x', o] (pixel stride ldy)
+int deconv_gather_launch(const float* ws, int splitk, int B, int Hin, int Win, int kh, int kw, int Cout, const float* bias, int relu,
+                         float* y, int ldy, hipStream_t s);
 
 // filter repacking (pack.hip).  All produce [Npad][Kpad] with zero padding.
 // conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src).  With tw_pad > tw_src > 0 the packed
@@ -241,6 +252,11 @@ struct P3hScale {
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
                    float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);
 size_t p3h_bytes(int B, int H, int W, int C);
+// rows [row0, row0 + R) of every image of an fp32 NHWC tensor (pixel stride ldx, row stride x_rstride, image stride x_bstride, all in
+// floats) -> fp16x2 planes [C/16][B*R*(W+1)][2][16] of v * 2^ka with ka from the EXACT maximum max(amax0[0], amax1[0]) the producers'
+// epilogues published (IgemmDesc::amax_out; amax1 nullable): nothing can saturate.  2^-ka -> a_inv[0].
+int h2_pack_rows_launch(const float* x, long x_bstride, long x_rstride, int ldx, int row0, int B, int R, int W, int C, const float* amax0,
+                        const float* amax1, void* planes, float* a_inv, unsigned* sat_count, hipStream_t s);
 // 3x3/2 SAME max-pool of relu(bn(x)) -> fp32 NHWC `y` (or null) and planes `p3` (or null) of the pooled tensor
 int p3_maxpool_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, void* p3, int B, int H,
                       int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -230,6 +231,10 @@ struct Fwd {
     std::string sfx;                 // suffix of the trunk buffers this stream owns ("" or "_b")
     hipEvent_t wait_before_mfma = nullptr;   // event the first contraction of this stream has to wait for (see forward)
     hipEvent_t wait_packs = nullptr;         // training step: the filter packs of everything behind the stem (second stream, sagen_forward_impl)
+    // set around one contract(): the partials [sk][M][N] are consumed by this pass instead of splitk_reduce_kernel (the scatter-form
+    // transposed convs: deconv_gather_kernel) - the contraction then ALWAYS writes partials, also with sk = 1
+    std::function<int(const float* ws, int sk, hipStream_t s)> custom_reduce;
+    const char* custom_reduce_name = "";
 
     hipEvent_t next_event() {
         if (c->events_used == c->event_pool.size()) {
@@ -265,10 +270,16 @@ struct Fwd {
     // launches the contraction with an explicit choice; returns the number of BN partial rows written (0 if none)
     int run_choice(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
         if (rc) return 0;
-        if (sk > 1 || rep > 1) {
+        if (sk > 1 || rep > 1 || custom_reduce) {
             IgemmDesc e = d;
             e.splitk = sk;
             e.splitk_ws = c->ws + c->bufs.at(wsname).off;
+            if (custom_reduce) {
+                e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
+                timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
+                timed(custom_reduce_name, 0.0, [&] { return custom_reduce(e.splitk_ws, sk, s); });
+                return 0;
+            }
             // the partials are combined by the contraction itself (last-arriver, igemm_epilogue) unless statistics ride on the reducer
             const long tiles = (long)cdiv(d.M, igemm_tile_bm(tile)) * cdiv(d.N, igemm_tile_bn(tile));
             if (c->sk_fused && sk > 1 && !d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && ((uintptr_t)d.y % 16) == 0 && (!d.bias || ((uintptr_t)d.bias % 16) == 0) &&
@@ -338,7 +349,7 @@ struct Fwd {
             for (int sk : SKS) {
                 if (sk > 1 && (!allow_split || !dense || igemm_tile_p3(tile))) break;
                 if (sk > 1 && (nk / sk < 4 || (size_t)sk * d.M * d.N > ws_capacity())) break;
-                if (sk == 1 && rep > 1 && (size_t)d.M * d.N > ws_capacity()) continue;
+                if (sk == 1 && (rep > 1 || custom_reduce) && (size_t)d.M * d.N > ws_capacity()) continue;
                 const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn) * sk;
                 if (sk > 1 && blocks > 8192) break;                     // more parallelism than the chip can use
                 float t_best = 1e30f;
@@ -388,7 +399,7 @@ struct Fwd {
         } else {
             ch = heuristic(d, rep, allow_split);
         }
-        if ((ch.splitk > 1 || rep > 1) && (size_t)std::max(ch.splitk, 1) * d.M * d.N > ws_capacity()) {
+        if ((ch.splitk > 1 || rep > 1 || custom_reduce) && (size_t)std::max(ch.splitk, 1) * d.M * d.N > ws_capacity()) {
             rc = fail(SAGEN_ERR_WORKSPACE, "split-K scratch too small for %s", layer.c_str());
             return 0;
         }
@@ -434,7 +445,8 @@ struct Fwd {
 
     // tfw.deconv_2d (core.py:96-153) as a stride-1 conv with a depth-to-space epilogue
     void deconv(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int a0, int a1, int Ylim,
-                long y_bstride, long y_row0, const float* mm_coeffs = nullptr, float* mm_out = nullptr, int mm_nf = 0) {
+                long y_bstride, long y_row0, const float* mm_coeffs = nullptr, float* mm_out = nullptr, int mm_nf = 0,
+                const std::function<void(IgemmDesc&)>& tweak = nullptr) {
         const std::string name = "separation/deconv" + std::to_string(l + 1);
         layer = name;
         const int kh = AENC_K[l][0], kw = AENC_K[l][1], sh = AENC_S[l][0], sw = AENC_S[l][1];
@@ -454,7 +466,29 @@ struct Fwd {
         d.y = y - y_row0 * d.y_rstride;
         d.relu_out = relu;
         if (mm_out) { d.mm_coeffs = mm_coeffs; d.mm_out = mm_out; d.mm_row0 = (int)y_row0; d.mm_nf = mm_nf; d.mm_f_lo = 1; }
+        if (tweak) tweak(d);
         gemm(d);
+    }
+
+    // stride-1 tfw.deconv_2d in scatter form (igemm.hip: deconv_gather_kernel): one GEMM over the INPUT pixels against the filter as
+    // [(p, q, o)][c] ("pks:" pack), gathered (+ bias, ReLU) into y by the pass that also sums the split-K partials
+    void deconv_scatter(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu) {
+        const std::string name = "separation/deconv" + std::to_string(l + 1);
+        layer = name;
+        const int kh = AENC_K[l][0], kw = AENC_K[l][1];
+        const int Cout = l == 0 ? c->nsep : AENC_F[l - 1];
+        IgemmDesc d;
+        d.x = x; d.w = c->p("pks:" + name + "/weights");
+        d.M = c->B * Hin * Win; d.N = kh * kw * Cout; d.K = Cin; d.Kpad = Cin;
+        d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = Cin; d.ldx = Cin; d.x_bstride = Cin;
+        d.ntaps = 1; d.Cout = d.N; d.Hlim = 1; d.Wlim = 1; d.ldy = d.N; d.y_rstride = d.N; d.y_bstride = d.N;
+        d.y = c->ws + c->bufs.at(wsname).off;            // (never written: the contraction leaves partials only)
+        const float* bias = c->v(name + "/biases");
+        const int B = c->B;
+        custom_reduce_name = "deconv_gather_kernel";
+        custom_reduce = [=](const float* ws, int sk, hipStream_t st) { return deconv_gather_launch(ws, sk, B, Hin, Win, kh, kw, Cout, bias, relu ? 1 : 0, y, ldy, st); };
+        gemm(d);
+        custom_reduce = nullptr;
     }
 
     // fp16x2 planes (conv3h.hip) for this forward?  (the training step's forward too, unless SAGEN_TRAIN_NO_H2=1: its backward reads the

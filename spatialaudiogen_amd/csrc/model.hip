@@ -134,9 +134,15 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
             n = packed_floats(vs.shape[1], vs.shape[0]);
         }
         c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
+        if (vs.name.find("/deconv") != std::string::npos) {     // stride-1 transposed convs also in scatter form: [(p, q, o)][c] (Fwd::deconv_scatter)
+            const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
+            if (AENC_S[l][0] * AENC_S[l][1] == 1 && vs.shape[3] % 16 == 0)
+                c->alloc("pks:" + vs.name, packed_split_floats(packed_floats((long)vs.shape[0] * vs.shape[1] * vs.shape[2], vs.shape[3])));
+        }
         // the 3x3 convs (and 1x1 projections) of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
-        if (vs.ndim == 4 && ((vs.shape[0] == 3 && vs.shape[1] == 3) || (vs.shape[0] == 1 && vs.shape[1] == 1)) && vs.shape[2] % 16 == 0 &&
-            vs.name.find("_encoder/conv") != std::string::npos) {
+        // ... and deconv1 of the mask decoder (conv3g_kernel with the fused decoder tail on planes of cat1: sagen_forward_impl)
+        if ((vs.ndim == 4 && ((vs.shape[0] == 3 && vs.shape[1] == 3) || (vs.shape[0] == 1 && vs.shape[1] == 1)) && vs.shape[2] % 16 == 0 &&
+             vs.name.find("_encoder/conv") != std::string::npos) || vs.name == "separation/deconv1/weights") {
             c->alloc("pkh:" + vs.name, n);
             h2_pack_blocks += n / 1024 + 1;
             const int slot = 8 + (int)c->h2_slot.size();
@@ -158,6 +164,10 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->alloc("coeffs", (size_t)B * 3 * 3 * (c->nsep + 1));
     c->alloc("splitk", std::max<size_t>((size_t)16 << 20, (size_t)B * 56 * 112 * 64 * 2));   // fp32 split-K partials (up to 2 splits of the largest conv), checked per use
     if (c->freq_mask) {
+        // rows 10..16 of cat1 as fp16x2 planes (the operand of deconv1 on conv3g_kernel) + the words around them: [0], [1] = exact max |y|
+        // of cat1's encoder / decoder half (published by the epilogues of conv1 / deconv2), [8] = 2^-ka of the planes
+        c->alloc("cat1p", (p3h_bytes(B, 7, c->enc_w[1], 2 * c->enc_c[1]) + 3) / 4 + 64);
+        c->alloc("amax", 16);
         c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
         c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
     }
@@ -298,6 +308,14 @@ int sagen_repack_part(sagen_ctx* c, hipStream_t s, int part) {
                 if (vs.name.size() < 8 || vs.name.compare(vs.name.size() - 8, 8, "/weights") != 0) continue;
                 const bool stem = vs.name.find("/conv1/conv/") != std::string::npos;
                 if (stem == (pass == 0)) c->pack_jobs.push_back(forward_pack_job(c, vs));
+                if (pass == 1 && c->bufs.count("pks:" + vs.name)) {      // the scatter-form pack of a stride-1 transposed conv: rows (p, q, o), columns c
+                    PackJob j;
+                    j.src = c->v(vs.name); j.dst = c->p("pks:" + vs.name);
+                    j.kind = PACK_ROWS;
+                    j.N = (int)(vs.shape[0] * vs.shape[1] * vs.shape[2]); j.Kpad = (int)vs.shape[3];
+                    j.p[0] = j.N; j.p[1] = (int)vs.shape[3];
+                    c->pack_jobs.push_back(j);
+                }
             }
             if (pass == 0) c->pack_early_jobs = (int)c->pack_jobs.size();
         }
@@ -323,6 +341,11 @@ int sagen_repack_part(sagen_ctx* c, hipStream_t s, int part) {
             if (!vs) continue;
             H2Job j;
             j.N = (int)vs->shape[3]; j.Kpad = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]);
+            if (vs->name.find("/deconv") != std::string::npos) {      // depth-to-space pack: N = (ry, rx, o), K = (dp, dq, c)
+                const int l = vs->name[vs->name.find("/deconv") + 7] - '1';
+                j.N = AENC_S[l][0] * AENC_S[l][1] * (int)vs->shape[2];
+                j.Kpad = cdiv(vs->shape[0], AENC_S[l][0]) * cdiv(vs->shape[1], AENC_S[l][1]) * (int)vs->shape[3];
+            }
             j.wp = c->p("pk:" + vs->name); j.w2 = c->p("pkh:" + vs->name); j.w_inv = c->p("h2s") + kv.second;
             j.first_block = nb;
             nb += (int)(((long)j.N * j.Kpad + 1023) / 1024);
@@ -378,6 +401,18 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     }
 
+    // deconv1 on fp16x2 planes of cat1 (conv3g_kernel + fused decoder tail): the planes' scale is the EXACT maximum of cat1, published by
+    // the epilogues of its two producers (conv1: encoder half, deconv2: decoder half) into words zeroed here
+    static const bool no_d1p = getenv("SAGEN_NO_DECONV1_PLANES") != nullptr;
+    bool d1_planes = !no_d1p && c->freq_mask && !c->train_mode && !c->materialize_mask && !c->fp32_only && c->nsep == 32 && f.h2() &&
+                     c->bufs.count("cat1p") != 0 && c->h2_slot.count("separation/deconv1") != 0 && getenv("SAGEN_NO_MASKFUSE") == nullptr;
+    if (d1_planes && !c->tuning) {             // a plan that names a register-staged tile for deconv1 keeps the round-4 path (no pack pass)
+        auto it = c->plan.find("separation/deconv1");
+        if (it != c->plan.end() && it->second.tile != (int)TILE_P3GH_MM_64x128_K2 && it->second.tile != (int)TILE_P3GH_MM_64x128_K4) d1_planes = false;
+    }
+    float* const amax = c->freq_mask ? c->p("amax") : nullptr;
+    if (d1_planes) SAGEN_HIP_CHECK(hipMemsetAsync(amax, 0, 16 * sizeof(float), g.s));
+
     // ---- stream g: STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
     g.layer = "stft";
     g.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), g.s); });
@@ -417,6 +452,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         }
         d.bias = c->v(name + "/biases");
         d.relu_out = 1;
+        if (l == 0 && d1_planes) d.amax_out = amax + 0;
         g.layer = name;
         g.gemm(d);
     }
@@ -484,10 +520,38 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
 
     // separation (model.py:282-348)
     f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6);     // tile over 6 freq columns
+    // Only rows 10..16 of cat1 reach deconv1's live grid rows (11..16, two vertical taps), hence - at inference - only output rows
+    // 10..16 of deconv2, whose grid rows 5..8 read rows 4..8 of cat2, hence only those of deconv3 (grid rows 2..4): the strided
+    // transposed convs run on the live part of their grid (4 of 16 and 3 of 8 grid rows).  The stride-1 ones (deconv5, deconv4) run in
+    // scatter form instead (every input pixel contracted once: Fwd::deconv_scatter).  The training step keeps the full tensors.
+    static const bool no_prune = getenv("SAGEN_NO_DECONV_PRUNE") != nullptr, no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
+    const bool lean = !c->train_mode && !c->fp32_only;
+    int need_lo[6], need_hi[6];                          // rows of cat_l the decoder below it reads
+    for (int l = 1; l <= 5; ++l) { need_lo[l] = 0; need_hi[l] = c->enc_h[l]; }
+    if (lean && !no_prune) {
+        need_lo[1] = 10; need_hi[1] = 17;
+        for (int l = 1; l <= 2; ++l) {                   // deconv(l+1) writes cat_l; both are strided (2x4, 2x2)
+            const int sh = AENC_S[l][0], nth = cdiv(AENC_K[l][0], sh);
+            const int a0 = need_lo[l] / sh, a1 = (need_hi[l] - 1) / sh + 1;
+            need_lo[l + 1] = std::max(a0 - (nth - 1), 0);
+            need_hi[l + 1] = std::min(a1, c->enc_h[l + 1]);
+        }
+    }
     for (int l = 4; l >= 1; --l) {
         const int Cin = 2 * c->enc_c[l + 1];
+        const bool strided = AENC_S[l][0] * AENC_S[l][1] > 1;
+        if (!strided && lean && !no_scatter && c->bufs.count("pks:separation/deconv" + std::to_string(l + 1) + "/weights")) {
+            f.deconv_scatter(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
+                             2 * c->enc_c[l], true);
+            continue;
+        }
+        int a0 = 0, a1 = 0, ylim = 0;
+        if (strided && (need_lo[l] > 0 || need_hi[l] < c->enc_h[l])) {
+            a0 = need_lo[l] / AENC_S[l][0]; a1 = (need_hi[l] - 1) / AENC_S[l][0] + 1; ylim = need_hi[l];
+        }
+        float* const am = (l == 1 && d1_planes) ? amax + 1 : nullptr;
         f.deconv(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
-                 2 * c->enc_c[l], true, 0, 0, 0, 0, 0);
+                 2 * c->enc_c[l], true, a0, a1, ylim, 0, 0, nullptr, nullptr, 0, [am](IgemmDesc& d) { d.amax_out = am; });
     }
     // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16.
     // Inference: sigmoid and the track-weighted sums run in its epilogue (igemm_epilogue_maskmix) and the 94 MB of logits are never
@@ -500,7 +564,28 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
     float* const ebuf = fused_tail ? c->p("dmask") : nullptr;       // (32 bytes per bin in the buffer of the 128-byte logits)
-    f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44, c->p("coeffs"), ebuf, 23);
+    std::function<void(IgemmDesc&)> d1_tweak = nullptr;
+    if (d1_planes && fused_tail) {
+        // rows 10..16 of cat1 (all deconv1's live grid rows read) -> two fp16 planes per element, one zero pixel closing every row
+        const int W1 = c->enc_w[1], C1 = 2 * c->enc_c[1];
+        f.layer = "separation/cat1-planes";
+        f.timed("h2_pack_rows_kernel", 0.0, [&] {
+            return h2_pack_rows_launch(c->p("cat1"), (long)c->enc_h[1] * W1 * C1, (long)W1 * C1, C1, 10, B, 7, W1, C1, amax + 0, amax + 1, c->p("cat1p"),
+                                       amax + 8, reinterpret_cast<unsigned*>(c->p("h2s") + 7), s); });
+        const float* w_inv = c->p("h2s") + c->h2_slot.at("separation/deconv1");
+        const void* planes = c->p("cat1p");
+        const void* wh2 = c->p("pkh:separation/deconv1/weights");
+        const float* a_inv = amax + 8;
+        d1_tweak = [=](IgemmDesc& d) {
+            d.xp3 = planes; d.xp3_fmt = 1; d.xp3_row0 = 10; d.xp3_rows = 7;
+            d.p3_np = B * 7 * (W1 + 1);
+            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+            d.xp3_bytes = (unsigned)((size_t)d.xp3_cstride * (C1 / 16));
+            d.wh2 = wh2; d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+            d.h2_a_inv = a_inv; d.h2_w_inv = w_inv;
+        };
+    }
+    f.deconv(c->p("cat1"), 31, 127, 64, 0, c->p("dmask"), c->nsep, false, 11, 17, 67, 23L * 1024 * c->nsep, 44, c->p("coeffs"), ebuf, 23, d1_tweak);
     if (fork2 && !fused_tail) {                          // the mix needs the localisation coefficients
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_join, c->aux));
         SAGEN_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));

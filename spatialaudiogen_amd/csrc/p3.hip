@@ -234,6 +234,48 @@ int p3_pack_launch(const float* x, const float* scale, const float* shift, const
     return SAGEN_OK;
 }
 
+// ---- a band of rows of a plain fp32 tensor as fp16x2 planes, scaled by its producers' EXACT maximum (the decoder's concat buffers:
+//      no batch-norm bounds them, so the contractions that wrote the two halves publish max |y| from their epilogues) ----
+__global__ __launch_bounds__(256) void h2_pack_rows_kernel(const float* __restrict__ x, long x_bstride, long x_rstride, int ldx, int row0, int B, int R,
+                                                           int W, int C, const float* __restrict__ amax0, const float* __restrict__ amax1,
+                                                           char* __restrict__ planes, float* __restrict__ a_inv, unsigned* __restrict__ sat_count) {
+    const int C8 = C >> 3;
+    const long NP = (long)B * R * (W + 1);
+    const long total = NP * C8;
+    const float bound = fmaxf(amax0[0], amax1 ? amax1[0] : 0.f);
+    const float sa = h2_scale_of_bound(bound);               // bound * sa in [512, 1024): an exact bound, nothing saturates
+    if (blockIdx.x == 0 && threadIdx.x == 0) a_inv[0] = 1.f / sa;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pp = i / C8;
+        const int c8 = (int)(i - pp * C8);
+        const long row = pp / (W + 1);
+        const int w = (int)(pp - row * (W + 1));
+        float v[8];
+        if (w < W) {
+            const long b = row / R;
+            const int r = (int)(row - b * R);
+            const float* src = x + b * x_bstride + (long)(row0 + r) * x_rstride + (long)w * ldx + 8 * c8;
+            const float4 a = *reinterpret_cast<const float4*>(src), bq = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        }
+        p3h_store(planes, NP * 64, pp, c8, v, sa, sat_count);
+    }
+}
+
+int h2_pack_rows_launch(const float* x, long x_bstride, long x_rstride, int ldx, int row0, int B, int R, int W, int C, const float* amax0,
+                        const float* amax1, void* planes, float* a_inv, unsigned* sat_count, hipStream_t s) {
+    if (!x || !amax0 || !planes || !a_inv) return fail(SAGEN_ERR_NULL, "h2_pack_rows: null argument");
+    if (C % 16 || ldx % 4 || ((uintptr_t)x % 16)) return fail(SAGEN_ERR_UNSUPPORTED, "h2_pack_rows: C %% 16, ldx %% 4 and a 16-byte aligned tensor are required");
+    const long total = (long)B * R * (W + 1) * (C / 8);
+    hipLaunchKernelGGL(h2_pack_rows_kernel, dim3((int)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, s, x, x_bstride, x_rstride, ldx, row0,
+                       B, R, W, C, amax0, amax1, (char*)planes, a_inv, sat_count);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
 // tf.nn.max_pool(x,[1,3,3,1],[1,2,2,1],'SAME') (resnet.py:135) of relu(bn(x)), -inf padding; see elementwise.hip
 template <bool H2>
 __global__ __launch_bounds__(256) void p3_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
