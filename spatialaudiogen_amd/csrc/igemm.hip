@@ -669,48 +669,61 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
 }
 
 // -----------------------------------------------------------------------------------------
-// stride-1 conv2d_transpose in SCATTER form (tf.nn.conv2d_transpose, core.py:96-153; the mask decoder's deconv5 / deconv4,
-// model.py:302-305): out[b, y+p, x+q, o] += in[b, y, x, c] * W[p, q, o, c].  As a stride-1 conv over the OUTPUT grid (igemm's depth-to-space
+// conv2d_transpose in SCATTER form (tf.nn.conv2d_transpose, core.py:96-153; the mask decoder's deconv5 .. deconv2 at inference,
+// model.py:302-305): out[b, y*sh+p, x*sw+q, o] += in[b, y, x, c] * W[p, q, o, c] (written below for stride 1).  As a stride-1 conv over the OUTPUT grid (igemm's depth-to-space
 // form) every output pixel contracts all kh*kw taps, of which only those landing inside the small input are non-zero - 5.4 of 15 for
 // deconv5 (3x6 -> 5x10), 7.7 of 15 for deconv4: the rest multiplies padding.  The scatter form contracts each INPUT pixel once,
 //     T[m = (b, y, x)][n = (p, q, o)] = sum_c in[m][c] * W[p][q][o][c]          (a plain GEMM: M = B*Hin*Win, K = Cin, N = kh*kw*Cout)
 // and this pass gathers out[b, y', x', o] = act(bias[o] + sum_z sum_{p, q valid} T_z[(b, y'-p, x'-q)][(p, q, o)]) in a fixed order -
 // it IS the split-K reducer of that GEMM.  36 % / 51 % of the matrix work and of the filter streaming of the conv form.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restrict__ ws, int splitk, int B, int Hin, int Win, int kh, int kw,
-                                                            int Cout, const float* __restrict__ bias, int relu, float* __restrict__ y, int ldy) {
-    const int Hout = Hin + kh - 1, Wout = Win + kw - 1, C4 = Cout >> 2;
+__global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restrict__ ws, int splitk, const DeconvGather g) {
+    const int Hout = g.Hin * g.sh + g.kh - g.sh, Wout = g.Win * g.sw + g.kw - g.sw, C4 = g.Cout >> 2;
+    const int rows = g.y1 - g.y0;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * Hout * Wout * C4) return;
-    const int c4 = (int)(idx % C4);
-    const long pix = idx / C4;
-    const int xo = (int)(pix % Wout), yo = (int)((pix / Wout) % Hout), b = (int)(pix / ((long)Wout * Hout));
-    const long M = (long)B * Hin * Win, N = (long)kh * kw * Cout;
-    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < kh; ++p) {
-        const int yi = yo - p;
-        if ((unsigned)yi >= (unsigned)Hin) continue;
-        for (int q = 0; q < kw; ++q) {
-            const int xi = xo - q;
-            if ((unsigned)xi >= (unsigned)Win) continue;
-            const float* t = ws + (((long)b * Hin + yi) * Win + xi) * N + (long)(p * kw + q) * Cout + 4 * c4;
-            for (int z = 0; z < splitk; ++z, t += M * N) {
-                const float4 v = *reinterpret_cast<const float4*>(t);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    float amax = 0.f;
+    if (idx < (long)g.B * rows * Wout * C4) {
+        const int c4 = (int)(idx % C4);
+        const long pix = idx / C4;
+        const int xo = (int)(pix % Wout), yo = g.y0 + (int)((pix / Wout) % rows), b = (int)(pix / ((long)Wout * rows));
+        const long M = (long)g.B * g.R * g.Win, N = (long)g.kh * g.kw * g.Cout;
+        float4 acc = g.bias ? *reinterpret_cast<const float4*>(g.bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // taps (p, q) with (yo - p, xo - q) divisible by the strides and inside the band / the row: dense ranges, no test in the loops
+        const int y_in0 = g.in_row0 * g.sh, y_in1 = (g.in_row0 + g.R - 1) * g.sh;       // yo - p must lie in [y_in0, y_in1]
+        int p_lo = yo % g.sh, p_hi = min(g.kh - 1, yo - y_in0);
+        if (yo - p_lo > y_in1) p_lo += (yo - p_lo - y_in1 + g.sh - 1) / g.sh * g.sh;
+        int q_lo = xo % g.sw, q_hi = min(g.kw - 1, xo);
+        const int x_in1 = (g.Win - 1) * g.sw;
+        if (xo - q_lo > x_in1) q_lo += (xo - q_lo - x_in1 + g.sw - 1) / g.sw * g.sw;
+        const long zstride = M * N;
+        for (int p = p_lo; p <= p_hi; p += g.sh) {
+            const int yi = (yo - p) / g.sh - g.in_row0;
+            const float* trow = ws + ((long)b * g.R + yi) * g.Win * N + (long)p * g.kw * g.Cout + 4 * c4;
+#pragma unroll 2
+            for (int q = q_lo; q <= q_hi; q += g.sw) {
+                const float* t = trow + (long)((xo - q) / g.sw) * N + (long)q * g.Cout;
+                for (int z = 0; z < splitk; ++z, t += zstride) {
+                    const float4 v = *reinterpret_cast<const float4*>(t);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
             }
         }
+        if (g.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4*>(g.y + (((long)b * Hout + yo) * Wout + xo) * g.ldy + 4 * c4) = acc;
+        amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
     }
-    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    *reinterpret_cast<float4*>(y + pix * ldy + 4 * c4) = acc;
+    if (g.amax_out != nullptr) igemm_publish_amax(g.amax_out, amax);
 }
 
-int deconv_gather_launch(const float* ws, int splitk, int B, int Hin, int Win, int kh, int kw, int Cout, const float* bias, int relu,
-                         float* y, int ldy, hipStream_t s) {
-    if (!ws || !y) return fail(SAGEN_ERR_NULL, "deconv_gather: null argument");
-    if (Cout % 4 || ldy % 4 || ((uintptr_t)y % 16) || (bias && ((uintptr_t)bias % 16)))
+int deconv_gather_launch(const float* ws, int splitk, const DeconvGather& g, hipStream_t s) {
+    if (!ws || !g.y) return fail(SAGEN_ERR_NULL, "deconv_gather: null argument");
+    if (g.Cout % 4 || g.ldy % 4 || ((uintptr_t)g.y % 16) || (g.bias && ((uintptr_t)g.bias % 16)))
         return fail(SAGEN_ERR_UNSUPPORTED, "deconv_gather: Cout / ldy must be multiples of 4 and the pointers 16-byte aligned");
-    const long total = (long)B * (Hin + kh - 1) * (Win + kw - 1) * (Cout / 4);
-    hipLaunchKernelGGL(deconv_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, ws, splitk, B, Hin, Win, kh, kw, Cout, bias, relu, y, ldy);
+    const int Hout = g.Hin * g.sh + g.kh - g.sh;
+    if (g.y0 < 0 || g.y1 > Hout || g.y1 <= g.y0 || g.in_row0 < 0 || g.R <= 0 || g.in_row0 + g.R > g.Hin)
+        return fail(SAGEN_ERR_SHAPE, "deconv_gather: rows [%d, %d) of %d / input band [%d, +%d) of %d", g.y0, g.y1, Hout, g.in_row0, g.R, g.Hin);
+    const long total = (long)g.B * (g.y1 - g.y0) * (g.Win * g.sw + g.kw - g.sw) * (g.Cout / 4);
+    hipLaunchKernelGGL(deconv_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, ws, splitk, g);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -25,6 +25,10 @@ struct BnRef {
     float eps = 1e-3f;
 };
 
+// an IgemmDesc::amax_out target: H2_AMAX_SLOTS words, one per 128-byte line (atomics to ONE line serialise in the L2 like atomics to
+// one word: with the 64 words adjacent the spectrogram conv still took 31 us instead of 18)
+constexpr int H2_AMAX_SLOTS = 64, H2_AMAX_STRIDE = 32, H2_AMAX_FLOATS = H2_AMAX_SLOTS * H2_AMAX_STRIDE;
+
 struct IgemmDesc {
     const float* x = nullptr;         // input, channel offset already applied
     const float* w = nullptr;         // packed filter [N][Kpad], k contiguous, zero padded
@@ -35,8 +39,9 @@ struct IgemmDesc {
     const float* in_shift = nullptr;
     BnRef bn_in;                      // alternative to in_scale/in_shift: derive them in-kernel (Cin <= 512)
     double* stats = nullptr;          // fp64 accumulators [2][N] of (sum, sumsq) of the raw output (atomics), or null
-    // exact max |y| over everything this launch stores (after bias / ReLU), atomicMax of the bit pattern into a zeroed word, or null:
-    // the scale of the fp16x2 planes a consumer's pack pass makes of the tensor (h2_pack_rows_launch) - exact, so nothing can saturate
+    // exact max |y| over everything this launch stores (after bias / ReLU): atomicMax of the bit pattern into H2_AMAX_SLOTS zeroed words
+    // (the maximum over the slots is the tensor's), or null - the scale of the fp16x2 planes a consumer's pack pass makes of the tensor
+    // (h2_pack_rows_launch): exact, so nothing can saturate
     float* amax_out = nullptr;
     float* splitk_ws = nullptr;       // [splitk][M][N] when splitk > 1
     // in-launch combine of the split-K partials (igemm_common.h: igemm_epilogue): one ticket per output tile, zero between launches;
@@ -163,8 +168,18 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
 
 // stride-1 conv2d_transpose in scatter form (igemm.hip): gathers act(bias + sum_z sum_taps T_z[(b, y'-p, x'-q)][(p, q, o)]) from the
 // partials ws[splitk][B*Hin*Win][kh*kw*Cout] of the GEMM over the INPUT pixels into y[b, y', x', o] (pixel stride ldy)
-int deconv_gather_launch(const float* ws, int splitk, int B, int Hin, int Win, int kh, int kw, int Cout, const float* bias, int relu,
-                         float* y, int ldy, hipStream_t s);
+// Strided transposed convs the same way (out[b, y*sh+p, x*sw+q, o]); a band of input rows [in_row0, in_row0 + R) contracted
+// (M = B*R*Win), output rows [y0, y1) written (the live rows of the mask decoder); amax_out: IgemmDesc::amax_out of what is written.
+struct DeconvGather {
+    int B = 0, Hin = 0, Win = 0, kh = 1, kw = 1, sh = 1, sw = 1, Cout = 0;
+    int in_row0 = 0, R = 0;           // the GEMM's rows: input rows [in_row0, in_row0 + R) of every image
+    int y0 = 0, y1 = 0;               // output rows written
+    int relu = 0, ldy = 0;
+    const float* bias = nullptr;
+    float* y = nullptr;               // [B][Hout][Wout][ldy]
+    float* amax_out = nullptr;
+};
+int deconv_gather_launch(const float* ws, int splitk, const DeconvGather& g, hipStream_t s);
 
 // filter repacking (pack.hip).  All produce [Npad][Kpad] with zero padding.
 // conv  : Wp[n][(tap, c)] = W_hwio[tap][c][n],  c < cin_src (cin_pad >= cin_src).  With tw_pad > tw_src > 0 the packed
@@ -253,8 +268,8 @@ int p3_pack_launch(const float* x, const float* scale, const float* shift, const
                    float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);
 size_t p3h_bytes(int B, int H, int W, int C);
 // rows [row0, row0 + R) of every image of an fp32 NHWC tensor (pixel stride ldx, row stride x_rstride, image stride x_bstride, all in
-// floats) -> fp16x2 planes [C/16][B*R*(W+1)][2][16] of v * 2^ka with ka from the EXACT maximum max(amax0[0], amax1[0]) the producers'
-// epilogues published (IgemmDesc::amax_out; amax1 nullable): nothing can saturate.  2^-ka -> a_inv[0].
+// floats) -> fp16x2 planes [C/16][B*R*(W+1)][2][16] of v * 2^ka with ka from the EXACT maximum the producers' epilogues published
+// (IgemmDesc::amax_out: H2_AMAX_SLOTS words each; amax1 nullable): nothing can saturate.  2^-ka -> a_inv[0].
 int h2_pack_rows_launch(const float* x, long x_bstride, long x_rstride, int ldx, int row0, int B, int R, int W, int C, const float* amax0,
                         const float* amax1, void* planes, float* a_inv, unsigned* sat_count, hipStream_t s);
 // 3x3/2 SAME max-pool of relu(bn(x)) -> fp32 NHWC `y` (or null) and planes `p3` (or null) of the pooled tensor

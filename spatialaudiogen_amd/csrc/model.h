@@ -470,23 +470,26 @@ struct Fwd {
         gemm(d);
     }
 
-    // stride-1 tfw.deconv_2d in scatter form (igemm.hip: deconv_gather_kernel): one GEMM over the INPUT pixels against the filter as
-    // [(p, q, o)][c] ("pks:" pack), gathered (+ bias, ReLU) into y by the pass that also sums the split-K partials
-    void deconv_scatter(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu) {
+    // tfw.deconv_2d in scatter form (igemm.hip: deconv_gather_kernel): one GEMM over the INPUT pixels of the band of rows
+    // [in_row0, in_row0 + R) against the filter as [(p, q, o)][c] ("pks:" pack); output rows [y0, y1) are gathered (+ bias, ReLU) into
+    // y by the pass that also sums the split-K partials
+    void deconv_scatter(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int in_row0, int R, int y0, int y1,
+                        float* amax_out = nullptr) {
         const std::string name = "separation/deconv" + std::to_string(l + 1);
         layer = name;
-        const int kh = AENC_K[l][0], kw = AENC_K[l][1];
-        const int Cout = l == 0 ? c->nsep : AENC_F[l - 1];
-        IgemmDesc d;
-        d.x = x; d.w = c->p("pks:" + name + "/weights");
-        d.M = c->B * Hin * Win; d.N = kh * kw * Cout; d.K = Cin; d.Kpad = Cin;
-        d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = Cin; d.ldx = Cin; d.x_bstride = Cin;
-        d.ntaps = 1; d.Cout = d.N; d.Hlim = 1; d.Wlim = 1; d.ldy = d.N; d.y_rstride = d.N; d.y_bstride = d.N;
+        DeconvGather gd;
+        gd.B = c->B; gd.Hin = Hin; gd.Win = Win; gd.kh = AENC_K[l][0]; gd.kw = AENC_K[l][1]; gd.sh = AENC_S[l][0]; gd.sw = AENC_S[l][1];
+        gd.Cout = l == 0 ? c->nsep : AENC_F[l - 1];
+        gd.in_row0 = in_row0; gd.R = R; gd.y0 = y0; gd.y1 = y1; gd.relu = relu ? 1 : 0; gd.ldy = ldy;
+        gd.bias = c->v(name + "/biases"); gd.y = y; gd.amax_out = amax_out;
+        IgemmDesc d;                           // a one-tap "conv" over the band: rows m = (b, row, column), dense partials [M][N]
+        d.x = x + (long)in_row0 * Win * Cin; d.w = c->p("pks:" + name + "/weights");
+        d.M = c->B * R * Win; d.N = gd.kh * gd.kw * gd.Cout; d.K = Cin; d.Kpad = Cin;
+        d.Hg = R; d.Wg = Win; d.Hin = Hin - in_row0; d.Win = Win; d.Cin = Cin; d.ldx = Cin; d.x_bstride = (long)Hin * Win * Cin;
+        d.ntaps = 1; d.Cout = d.N; d.Hlim = R; d.Wlim = Win; d.ldy = d.N; d.y_rstride = (long)Win * d.N; d.y_bstride = (long)R * Win * d.N;
         d.y = c->ws + c->bufs.at(wsname).off;            // (never written: the contraction leaves partials only)
-        const float* bias = c->v(name + "/biases");
-        const int B = c->B;
         custom_reduce_name = "deconv_gather_kernel";
-        custom_reduce = [=](const float* ws, int sk, hipStream_t st) { return deconv_gather_launch(ws, sk, B, Hin, Win, kh, kw, Cout, bias, relu ? 1 : 0, y, ldy, st); };
+        custom_reduce = [gd](const float* ws, int sk, hipStream_t st) { return deconv_gather_launch(ws, sk, gd, st); };
         gemm(d);
         custom_reduce = nullptr;
     }

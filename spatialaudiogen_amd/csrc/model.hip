@@ -134,9 +134,9 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
             n = packed_floats(vs.shape[1], vs.shape[0]);
         }
         c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
-        if (vs.name.find("/deconv") != std::string::npos) {     // stride-1 transposed convs also in scatter form: [(p, q, o)][c] (Fwd::deconv_scatter)
+        if (vs.name.find("/deconv") != std::string::npos) {     // deconv5 .. deconv2 also in scatter form: [(p, q, o)][c] (Fwd::deconv_scatter)
             const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
-            if (AENC_S[l][0] * AENC_S[l][1] == 1 && vs.shape[3] % 16 == 0)
+            if (l >= 1 && vs.shape[3] % 16 == 0)
                 c->alloc("pks:" + vs.name, packed_split_floats(packed_floats((long)vs.shape[0] * vs.shape[1] * vs.shape[2], vs.shape[3])));
         }
         // the 3x3 convs (and 1x1 projections) of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
@@ -164,10 +164,10 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->alloc("coeffs", (size_t)B * 3 * 3 * (c->nsep + 1));
     c->alloc("splitk", std::max<size_t>((size_t)16 << 20, (size_t)B * 56 * 112 * 64 * 2));   // fp32 split-K partials (up to 2 splits of the largest conv), checked per use
     if (c->freq_mask) {
-        // rows 10..16 of cat1 as fp16x2 planes (the operand of deconv1 on conv3g_kernel) + the words around them: [0], [1] = exact max |y|
-        // of cat1's encoder / decoder half (published by the epilogues of conv1 / deconv2), [8] = 2^-ka of the planes
+        // rows 10..16 of cat1 as fp16x2 planes (the operand of deconv1 on conv3g_kernel) + the words around them: H2_AMAX_FLOATS floats (H2_AMAX_SLOTS lines) each for the exact
+        // max |y| of cat1's encoder / decoder half (published by the epilogues of conv1 / deconv2's gather), then 2^-ka of the planes
         c->alloc("cat1p", (p3h_bytes(B, 7, c->enc_w[1], 2 * c->enc_c[1]) + 3) / 4 + 64);
-        c->alloc("amax", 16);
+        c->alloc("amax", 2 * H2_AMAX_FLOATS + 64);
         c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
         c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
     }
@@ -411,7 +411,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         if (it != c->plan.end() && it->second.tile != (int)TILE_P3GH_MM_64x128_K2 && it->second.tile != (int)TILE_P3GH_MM_64x128_K4) d1_planes = false;
     }
     float* const amax = c->freq_mask ? c->p("amax") : nullptr;
-    if (d1_planes) SAGEN_HIP_CHECK(hipMemsetAsync(amax, 0, 16 * sizeof(float), g.s));
+    if (d1_planes) SAGEN_HIP_CHECK(hipMemsetAsync(amax, 0, (2 * H2_AMAX_FLOATS + 64) * sizeof(float), g.s));
 
     // ---- stream g: STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
     g.layer = "stft";
@@ -520,38 +520,34 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
 
     // separation (model.py:282-348)
     f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6);     // tile over 6 freq columns
-    // Only rows 10..16 of cat1 reach deconv1's live grid rows (11..16, two vertical taps), hence - at inference - only output rows
-    // 10..16 of deconv2, whose grid rows 5..8 read rows 4..8 of cat2, hence only those of deconv3 (grid rows 2..4): the strided
-    // transposed convs run on the live part of their grid (4 of 16 and 3 of 8 grid rows).  The stride-1 ones (deconv5, deconv4) run in
-    // scatter form instead (every input pixel contracted once: Fwd::deconv_scatter).  The training step keeps the full tensors.
-    static const bool no_prune = getenv("SAGEN_NO_DECONV_PRUNE") != nullptr, no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
-    const bool lean = !c->train_mode && !c->fp32_only;
-    int need_lo[6], need_hi[6];                          // rows of cat_l the decoder below it reads
+    // Inference runs deconv5 .. deconv2 in SCATTER form (Fwd::deconv_scatter): every input pixel is contracted once against the whole
+    // filter and a gather pass assembles the output - the conv form over the output grid multiplies padding for most taps of the
+    // stride-1 layers (5.4 of 15 taps of deconv5 land inside its 3x6 input), and the strided layers' depth-to-space form cannot split K.
+    // Only rows 10..16 of cat1 reach deconv1's live grid rows (11..16, two vertical taps), hence only rows 4..8 of cat2 (deconv2's
+    // taps) and rows 1..4 of cat3: each layer contracts the band of input rows it needs and gathers the output rows that are read.
+    // The training step (and SAGEN_FP32_ONLY) keep the round-4 form on the full tensors.
+    static const bool no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
+    const bool lean = !c->train_mode && !c->fp32_only && !no_scatter;
+    int need_lo[7], need_hi[7];                          // rows of cat_l that the layer below reads
     for (int l = 1; l <= 5; ++l) { need_lo[l] = 0; need_hi[l] = c->enc_h[l]; }
-    if (lean && !no_prune) {
+    if (lean) {
         need_lo[1] = 10; need_hi[1] = 17;
-        for (int l = 1; l <= 2; ++l) {                   // deconv(l+1) writes cat_l; both are strided (2x4, 2x2)
-            const int sh = AENC_S[l][0], nth = cdiv(AENC_K[l][0], sh);
-            const int a0 = need_lo[l] / sh, a1 = (need_hi[l] - 1) / sh + 1;
-            need_lo[l + 1] = std::max(a0 - (nth - 1), 0);
-            need_hi[l + 1] = std::min(a1, c->enc_h[l + 1]);
+        for (int l = 1; l <= 4; ++l) {                   // deconv(l+1) writes rows [need_lo[l], need_hi[l]) of cat_l from these rows of cat_(l+1)
+            const int sh = AENC_S[l][0], kh = AENC_K[l][0];
+            need_lo[l + 1] = std::max((need_lo[l] - (kh - 1) + sh - 1) / sh, 0);            // smallest y with y*sh + kh - 1 >= need_lo
+            need_hi[l + 1] = std::min((need_hi[l] - 1) / sh + 1, c->enc_h[l + 1]);           // largest y with y*sh <= need_hi - 1
         }
     }
     for (int l = 4; l >= 1; --l) {
         const int Cin = 2 * c->enc_c[l + 1];
-        const bool strided = AENC_S[l][0] * AENC_S[l][1] > 1;
-        if (!strided && lean && !no_scatter && c->bufs.count("pks:separation/deconv" + std::to_string(l + 1) + "/weights")) {
+        float* const am = (l == 1 && d1_planes) ? amax + H2_AMAX_FLOATS : nullptr;
+        if (lean && c->bufs.count("pks:separation/deconv" + std::to_string(l + 1) + "/weights")) {
             f.deconv_scatter(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
-                             2 * c->enc_c[l], true);
+                             2 * c->enc_c[l], true, need_lo[l + 1], need_hi[l + 1] - need_lo[l + 1], need_lo[l], need_hi[l], am);
             continue;
         }
-        int a0 = 0, a1 = 0, ylim = 0;
-        if (strided && (need_lo[l] > 0 || need_hi[l] < c->enc_h[l])) {
-            a0 = need_lo[l] / AENC_S[l][0]; a1 = (need_hi[l] - 1) / AENC_S[l][0] + 1; ylim = need_hi[l];
-        }
-        float* const am = (l == 1 && d1_planes) ? amax + 1 : nullptr;
         f.deconv(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
-                 2 * c->enc_c[l], true, a0, a1, ylim, 0, 0, nullptr, nullptr, 0, [am](IgemmDesc& d) { d.amax_out = am; });
+                 2 * c->enc_c[l], true, 0, 0, 0, 0, 0, nullptr, nullptr, 0, [am](IgemmDesc& d) { d.amax_out = am; });
     }
     // deconv1: only output rows 44..66 (mask frames 1..23) reach the cropped window -> grid rows a = 11..16.
     // Inference: sigmoid and the track-weighted sums run in its epilogue (igemm_epilogue_maskmix) and the 94 MB of logits are never
@@ -570,12 +566,12 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         const int W1 = c->enc_w[1], C1 = 2 * c->enc_c[1];
         f.layer = "separation/cat1-planes";
         f.timed("h2_pack_rows_kernel", 0.0, [&] {
-            return h2_pack_rows_launch(c->p("cat1"), (long)c->enc_h[1] * W1 * C1, (long)W1 * C1, C1, 10, B, 7, W1, C1, amax + 0, amax + 1, c->p("cat1p"),
-                                       amax + 8, reinterpret_cast<unsigned*>(c->p("h2s") + 7), s); });
+            return h2_pack_rows_launch(c->p("cat1"), (long)c->enc_h[1] * W1 * C1, (long)W1 * C1, C1, 10, B, 7, W1, C1, amax, amax + H2_AMAX_FLOATS, c->p("cat1p"),
+                                       amax + 2 * H2_AMAX_FLOATS, reinterpret_cast<unsigned*>(c->p("h2s") + 7), s); });
         const float* w_inv = c->p("h2s") + c->h2_slot.at("separation/deconv1");
         const void* planes = c->p("cat1p");
         const void* wh2 = c->p("pkh:separation/deconv1/weights");
-        const float* a_inv = amax + 8;
+        const float* a_inv = amax + 2 * H2_AMAX_FLOATS;
         d1_tweak = [=](IgemmDesc& d) {
             d.xp3 = planes; d.xp3_fmt = 1; d.xp3_row0 = 10; d.xp3_rows = 7;
             d.p3_np = B * 7 * (W1 + 1);

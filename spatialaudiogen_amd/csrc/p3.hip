@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void h2_pack_rows_kernel(const float* __restri
     const int C8 = C >> 3;
     const long NP = (long)B * R * (W + 1);
     const long total = NP * C8;
-    const float bound = fmaxf(amax0[0], amax1 ? amax1[0] : 0.f);
+    // the producers' maxima: H2_AMAX_SLOTS words each (one lane per slot; every wave folds them itself)
+    float bound = amax0[H2_AMAX_STRIDE * (threadIdx.x & (H2_AMAX_SLOTS - 1))];
+    if (amax1) bound = fmaxf(bound, amax1[H2_AMAX_STRIDE * (threadIdx.x & (H2_AMAX_SLOTS - 1))]);
+    bound = wave_max_f(bound);
     const float sa = h2_scale_of_bound(bound);               // bound * sa in [512, 1024): an exact bound, nothing saturates
     if (blockIdx.x == 0 && threadIdx.x == 0) a_inv[0] = 1.f / sa;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
