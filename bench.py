@@ -636,11 +636,15 @@ def main():
     except Exception:
         pass
     step_tflops = cfg['gflop'] * BATCH / (ms_per_step * 1e-3) / 1e3          # throughput-based (steps overlap when NF > 1)
-    h2 = dom.startswith('conv3h') or dom.startswith('stem8pool')   # three matrix products per fp32 multiply (fp16x2 planes / the exact uint8 plane)
-    b3 = dom.startswith('igemm3') or dom.startswith('conv3p') or dom.startswith('conv3g')   # the six-product bf16x3 family
+    def is_h2(k):        # three matrix products per fp32 multiply: fp16x2 planes (conv3h, conv3g<..., true, ...>) / the exact uint8 plane
+        return k.startswith('conv3h') or k.startswith('stem8pool') or (k.startswith('conv3g') and ',true' in k)
+
+    def is_b3(k):        # the six-product bf16x3 family
+        return k.startswith('igemm3') or k.startswith('conv3p') or (k.startswith('conv3g') and ',true' not in k)
+    h2, b3 = is_h2(dom), is_b3(dom)
     peak = PEAK_FP16X2_TFLOPS if h2 else (PEAK_BF16X3_TFLOPS if b3 else PEAK_FP32_MFMA_TFLOPS)
-    b3_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm3') or k.startswith('conv3p') or k.startswith('conv3g'))
-    h2_us = sum(a[1] for k, a in agg.items() if k.startswith('conv3h') or k.startswith('stem8pool'))
+    b3_us = sum(a[1] for k, a in agg.items() if is_b3(k))
+    h2_us = sum(a[1] for k, a in agg.items() if is_h2(k))
     f32_us = sum(a[1] for k, a in agg.items() if k.startswith('igemm_kernel'))
     roofline = {
         'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': round(peak, 1),

@@ -340,7 +340,7 @@ bool conv3g_ok(const IgemmDesc& d) {
     if (d.mm_out != nullptr) {       // the fused decoder tail: a depth-to-space tile of 64 grid columns x (4 pixels x 32 tracks) = one mask frame of one window
         if (d.xp3_fmt != 1 || d.Cout != 32 || d.dsh * d.dsw <= 1 || d.Wg % 64 || (d.dsw * d.Cout) % 128 || d.splitk != 1 || !d.mm_coeffs) return false;
     } else {
-        if (d.dsh * d.dsw != 1 || d.g_h0 != 0 || d.g_w0 != 0 || d.xp3_row0 != 0 || d.xp3_rows != 0) return false;
+        if (d.dsh * d.dsw != 1 || d.g_h0 != 0 || d.g_w0 != 0) return false;
         if (d.y_rstride != (long)d.Wg * d.ldy || (d.M > d.Hg * d.Wg && d.y_bstride != (long)d.Hg * d.Wg * d.ldy)) return false;
     }
     // horizontal reach of the taps over the whole grid: the pad pixel closing every plane row is column -1 and column Win

@@ -513,10 +513,13 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
 template <int V>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
                                                             const float* __restrict__ bias, int relu,
-                                                            float* __restrict__ y, int ldy, int rep) {
+                                                            float* __restrict__ y, int ldy, int rep, float* __restrict__ amax_out) {
     const int NV = N / V;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)M * NV) return;
+    if (idx >= (long)M * NV) {
+        if (amax_out != nullptr) igemm_publish_amax(amax_out, 0.f);     // (wave-wide: every lane takes part)
+        return;
+    }
     const int m = (int)(idx / NV), n = (int)(idx - (long)m * NV) * V;
     float v[V];
 #pragma unroll
@@ -549,6 +552,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
         else o[0] = v[0];
     }
+    if (amax_out != nullptr) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) a = fmaxf(a, fabsf(v[i]));
+        igemm_publish_amax(amax_out, a);
+    }
 }
 
 // The same for FEW outputs and MANY partials (weight gradients of small layers: 28 KB of gradient from 256 pixel ranges took 27 us
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // (four loads in flight), combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void splitk_reduce_sliced_kernel(const float* __restrict__ ws, int splitk, int M, int N,
                                                                    const float* __restrict__ bias, int relu,
-                                                                   float* __restrict__ y, int ldy, int rep) {
+                                                                   float* __restrict__ y, int ldy, int rep, float* __restrict__ amax_out) {
     __shared__ float4 red[8][32];
     const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int NV = N / 4;
@@ -588,6 +597,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_sliced_kernel(const float* 
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         for (int r = 0; r < rep; ++r) *reinterpret_cast<float4*>(y + ((long)m * rep + r) * ldy + n) = v;
     }
+    if (amax_out != nullptr)
+        igemm_publish_amax(amax_out, (sl == 0 && ok) ? fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) : 0.f);
 }
 
 // Same sum, plus the per-channel (sum, sumsq) of the raw sums over each block of SPLITK_RB rows
@@ -642,8 +653,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 }
 
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
-                         float* y, int ldy, int rep, double* stats, hipStream_t s) {
+                         float* y, int ldy, int rep, double* stats, hipStream_t s, float* amax_out) {
     if (stats) {
+        if (amax_out) return fail(SAGEN_ERR_UNSUPPORTED, "split-K reduce: statistics and amax_out together");
         if (N % 4 || ldy % 4 || rep != 1 || bias || relu)
             return fail(SAGEN_ERR_UNSUPPORTED, "split-K reduce with statistics needs N %% 4 == 0 and a plain epilogue");
         const int CN4 = N >= 256 ? 64 : (N >= 128 ? 32 : 16);         // 256 / 128 / 64 columns per workgroup
@@ -656,13 +668,13 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
     } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && splitk >= 16 &&
                (long)M * (N / 4) <= 65536) {
         hipLaunchKernelGGL(splitk_reduce_sliced_kernel, dim3(cdiv((long)M * (N / 4), 32)), dim3(256), 0, s, ws, splitk, M, N, bias,
-                           relu, y, ldy, rep);
+                           relu, y, ldy, rep, amax_out);
     } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0)) {
         hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, s, ws, splitk, M, N, bias,
-                           relu, y, ldy, rep);
+                           relu, y, ldy, rep, amax_out);
     } else {
         hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv((long)M * N, 256)), dim3(256), 0, s, ws, splitk, M, N, bias, relu,
-                           y, ldy, rep);
+                           y, ldy, rep, amax_out);
     }
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
@@ -677,6 +689,10 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
 // and this pass gathers out[b, y', x', o] = act(bias[o] + sum_z sum_{p, q valid} T_z[(b, y'-p, x'-q)][(p, q, o)]) in a fixed order -
 // it IS the split-K reducer of that GEMM.  36 % / 51 % of the matrix work and of the filter streaming of the conv form.
 // -----------------------------------------------------------------------------------------
+// PT x QT = the most taps per dimension that can reach one output pixel (ceil(kh / sh) x ceil(kw / sw)): the loops are fully unrolled
+// and every load is issued before the first add - with run-time loops each thread walked its 5..15 taps one memory round trip at
+// a time (12 us for the 9 MB of deconv5's partials)
+template <int PT, int QT>
 __global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restrict__ ws, int splitk, const DeconvGather g) {
     const int Hout = g.Hin * g.sh + g.kh - g.sh, Wout = g.Win * g.sw + g.kw - g.sw, C4 = g.Cout >> 2;
     const int rows = g.y1 - g.y0;
@@ -688,25 +704,37 @@ __global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restr
         const int xo = (int)(pix % Wout), yo = g.y0 + (int)((pix / Wout) % rows), b = (int)(pix / ((long)Wout * rows));
         const long M = (long)g.B * g.R * g.Win, N = (long)g.kh * g.kw * g.Cout;
         float4 acc = g.bias ? *reinterpret_cast<const float4*>(g.bias + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        // taps (p, q) with (yo - p, xo - q) divisible by the strides and inside the band / the row: dense ranges, no test in the loops
+        // taps (p, q) with (yo - p, xo - q) divisible by the strides and inside the band / the row: p = p_lo + i*sh <= p_hi, q alike
         const int y_in0 = g.in_row0 * g.sh, y_in1 = (g.in_row0 + g.R - 1) * g.sh;       // yo - p must lie in [y_in0, y_in1]
-        int p_lo = yo % g.sh, p_hi = min(g.kh - 1, yo - y_in0);
+        int p_lo = yo % g.sh;
+        const int p_hi = min(g.kh - 1, yo - y_in0);
         if (yo - p_lo > y_in1) p_lo += (yo - p_lo - y_in1 + g.sh - 1) / g.sh * g.sh;
-        int q_lo = xo % g.sw, q_hi = min(g.kw - 1, xo);
+        int q_lo = xo % g.sw;
+        const int q_hi = min(g.kw - 1, xo);
         const int x_in1 = (g.Win - 1) * g.sw;
         if (xo - q_lo > x_in1) q_lo += (xo - q_lo - x_in1 + g.sw - 1) / g.sw * g.sw;
         const long zstride = M * N;
-        for (int p = p_lo; p <= p_hi; p += g.sh) {
-            const int yi = (yo - p) / g.sh - g.in_row0;
-            const float* trow = ws + ((long)b * g.R + yi) * g.Win * N + (long)p * g.kw * g.Cout + 4 * c4;
-#pragma unroll 2
-            for (int q = q_lo; q <= q_hi; q += g.sw) {
-                const float* t = trow + (long)((xo - q) / g.sw) * N + (long)q * g.Cout;
-                for (int z = 0; z < splitk; ++z, t += zstride) {
-                    const float4 v = *reinterpret_cast<const float4*>(t);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        const float* const base = ws + 4 * c4;
+        for (int z = 0; z < splitk; ++z) {
+            float4 v[PT][QT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const int p = p_lo + i * g.sh;
+                const bool pok = p <= p_hi;
+                const int yi = pok ? (yo - p) / g.sh - g.in_row0 : 0;
+#pragma unroll
+                for (int j = 0; j < QT; ++j) {
+                    const int q = q_lo + j * g.sw;
+                    const bool ok = pok && q <= q_hi;
+                    const int xi = ok ? (xo - q) / g.sw : 0;
+                    const float* t = base + z * zstride + (((long)b * g.R + yi) * g.Win + xi) * N + (long)((ok ? p : 0) * g.kw + (ok ? q : 0)) * g.Cout;
+                    v[i][j] = ok ? *reinterpret_cast<const float4*>(t) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int j = 0; j < QT; ++j) { acc.x += v[i][j].x; acc.y += v[i][j].y; acc.z += v[i][j].z; acc.w += v[i][j].w; }
         }
         if (g.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
         *reinterpret_cast<float4*>(g.y + (((long)b * Hout + yo) * Wout + xo) * g.ldy + 4 * c4) = acc;
@@ -723,7 +751,12 @@ int deconv_gather_launch(const float* ws, int splitk, const DeconvGather& g, hip
     if (g.y0 < 0 || g.y1 > Hout || g.y1 <= g.y0 || g.in_row0 < 0 || g.R <= 0 || g.in_row0 + g.R > g.Hin)
         return fail(SAGEN_ERR_SHAPE, "deconv_gather: rows [%d, %d) of %d / input band [%d, +%d) of %d", g.y0, g.y1, Hout, g.in_row0, g.R, g.Hin);
     const long total = (long)g.B * (g.y1 - g.y0) * (g.Win * g.sw + g.kw - g.sw) * (g.Cout / 4);
-    hipLaunchKernelGGL(deconv_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, ws, splitk, g);
+    const int pt = cdiv(g.kh, g.sh), qt = cdiv(g.kw, g.sw);
+    const dim3 grid(cdiv(total, 256));
+    if (pt <= 2 && qt <= 2) hipLaunchKernelGGL((deconv_gather_kernel<2, 2>), grid, dim3(256), 0, s, ws, splitk, g);
+    else if (pt <= 2 && qt <= 3) hipLaunchKernelGGL((deconv_gather_kernel<2, 3>), grid, dim3(256), 0, s, ws, splitk, g);
+    else if (pt <= 3 && qt <= 5) hipLaunchKernelGGL((deconv_gather_kernel<3, 5>), grid, dim3(256), 0, s, ws, splitk, g);
+    else return fail(SAGEN_ERR_UNSUPPORTED, "deconv_gather: %d x %d taps per output pixel", pt, qt);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -164,7 +164,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation
 // per-channel (sum, sumsq) of the raw sums, accumulated into stats[2][N] (fp64 atomics)
 constexpr int SPLITK_RB = 16;
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
-                         float* y, int ldy, int rep, double* stats, hipStream_t s);
+                         float* y, int ldy, int rep, double* stats, hipStream_t s, float* amax_out = nullptr);      // amax_out: IgemmDesc::amax_out of what is written
 
 // stride-1 conv2d_transpose in scatter form (igemm.hip): gathers act(bias + sum_z sum_taps T_z[(b, y'-p, x'-q)][(p, q, o)]) from the
 // partials ws[splitk][B*Hin*Win][kh*kw*Cout] of the GEMM over the INPUT pixels into y[b, y', x', o] (pixel stride ldy)

@@ -274,15 +274,17 @@ struct Fwd {
             IgemmDesc e = d;
             e.splitk = sk;
             e.splitk_ws = c->ws + c->bufs.at(wsname).off;
+            e.amax_out = nullptr;                    // (partials are not the tensor: the pass that finishes them publishes the maximum)
             if (custom_reduce) {
                 e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
+                if (igemm_tile_p3(tile)) e.y = e.splitk_ws;       // the plane-fed kernels do not split K: their dense output IS partial 0
                 timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
                 timed(custom_reduce_name, 0.0, [&] { return custom_reduce(e.splitk_ws, sk, s); });
                 return 0;
             }
             // the partials are combined by the contraction itself (last-arriver, igemm_epilogue) unless statistics ride on the reducer
             const long tiles = (long)cdiv(d.M, igemm_tile_bm(tile)) * cdiv(d.N, igemm_tile_bn(tile));
-            if (c->sk_fused && sk > 1 && !d.stats && d.N % 4 == 0 && d.ldy % 4 == 0 && ((uintptr_t)d.y % 16) == 0 && (!d.bias || ((uintptr_t)d.bias % 16) == 0) &&
+            if (c->sk_fused && sk > 1 && !d.stats && !d.amax_out && d.N % 4 == 0 && d.ldy % 4 == 0 && ((uintptr_t)d.y % 16) == 0 && (!d.bias || ((uintptr_t)d.bias % 16) == 0) &&
                 tiles <= SK_TICKETS && igemm_tile_fused_splitk(tile) && c->bufs.count(wsname + ":tk")) {
                 e.sk_ticket = reinterpret_cast<int*>(c->ws + c->bufs.at(wsname + ":tk").off);
                 e.sk_rep = rep;
@@ -293,7 +295,7 @@ struct Fwd {
             e.bias = nullptr; e.relu_out = 0; e.stats = nullptr;
             timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(e, tile, s); });
             timed("splitk_reduce_kernel", 0.0, [&] {
-                return splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, d.stats, s); });
+                return splitk_reduce_launch(e.splitk_ws, sk, d.M, d.N, d.bias, d.relu_out, d.y, d.ldy, rep, d.stats, s, d.amax_out); });
             return 0;
         }
         timed(igemm_tile_name(tile), 2.0 * d.M * d.N * d.K, [&] { return igemm_launch(d, tile, s); });
@@ -432,7 +434,7 @@ struct Fwd {
     }
 
     // tfw.fully_connected (core.py:43-93) on dense rows
-    void fc(const float* x, int M, int K, int ldx, const std::string& name, int N, bool relu, float* y, int ldy, int rep = 1) {
+    void fc(const float* x, int M, int K, int ldx, const std::string& name, int N, bool relu, float* y, int ldy, int rep = 1, float* amax_out = nullptr) {
         layer = name;
         IgemmDesc d;
         d.x = x; d.w = c->p("pk:" + name + "/weights"); d.y = y; d.bias = c->v(name + "/biases");
@@ -440,6 +442,7 @@ struct Fwd {
         d.Hg = 1; d.Wg = 1; d.Hin = 1; d.Win = 1; d.Cin = K; d.ldx = ldx; d.x_bstride = ldx;
         d.ntaps = 1; d.Cout = N; d.Hlim = 1; d.Wlim = 1; d.ldy = ldy; d.y_rstride = ldy; d.y_bstride = ldy;
         d.relu_out = relu;
+        d.amax_out = amax_out;
         gemm(d, rep);
     }
 
@@ -473,8 +476,14 @@ struct Fwd {
     // tfw.deconv_2d in scatter form (igemm.hip: deconv_gather_kernel): one GEMM over the INPUT pixels of the band of rows
     // [in_row0, in_row0 + R) against the filter as [(p, q, o)][c] ("pks:" pack); output rows [y0, y1) are gathered (+ bias, ReLU) into
     // y by the pass that also sums the split-K partials
+    // exact maxima of the concat buffers' halves (IgemmDesc::amax_out targets; half 0 = decoder, 1 = encoder) and the scale of the planes
+    // packed from cat_l
+    float* cat_amax(int l, int half) { return c->p("amax") + (size_t)((l - 1) * 2 + half) * H2_AMAX_FLOATS; }
+    float* cat_a_inv(int l) { return c->p("amax") + (size_t)10 * H2_AMAX_FLOATS + l; }
+    // x_planes: contract fp16x2 planes of the band (packed here from the fp32 tensor with the exact maximum its producers published)
+    // on conv3g_kernel instead of splitting the fp32 operand inside igemm3_kernel's K loop; lx = the index of the concat buffer x is
     void deconv_scatter(const float* x, int Hin, int Win, int Cin, int l, float* y, int ldy, bool relu, int in_row0, int R, int y0, int y1,
-                        float* amax_out = nullptr) {
+                        float* amax_out = nullptr, bool x_planes = false) {
         const std::string name = "separation/deconv" + std::to_string(l + 1);
         layer = name;
         DeconvGather gd;
@@ -488,6 +497,23 @@ struct Fwd {
         d.Hg = R; d.Wg = Win; d.Hin = Hin - in_row0; d.Win = Win; d.Cin = Cin; d.ldx = Cin; d.x_bstride = (long)Hin * Win * Cin;
         d.ntaps = 1; d.Cout = d.N; d.Hlim = R; d.Wlim = Win; d.ldy = d.N; d.y_rstride = (long)Win * d.N; d.y_bstride = (long)R * Win * d.N;
         d.y = c->ws + c->bufs.at(wsname).off;            // (never written: the contraction leaves partials only)
+        if (x_planes && !c->tuning) {              // a plan that names a register-staged tile keeps the fp32 operand (no pack pass)
+            auto it = c->plan.find(name);
+            if (it != c->plan.end() && !igemm_tile_p3((IgemmTile)it->second.tile)) x_planes = false;
+        }
+        if (x_planes) {
+            const int lx = l + 1;
+            void* planes = c->p("catp");
+            timed("h2_pack_rows_kernel", 0.0, [&] {
+                return h2_pack_rows_launch(x, (long)Hin * Win * Cin, (long)Win * Cin, Cin, in_row0, c->B, R, Win, Cin, cat_amax(lx, 0), cat_amax(lx, 1), planes,
+                                           cat_a_inv(lx), reinterpret_cast<unsigned*>(c->p("h2s") + 7), s); });
+            d.xp3 = planes; d.xp3_fmt = 1; d.xp3_row0 = 0; d.xp3_rows = R;
+            d.p3_np = c->B * R * (Win + 1);
+            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+            d.xp3_bytes = (unsigned)((size_t)d.xp3_cstride * (Cin / 16));
+            d.wh2 = c->p("pkhs:" + name + "/weights"); d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+            d.h2_a_inv = cat_a_inv(lx); d.h2_w_inv = c->p("h2s") + c->h2_slot.at("pks:" + name);
+        }
         custom_reduce_name = "deconv_gather_kernel";
         custom_reduce = [gd](const float* ws, int sk, hipStream_t st) { return deconv_gather_launch(ws, sk, gd, st); };
         gemm(d);

@@ -136,8 +136,13 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         c->alloc("pk:" + vs.name, packed_split_floats(n));      // fp32 filter + its three bf16 planes (bf16x3 tiles)
         if (vs.name.find("/deconv") != std::string::npos) {     // deconv5 .. deconv2 also in scatter form: [(p, q, o)][c] (Fwd::deconv_scatter)
             const int l = vs.name[vs.name.find("/deconv") + 7] - '1';
-            if (l >= 1 && vs.shape[3] % 16 == 0)
-                c->alloc("pks:" + vs.name, packed_split_floats(packed_floats((long)vs.shape[0] * vs.shape[1] * vs.shape[2], vs.shape[3])));
+            if (l >= 1 && vs.shape[3] % 16 == 0) {
+                const size_t ns = packed_floats((long)vs.shape[0] * vs.shape[1] * vs.shape[2], vs.shape[3]);
+                c->alloc("pks:" + vs.name, packed_split_floats(ns));
+                c->alloc("pkhs:" + vs.name, ns);                   // ... and as two fp16 planes (conv3g_kernel on planes of the concat buffer)
+                h2_pack_blocks += ns / 1024 + 1;
+                c->h2_slot["pks:" + vs.name.substr(0, vs.name.size() - 8)] = -1;     // (slot numbers are dealt below)
+            }
         }
         // the 3x3 convs (and 1x1 projections) of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
         // ... and deconv1 of the mask decoder (conv3g_kernel with the fused decoder tail on planes of cat1: sagen_forward_impl)
@@ -145,9 +150,13 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
              vs.name.find("_encoder/conv") != std::string::npos) || vs.name == "separation/deconv1/weights") {
             c->alloc("pkh:" + vs.name, n);
             h2_pack_blocks += n / 1024 + 1;
-            const int slot = 8 + (int)c->h2_slot.size();
-            c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = slot;
+            c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = -1;
         }
+    }
+    {   // 2^-kw slots of the fp16x2 filter planes, h2s[8 ..]
+        int slot = 8;
+        for (auto& kv : c->h2_slot) kv.second = slot++;
+        if (slot > 2 + H2_RIG_OFF) return fail(SAGEN_ERR_UNSUPPORTED, "too many fp16x2 layers for the scale table");
     }
     c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
     c->alloc("h2:amax", c->h2_slot.size() + h2_pack_blocks + 64);      // per-job maxima + per-workgroup partials
@@ -167,7 +176,12 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         // rows 10..16 of cat1 as fp16x2 planes (the operand of deconv1 on conv3g_kernel) + the words around them: H2_AMAX_FLOATS floats (H2_AMAX_SLOTS lines) each for the exact
         // max |y| of cat1's encoder / decoder half (published by the epilogues of conv1 / deconv2's gather), then 2^-ka of the planes
         c->alloc("cat1p", (p3h_bytes(B, 7, c->enc_w[1], 2 * c->enc_c[1]) + 3) / 4 + 64);
-        c->alloc("amax", 2 * H2_AMAX_FLOATS + 64);
+        {   // planes of the band of cat_(l+1) the scatter-form deconv(l+1) contracts (one buffer: pack -> contraction, layer after layer)
+            size_t mx = 0;
+            for (int l = 2; l <= 5; ++l) mx = std::max(mx, p3h_bytes(B, c->enc_h[l], c->enc_w[l], 2 * c->enc_c[l]));
+            c->alloc("catp", (mx + 3) / 4 + 64);
+        }
+        c->alloc("amax", 10 * H2_AMAX_FLOATS + 64);       // [cat_l: l = 1..5][decoder half, encoder half][H2_AMAX_FLOATS], then 2^-ka of the planes of cat_l at [.. + l]
         c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
         c->alloc("frames", mask_istft_scratch_bytes(B) / sizeof(float));
     }
@@ -336,10 +350,20 @@ int sagen_repack_part(sagen_ctx* c, hipStream_t s, int part) {
     if (c->h2_jobs.empty()) {
         int nb = 0;
         for (const auto& kv : c->h2_slot) {
+            const bool scatter = kv.first.compare(0, 4, "pks:") == 0;       // the scatter-form pack of a transposed conv: rows (p, q, o), columns c
+            const std::string vname = (scatter ? kv.first.substr(4) : kv.first) + "/weights";
             const VarSpec* vs = nullptr;
-            for (const auto& v : c->vars) if (v.name == kv.first + "/weights") vs = &v;
+            for (const auto& v : c->vars) if (v.name == vname) vs = &v;
             if (!vs) continue;
             H2Job j;
+            if (scatter) {
+                j.N = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]); j.Kpad = (int)vs->shape[3];
+                j.wp = c->p("pks:" + vs->name); j.w2 = c->p("pkhs:" + vs->name); j.w_inv = c->p("h2s") + kv.second;
+                j.first_block = nb;
+                nb += (int)(((long)j.N * j.Kpad + 1023) / 1024);
+                c->h2_jobs.push_back(j);
+                continue;
+            }
             j.N = (int)vs->shape[3]; j.Kpad = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]);
             if (vs->name.find("/deconv") != std::string::npos) {      // depth-to-space pack: N = (ry, rx, o), K = (dp, dq, c)
                 const int l = vs->name[vs->name.find("/deconv") + 7] - '1';
@@ -404,14 +428,19 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // deconv1 on fp16x2 planes of cat1 (conv3g_kernel + fused decoder tail): the planes' scale is the EXACT maximum of cat1, published by
     // the epilogues of its two producers (conv1: encoder half, deconv2: decoder half) into words zeroed here
     static const bool no_d1p = getenv("SAGEN_NO_DECONV1_PLANES") != nullptr;
-    bool d1_planes = !no_d1p && c->freq_mask && !c->train_mode && !c->materialize_mask && !c->fp32_only && c->nsep == 32 && f.h2() &&
+    // (the opt-in in-launch split-K combine, SAGEN_SK_FUSED=1, has no reducer to publish a maximum from: it keeps the round-4 decoder)
+    bool d1_planes = !no_d1p && !c->sk_fused && c->freq_mask && !c->train_mode && !c->materialize_mask && !c->fp32_only && c->nsep == 32 && f.h2() &&
                      c->bufs.count("cat1p") != 0 && c->h2_slot.count("separation/deconv1") != 0 && getenv("SAGEN_NO_MASKFUSE") == nullptr;
     if (d1_planes && !c->tuning) {             // a plan that names a register-staged tile for deconv1 keeps the round-4 path (no pack pass)
         auto it = c->plan.find("separation/deconv1");
         if (it != c->plan.end() && it->second.tile != (int)TILE_P3GH_MM_64x128_K2 && it->second.tile != (int)TILE_P3GH_MM_64x128_K4) d1_planes = false;
     }
-    float* const amax = c->freq_mask ? c->p("amax") : nullptr;
-    if (d1_planes) SAGEN_HIP_CHECK(hipMemsetAsync(amax, 0, (2 * H2_AMAX_FLOATS + 64) * sizeof(float), g.s));
+    // ... and deconv5 .. deconv2 (scatter form) on planes of the band of cat_(l+1) they contract, the same way
+    static const bool no_decp = getenv("SAGEN_NO_DECODER_PLANES") != nullptr;
+    const bool dec_planes = !no_decp && !c->sk_fused && c->freq_mask && !c->train_mode && !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 &&
+                            getenv("SAGEN_NO_DECONV_SCATTER") == nullptr;
+    const bool want_amax = d1_planes || dec_planes;
+    if (want_amax) SAGEN_HIP_CHECK(hipMemsetAsync(c->p("amax"), 0, (10 * H2_AMAX_FLOATS + 64) * sizeof(float), g.s));
 
     // ---- stream g: STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
     g.layer = "stft";
@@ -452,7 +481,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         }
         d.bias = c->v(name + "/biases");
         d.relu_out = 1;
-        if (l == 0 && d1_planes) d.amax_out = amax + 0;
+        if (want_amax) d.amax_out = g.cat_amax(l + 1, 1);        // max |conv(l+1)| = the encoder half of cat_(l+1)
         g.layer = name;
         g.gemm(d);
     }
@@ -519,7 +548,8 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     }
 
     // separation (model.py:282-348)
-    f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6);     // tile over 6 freq columns
+    f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6,     // tile over 6 freq columns
+         want_amax ? f.cat_amax(5, 0) : nullptr);
     // Inference runs deconv5 .. deconv2 in SCATTER form (Fwd::deconv_scatter): every input pixel is contracted once against the whole
     // filter and a gather pass assembles the output - the conv form over the output grid multiplies padding for most taps of the
     // stride-1 layers (5.4 of 15 taps of deconv5 land inside its 3x6 input), and the strided layers' depth-to-space form cannot split K.
@@ -540,10 +570,10 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     }
     for (int l = 4; l >= 1; --l) {
         const int Cin = 2 * c->enc_c[l + 1];
-        float* const am = (l == 1 && d1_planes) ? amax + H2_AMAX_FLOATS : nullptr;
+        float* const am = want_amax ? f.cat_amax(l, 0) : nullptr;        // max |deconv(l+1)| = the decoder half of cat_l
         if (lean && c->bufs.count("pks:separation/deconv" + std::to_string(l + 1) + "/weights")) {
             f.deconv_scatter(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
-                             2 * c->enc_c[l], true, need_lo[l + 1], need_hi[l + 1] - need_lo[l + 1], need_lo[l], need_hi[l], am);
+                             2 * c->enc_c[l], true, need_lo[l + 1], need_hi[l + 1] - need_lo[l + 1], need_lo[l], need_hi[l], am, dec_planes);
             continue;
         }
         f.deconv(c->p("cat" + std::to_string(l + 1)), c->enc_h[l + 1], c->enc_w[l + 1], Cin, l, c->p("cat" + std::to_string(l)),
@@ -566,12 +596,12 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         const int W1 = c->enc_w[1], C1 = 2 * c->enc_c[1];
         f.layer = "separation/cat1-planes";
         f.timed("h2_pack_rows_kernel", 0.0, [&] {
-            return h2_pack_rows_launch(c->p("cat1"), (long)c->enc_h[1] * W1 * C1, (long)W1 * C1, C1, 10, B, 7, W1, C1, amax, amax + H2_AMAX_FLOATS, c->p("cat1p"),
-                                       amax + 2 * H2_AMAX_FLOATS, reinterpret_cast<unsigned*>(c->p("h2s") + 7), s); });
+            return h2_pack_rows_launch(c->p("cat1"), (long)c->enc_h[1] * W1 * C1, (long)W1 * C1, C1, 10, B, 7, W1, C1, f.cat_amax(1, 0), f.cat_amax(1, 1), c->p("cat1p"),
+                                       f.cat_a_inv(1), reinterpret_cast<unsigned*>(c->p("h2s") + 7), s); });
         const float* w_inv = c->p("h2s") + c->h2_slot.at("separation/deconv1");
         const void* planes = c->p("cat1p");
         const void* wh2 = c->p("pkh:separation/deconv1/weights");
-        const float* a_inv = amax + 2 * H2_AMAX_FLOATS;
+        const float* a_inv = f.cat_a_inv(1);
         d1_tweak = [=](IgemmDesc& d) {
             d.xp3 = planes; d.xp3_fmt = 1; d.xp3_row0 = 10; d.xp3_rows = 7;
             d.p3_np = B * 7 * (W1 + 1);
