@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libsagen_hip.so')
-SOURCES = ['conv3p.hip', 'conv3h.hip', 'conv3g.hip', 'p3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'stempool.hip', 'stem8.hip', 'igemm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'train.hip', 'wgrad.hip', 'wgrad3h.hip', 'backward.hip', 'model.hip', 'train_model.hip', 'api.hip']
+SOURCES = ['conv3p.hip', 'conv3h.hip', 'conv3g.hip', 'p3.hip', 'igemm3dw.hip', 'igemm3s2.hip', 'stempool.hip', 'stem8.hip', 'igemm.hip', 'fcm.hip', 'igemm3.hip', 'elementwise.hip', 'fft.hip', 'eval.hip', 'train.hip', 'wgrad.hip', 'wgrad3h.hip', 'backward.hip', 'model.hip', 'train_model.hip', 'api.hip']
 # every header of csrc/ (the listing source_digest() hashes) + the public one: editing any of them rebuilds every object
 HEADERS = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith('.h')) + \
           [os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'sagen.h')]

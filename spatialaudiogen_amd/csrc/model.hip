@@ -171,6 +171,30 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->alloc("bott", (size_t)B * 3 * c->Cb);
     for (int i = 0; i < cfg->n_loc_units; ++i) c->alloc("loc" + std::to_string(i + 1), (size_t)B * 3 * cfg->loc_units[i]);
     c->alloc("coeffs", (size_t)B * 3 * 3 * (c->nsep + 1));
+    {   // fcm_kernel (fcm.hip) for the skinny FC layers at inference: partial buffers [slices][rows][N] per layer
+        struct L { std::string name; int rows, K, N; };
+        std::vector<L> ls;
+        ls.push_back({"bottleneck/audio-fc", 3 * B, c->enc_w[5] * c->enc_c[5], 1024});
+        if (c->has_video) ls.push_back({"bottleneck/video-fc", B, 7 * 14 * 128, 512});
+        if (c->has_flow) ls.push_back({"bottleneck/flow-fc", B, 7 * 14 * 128, 512});
+        int fin = c->Cb;
+        for (int i = 0; i < cfg->n_loc_units; ++i) { ls.push_back({"localization/fc" + std::to_string(i + 1), 3 * B, fin, cfg->loc_units[i]}); fin = cfg->loc_units[i]; }
+        ls.push_back({"localization/fc" + std::to_string(cfg->n_loc_units + 1), 3 * B, fin, 3 * (c->nsep + 1)});
+        if (c->freq_mask) ls.push_back({"separation/fc-feats", 3 * B, c->Cb, 512});
+        // OPT-IN (SAGEN_FCM=1): measured slower than the general kernels it replaces (audio-fc 33 vs 15 us, video-fc 22 vs 18, fc2 / fc3 17 vs
+        // 9 - 10; only fc1 + fc-feats in one launch wins, 19 vs 23): these layers are bound by the latency of a short dependent launch
+        // (~6 us, what a reducer takes), not by how their arithmetic is fed
+        bool ok = getenv("SAGEN_FCM") != nullptr && !c->sk_fused && 3 * B <= FCM_MAX_M;
+        for (const L& l : ls) ok = ok && fcm_pick_slices(l.K, (long)l.K * l.N) > 0;
+        c->use_fcm = ok;
+        if (ok)
+            for (const L& l : ls) {
+                int ns = fcm_pick_slices(l.K, (long)l.K * l.N);
+                if (l.name == "separation/fc-feats") ns = c->fcm_slices.at("localization/fc1");      // (one launch with fc1: the same slicing)
+                c->fcm_slices[l.name] = ns;
+                c->alloc("fcm:" + l.name, (size_t)ns * l.rows * l.N);
+            }
+    }
     c->alloc("splitk", std::max<size_t>((size_t)16 << 20, (size_t)B * 56 * 112 * 64 * 2));   // fp32 split-K partials (up to 2 splits of the largest conv), checked per use
     if (c->freq_mask) {
         // rows 10..16 of cat1 as fp16x2 planes (the operand of deconv1 on conv3g_kernel) + the words around them: H2_AMAX_FLOATS floats (H2_AMAX_SLOTS lines) each for the exact
@@ -488,7 +512,34 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
 
     // bottleneck (model.py:203-239)
     float* bott = c->p("bott");
-    {   // audio-fc over (w, c) of conv5: 6 taps along W, 512 channels each
+    const bool fcm = c->use_fcm && !c->train_mode && !c->tuning;
+    // one fcm launch: `segs` describe the input rows, `names` the layers (their variables, their "fcm:" partial buffers)
+    auto fcm_layer = [&](Fwd& w, const std::string& label, int M, int K, const std::vector<FcmSeg>& segs, const std::vector<std::string>& names, const std::vector<int>& Ns) {
+        FcmDesc fd;
+        fd.M = M; fd.K = K; fd.nseg = (int)segs.size(); fd.njobs = (int)names.size(); fd.nslices = c->fcm_slices.at(names[0]);
+        for (size_t q = 0; q < segs.size(); ++q) fd.seg[q] = segs[q];
+        double fl = 0.0;
+        for (size_t j = 0; j < names.size(); ++j) {
+            fd.job[j].w = c->v(names[j] + "/weights"); fd.job[j].N = Ns[j]; fd.job[j].out = c->p("fcm:" + names[j]);
+            fl += 2.0 * M * K * Ns[j];
+        }
+        w.layer = label;
+        w.timed(M <= 32 ? "fcm_kernel<1>" : (M <= 64 ? "fcm_kernel<2>" : "fcm_kernel<3>"), fl, [&] { return fcm_launch(fd, w.s); });
+    };
+    // ... and the reducer behind it: y[(m * rep + r) * ldy + n] = act(bias + sum of the slices)
+    auto fcm_finish = [&](Fwd& w, const std::string& name, int rows, int N, bool relu, float* y, int ldy, int rep, float* amax_out = nullptr) {
+        w.layer = name;
+        w.timed("splitk_reduce_kernel", 0.0, [&] {
+            return splitk_reduce_launch(c->p("fcm:" + name), c->fcm_slices.at(name), rows, N, c->v(name + "/biases"), relu ? 1 : 0, y, ldy, rep, nullptr, w.s, amax_out); });
+    };
+    if (fcm) {  // audio-fc: the six frequency columns of conv5 (the first 512 channels of cat5's pixels) are six plain input ranges
+        std::vector<FcmSeg> segs(6);
+        for (int wq = 0; wq < 6; ++wq) {
+            segs[wq].p = c->p("cat5") + (size_t)wq * 1024; segs[wq].k0 = wq * 512; segs[wq].k1 = (wq + 1) * 512; segs[wq].ld = 6 * 1024;
+        }
+        fcm_layer(g, "bottleneck/audio-fc", B * 3, 6 * 512, segs, {"bottleneck/audio-fc"}, {1024});
+        fcm_finish(g, "bottleneck/audio-fc", B * 3, 1024, true, bott, c->Cb, 1);
+    } else {   // audio-fc over (w, c) of conv5: 6 taps along W, 512 channels each
         IgemmDesc d;
         d.x = c->p("cat5"); d.w = c->p("pk:bottleneck/audio-fc/weights"); d.y = bott; d.bias = c->v("bottleneck/audio-fc/biases");
         d.M = B * 3; d.N = 1024; d.K = 6 * 512; d.Kpad = d.K;
@@ -510,7 +561,14 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         const float* feat = c->train_mode ? w.resnet_train(e == 0 ? video : flow, enc + "_encoder")      // (retains every activation)
                                           : w.resnet(e == 0 ? video : flow, enc + "_encoder");          // [B,7,14,512]
         w.fc(feat, B * 98, 512, 512, "bottleneck/" + enc + "-fc-red", 128, true, c->p("fcred" + w.sfx), 128);
-        w.fc(c->p("fcred" + w.sfx), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
+        if (fcm) {
+            FcmSeg sg;
+            sg.p = c->p("fcred" + w.sfx); sg.k0 = 0; sg.k1 = 98 * 128; sg.ld = 98 * 128;
+            fcm_layer(w, "bottleneck/" + enc + "-fc", B, 98 * 128, {sg}, {"bottleneck/" + enc + "-fc"}, {512});
+            fcm_finish(w, "bottleneck/" + enc + "-fc", B, 512, true, bott + choff, c->Cb, 3);      // tile x3 (model.py:230-232)
+        } else {
+            w.fc(c->p("fcred" + w.sfx), B, 98 * 128, 98 * 128, "bottleneck/" + enc + "-fc", 512, true, bott + choff, c->Cb, 3);   // tile x3 (model.py:230-232)
+        }
         choff += 512;
     }
     if (f.rc || g.rc) return bail(f.rc ? f.rc : g.rc);
@@ -523,6 +581,34 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // independent consumers of the bottleneck: second fork, the FCs go to the context's stream.
     static const bool no_fork2 = getenv("SAGEN_NO_FORK2") != nullptr;
     const bool fork2 = forked && c->freq_mask && !no_fork2;
+    const int nlast_fcm = 3 * (c->nsep + 1);
+    if (fcm) {
+        // fc1 and fc-feats read the same rows (the bottleneck): one launch; the feats tile (cat5, six frequency columns: the decoder's
+        // input) is finished on the caller's stream, then the streams fork: fc1's reducer, fc2, fc3 run next to the decoder.
+        const int M3 = B * 3, nl = c->cfg.n_loc_units;
+        auto plain = [&](const float* x, int K) { FcmSeg sg; sg.p = x; sg.k0 = 0; sg.k1 = K; sg.ld = K; return sg; };
+        std::vector<std::string> names{"localization/fc1"};
+        std::vector<int> Ns{nl > 0 ? c->cfg.loc_units[0] : nlast_fcm};
+        if (c->freq_mask) { names.push_back("separation/fc-feats"); Ns.push_back(512); }
+        fcm_layer(f, c->freq_mask ? "localization/fc1+separation/fc-feats" : "localization/fc1", M3, c->Cb, {plain(bott, c->Cb)}, names, Ns);
+        if (c->freq_mask) fcm_finish(f, "separation/fc-feats", M3, 512, true, c->p("cat5") + 512, 1024, 6, want_amax ? f.cat_amax(5, 0) : nullptr);
+        if (fork2) {
+            SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+            SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        }
+        Fwd& w = fork2 ? g : f;
+        int K = Ns[0];
+        for (int i = 1; i <= nl; ++i) {
+            const std::string prev = "localization/fc" + std::to_string(i), cur = "localization/fc" + std::to_string(i + 1);
+            const int N = i < nl ? c->cfg.loc_units[i] : nlast_fcm;
+            float* y = c->p("loc" + std::to_string(i));
+            fcm_finish(w, prev, M3, K, true, y, K, 1);
+            fcm_layer(w, cur, M3, K, {plain(y, K)}, {cur}, {N});
+            K = N;
+        }
+        fcm_finish(w, "localization/fc" + std::to_string(nl + 1), M3, nlast_fcm, false, c->p("coeffs"), nlast_fcm, 1);
+        if (f.rc || g.rc) return bail(f.rc ? f.rc : g.rc);
+    } else {
     if (fork2) {
         SAGEN_HIP_CHECK(hipEventRecord(c->ev_fork, s));
         SAGEN_HIP_CHECK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
@@ -540,6 +626,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         w.fc(x, B * 3, K, K, "localization/fc" + std::to_string(c->cfg.n_loc_units + 1), nlast, false, c->p("coeffs"), nlast);
         if (f.rc || g.rc) return bail(f.rc ? f.rc : g.rc);
     }
+    }
 
     if (!c->freq_mask) {
         f.layer = "decoder";
@@ -548,8 +635,9 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     }
 
     // separation (model.py:282-348)
-    f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6,     // tile over 6 freq columns
-         want_amax ? f.cat_amax(5, 0) : nullptr);
+    if (!fcm)
+        f.fc(bott, B * 3, c->Cb, c->Cb, "separation/fc-feats", 512, true, c->p("cat5") + 512, 1024, 6,     // tile over 6 freq columns
+             want_amax ? f.cat_amax(5, 0) : nullptr);
     // Inference runs deconv5 .. deconv2 in SCATTER form (Fwd::deconv_scatter): every input pixel is contracted once against the whole
     // filter and a gather pass assembles the output - the conv form over the output grid multiplies padding for most taps of the
     // stride-1 layers (5.4 of 15 taps of deconv5 land inside its 3x6 input), and the strided layers' depth-to-space form cannot split K.

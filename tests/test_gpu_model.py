@@ -538,3 +538,20 @@ def test_three_stream_batch_at_full_size_against_the_independent_cpu_reference(T
     net.load_variables(P)
     check_out(net.inference_ops(inp['audio'], inp['video'], inp['flow']).cpu().numpy(), ref)
     assert net.counter(B, 'fp16x2_saturations') == 0
+
+
+def test_skinny_fc_kernel_opt_in_agrees_with_the_oracle(T, monkeypatch):
+    """SAGEN_FCM=1 (read when a context is created): the bottleneck / localisation / fc-feats layers on fcm_kernel (exact fp32 MFMA on the
+    variables in their TF layout, fc1 + fc-feats in one launch) instead of the general contraction kernels - an experiment kept opt-in
+    because it measured slower; same bars, and the kernels must really be the ones running."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    monkeypatch.setenv('SAGEN_FCM', '1')
+    for enc, B in ((['audio'], 10), (['audio', 'video'], 3)):
+        net, orc, got, ref = run_pair(T, enc, batch=B, seed=4)
+        check_out(got, ref)
+        assert rel_rms_err(net.intermediate(B, 'bottleneck').cpu().numpy(), np.asarray(orc.ends['bottleneck']).reshape(B, 3, -1)) < 2e-5
+        net.profile_enable(B, True)
+        net.inference_ops(*[x for x in (synth_inputs(B, enc, seed=1238)[k] for k in ('audio', 'video')[:len(enc)])])
+        kernels = [k for k, layer, us, fl in net.profile_report(B)]
+        net.profile_enable(B, False)
+        assert sum(1 for k in kernels if k.startswith('fcm_kernel')) == (4 if 'video' not in enc else 5), kernels
