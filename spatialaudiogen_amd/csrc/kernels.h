@@ -263,6 +263,11 @@ struct P3hScale {
     // out (nullable, p3_pack only): the ReLU mask of the tensor written, ONE BIT per element - byte (dense pixel * C/8 + channel octet),
     // bit k = [channel 8*octet + k > 0]: the training step's batch-norm backward reads it instead of the fp32 activation (1/32 of the bytes)
     unsigned char* relu_bits = nullptr;
+    // in (p3_pack, fmt 1): the residual as fp16x2 planes of the SAME geometry (hi + lo carries the value conv_1 saw) scaled by
+    // res_a_inv[0] = 2^-ka of those planes, instead of an fp32 tensor; may be the very buffer the pass writes (each thread reads its
+    // own 8 channels of its own pixel before it overwrites them) - the block output then needs no fp32 copy at all
+    const void* res_planes = nullptr;
+    const float* res_a_inv = nullptr;
 };
 int p3_pack_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual, int relu,
                    float* y, void* p3, int B, int H, int W, int C, hipStream_t s, int fmt = 0, const P3hScale* h2 = nullptr);

@@ -528,6 +528,10 @@ struct Fwd {
     bool h2() const { return c->use_h2 && c->use_p3 && !c->fp32_only && (!c->train_mode || c->train_h2); }
     int p3_fmt() const { return h2() ? 1 : 0; }
     float* h2_a_inv() { return c->p("h2s") + (sfx.empty() ? 0 : 1); }        // 2^-ka of the planes currently in this trunk's plane buffer
+    // lean trunk (round 5, resnet()): the block input / output planes live in buffer "p3" with two alternating scale slots (a merge reads
+    // its residual under the old scale while it publishes the new one), the conv_2 input planes in "p3b" with their own
+    float* h2_a_inv_x(int parity) { return c->p("h2s") + 232 + 2 * (parity & 1) + (sfx.empty() ? 0 : 1); }
+    float* h2_a_inv_b() { return c->p("h2s") + 236 + (sfx.empty() ? 0 : 1); }
     // statistical bound of the current block input / output (conv3h.hip, p3.hip: P3hScale), two slots used alternately so that a merge
     // reads its input's bound from one and publishes its output's bound into the other
     float* h2_xbound(int parity) { return c->p("h2s") + 2 + 2 * (parity & 1) + (sfx.empty() ? 0 : 1); }
@@ -591,6 +595,12 @@ struct Fwd {
         // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
         const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode;
         const bool pool_planes = c->use_p3 && c->p3_from_stage <= 2;       // the pooled tensor is also wanted as planes (operand of conv2_1/conv_1)
+        // Lean trunk (round 5): with fp16x2 planes from stage 2 on and the plane-fed stride-2 kernels, NOTHING reads a block output as
+        // fp32 except the trunk's end: the merges read their identity residual from the block-input planes (in place: buffer "p3"
+        // holds block inputs / outputs, "p3b" the conv_2 inputs) and write planes only - 4 bytes per element less per merge, no fp32
+        // copy of the pooled tensor.  The planes carry the value conv_1 saw (22 significant bits + the residual's sign).
+        static const bool no_lean = getenv("SAGEN_NO_LEAN_TRUNK") != nullptr;
+        const bool lean = !no_lean && h2() && pool_planes && c->use_p3g && c->bufs.count("p3b" + sfx) != 0 && !c->train_mode;
         if (fast8)
             timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s); });
         else if (c->video_u8 && scope == "video_encoder")
@@ -613,9 +623,10 @@ struct Fwd {
                     return stem8pool_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });
                 const BnRef bnf = bn_ref(li, name, (long)B * H * W);
                 layer = name + "/bn-relu";
-                const P3hScale hs0 = h2_scale(h2_xbound(0));
-                if (pool_planes)       // BN + ReLU of the pooled tensor in place (the residual of conv2_1) AND as planes
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, 1, c->p("rx0" + sfx), c->p("p3" + sfx), B, 56, 112, 64, s, p3_fmt(), &hs0); });
+                P3hScale hs0 = h2_scale(h2_xbound(0));
+                if (lean) hs0.a_inv = h2_a_inv_x(0);
+                if (pool_planes)       // BN + ReLU of the pooled tensor as planes (lean trunk: planes only - the residual of conv2_1 is read from them) and in place
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, 1, lean ? nullptr : c->p("rx0" + sfx), c->p("p3" + sfx), B, 56, 112, 64, s, p3_fmt(), &hs0); });
                 else
                     timed("bn_apply_relu_kernel", 0.0, [&] { return bn_apply_relu_launch(c->p("rx0" + sfx), nullptr, nullptr, bnf, nullptr, c->p("rx0" + sfx), (long)B * 56 * 112, 64, s); });
             } else if (fused) {
@@ -637,8 +648,9 @@ struct Fwd {
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
             if (c->use_p3 && c->p3_from_stage <= 2)       // pooled block input as fp32 (residual) AND as planes (operand of conv2_1/conv_1)
             {
-                const P3hScale hs0 = h2_scale(h2_xbound(0));
-                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s, p3_fmt(), &hs0); });
+                P3hScale hs0 = h2_scale(h2_xbound(0));
+                if (lean) hs0.a_inv = h2_a_inv_x(0);
+                timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, lean ? nullptr : c->p("rx0" + sfx), c->p("p3" + sfx), B, H, W, 64, s, p3_fmt(), &hs0); });
             }
             else
                 timed("maxpool3x3s2_kernel", 0.0, [&] { return maxpool3x3s2_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("rx0" + sfx), B, H, W, 64, s); });
@@ -652,7 +664,7 @@ struct Fwd {
         const int couts[4] = {64, 128, 256, 512};
         bool x_in_planes = pool_planes;        // the pooled tensor exists as planes (p3_pack after the fused uint8 stem, p3_maxpool otherwise)
         int xb_par = 0;                                                 // which h2_xbound slot holds the current block input's bound
-        bool x_fp32_valid = true;                                       // false: the previous merge wrote the block input as planes only
+        bool x_fp32_valid = !lean;                                      // false: the previous pass wrote the block input as planes only (lean trunk: already the pool)
         for (int st = 0; st < 4; ++st) {
             const int cout = couts[st];
             for (int unit = 1; unit <= 2; ++unit) {
@@ -665,10 +677,12 @@ struct Fwd {
                 // passes cost 77 / 38 / 27 / 22 us (stage 2..5, batch 32) against ~30 / 15 / 8 / 5 us for the fp32 BN passes they
                 // replace, while conv3p saves ~19 us per conv at every stage (profiles/r02_*): stage 2 stays on igemm3dw.
                 const bool p3_here = c->use_p3 && st + 2 >= c->p3_from_stage;
-                void* planes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;
+                void* planes = p3_here ? (void*)c->p((lean ? "p3b" : "p3") + sfx) : nullptr;          // of conv_2's input
+                void* const xplanes = p3_here ? (void*)c->p("p3" + sfx) : nullptr;                     // of the block input / output
+                const float* const x_ai = lean ? h2_a_inv_x(xb_par) : nullptr;                        // (null: the trunk's one slot)
                 // the block input as planes: written by the previous block's merge (x_in_planes) - stride-1 conv_1 (conv3p_kernel) and,
                 // since round 4, the stride-2 conv_1 + 1x1 shortcut of a stage's first block (conv3g_kernel: gathered operand tiles)
-                const void* in_planes = (p3_here && x_in_planes) ? planes : nullptr;
+                const void* in_planes = (p3_here && x_in_planes) ? xplanes : nullptr;
                 if (first) {   // 1x1/2 projection, no bias, no BN (resnet.py:211-212)
                     IgemmDesc d = conv_desc(xin, H, W, cin, cin, c->p("pk:" + pfx + "/shortcut/weights"), 1, 1, 2, 2, true,
                                             cout, c->p("rsc" + sfx), cout, Ho, Wo);
@@ -683,7 +697,7 @@ struct Fwd {
                             d.xp3_bytes = (unsigned)p3h_bytes(B, H, W, cin);
                             d.wh2 = c->p("pkh:" + pfx + "/shortcut/weights");
                             d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
-                            d.h2_a_inv = h2_a_inv();
+                            d.h2_a_inv = x_ai ? x_ai : h2_a_inv();
                             d.h2_w_inv = c->p("h2s") + hs->second;
                         } else {
                             d.xp3_cstride = (unsigned)((size_t)d.p3_np * 96);
@@ -695,7 +709,7 @@ struct Fwd {
                     gemm(d, 1, false);
                     shortcut = c->p("rsc" + sfx);
                 }
-                conv_bn(x_fp32_valid ? xin : nullptr, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "", in_planes);
+                conv_bn(x_fp32_valid ? xin : nullptr, H, W, cin, pfx + "/conv_1", 3, stride, cout, BnRef(), c->p("ry1" + sfx), Ho, Wo, li, "", in_planes, x_ai);
                 const BnRef bn1 = bn_ref(li, pfx + "/conv_1", (long)B * Ho * Wo);
                 ++li;
                 int H2, W2;
@@ -703,9 +717,10 @@ struct Fwd {
                     // relu(bn1(y1)) -> planes (one elementwise pass), conv_2 on the planes, then the residual merge, which also
                     // writes the planes of the block output when the next conv_1 is a stride-1 3x3 (unit 1 of a stage)
                     layer = pfx + "/bn1-relu";
-                    const P3hScale hs1 = h2_scale();
+                    P3hScale hs1 = h2_scale();
+                    if (lean) hs1.a_inv = h2_a_inv_b();
                     timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry1" + sfx), nullptr, nullptr, bn1, nullptr, 1, nullptr, planes, B, Ho, Wo, cout, s, p3_fmt(), &hs1); });
-                    conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes);
+                    conv_bn(nullptr, Ho, Wo, cout, pfx + "/conv_2", 3, 1, cout, BnRef(), c->p("ry2" + sfx), H2, W2, li, "", planes, lean ? h2_a_inv_b() : nullptr);
                     const BnRef bn2 = bn_ref(li, pfx + "/conv_2", (long)B * Ho * Wo);
                     layer = pfx + "/merge";
                     // the block output as planes when the next conv_1 reads planes: the stride-1 3x3 of this stage (unit 1), or the
@@ -714,12 +729,20 @@ struct Fwd {
                     const bool to_next_stage = unit == 2 && c->use_p3g && st < 3;
                     const bool next_p3 = unit == 1 || to_next_stage;
                     // the residual's statistical bound: tracked from the previous pass (identity) or from the shortcut conv's statistics
-                    const P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
-                                               : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
+                    P3hScale hs2 = first ? h2_scale(h2_xbound(xb_par ^ 1), nullptr, bn_acc(20 + st), 1.0 / ((double)B * Ho * Wo))
+                                         : h2_scale(h2_xbound(xb_par ^ 1), h2_xbound(xb_par));
+                    // lean trunk: an identity residual comes from the block-input planes (overwritten in place by the block output,
+                    // under the other scale slot); only the trunk's last block writes fp32
+                    const bool res_planes = lean && !first;
+                    const bool y_fp32 = lean ? !next_p3 : !to_next_stage;
+                    if (lean) {
+                        hs2.a_inv = h2_a_inv_x(xb_par ^ 1);
+                        if (res_planes) { hs2.res_planes = xplanes; hs2.res_a_inv = h2_a_inv_x(xb_par); }
+                    }
                     xb_par ^= 1;
-                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, shortcut, 1, to_next_stage ? nullptr : xout, next_p3 ? planes : nullptr, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
+                    timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("ry2" + sfx), nullptr, nullptr, bn2, res_planes ? nullptr : shortcut, 1, y_fp32 ? xout : nullptr, next_p3 ? xplanes : nullptr, B, Ho, Wo, cout, s, p3_fmt(), &hs2); });
                     x_in_planes = next_p3;
-                    x_fp32_valid = !to_next_stage;
+                    x_fp32_valid = y_fp32;
                     ++li;
                     std::swap(xin, xout);
                     H = Ho; W = Wo; cin = cout;

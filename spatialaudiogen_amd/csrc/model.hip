@@ -220,6 +220,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         const size_t stage = (size_t)B * 56 * 112 * 64;
         for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc", "ry1n"}) c->alloc(nm + x, stage);
         c->alloc("p3" + x, (p3_bytes(B, 56, 112, 64) + 3) / 4 + 64);   // bf16 planes of the current 3x3 conv input (largest: stage 2)
+        c->alloc("p3b" + x, (p3h_bytes(B, 56, 112, 64) + 3) / 4 + 64); // lean trunk (model.h: resnet): the conv_2 input planes, "p3" then holds block inputs / outputs
         c->alloc("bnacc" + x, (size_t)24 * 2 * 512 * 2);   // fp64 (sum, sumsq) accumulators per BN layer
         c->alloc("fcred" + x, (size_t)B * 98 * 128);
         // trunk output (block conv5_2) for parity tests: the ping-pong lands in rx0 after the 8 blocks

@@ -151,7 +151,7 @@ template <bool H2>
 __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const BnRef bn,
                                                       const float* __restrict__ res, int relu, float* __restrict__ y,
-                                                      char* __restrict__ p3, long nrows, int W, int C, const P3hScale h2) {
+                                                      char* p3, long nrows, int W, int C, const P3hScale h2) {       // (p3 may alias h2.res_planes)
     const int C8 = C >> 3;
     const long total = nrows * (W + 1) * C8;             // padded pixels x channel octets (the grid stride is a multiple of C8)
     const long cstride = nrows * (W + 1) * (H2 ? 64 : 96);
@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
     const int c8 = (int)(t0 % C8);
     __shared__ __attribute__((aligned(16))) float tab[2][P3_MAX_C];
-    const float sa = p3_tables<H2>(scale, shift, bn, h2, res != nullptr, C, tab, s_bits);
+    const char* const resp = H2 ? reinterpret_cast<const char*>(h2.res_planes) : nullptr;
+    const float sa = p3_tables<H2>(scale, shift, bn, h2, res != nullptr || resp != nullptr, C, tab, s_bits);
+    const float r_inv = resp ? h2.res_a_inv[0] : 0.f;
     const float4 sc0 = *reinterpret_cast<const float4*>(&tab[0][8 * c8]), sc1 = *reinterpret_cast<const float4*>(&tab[0][8 * c8 + 4]);
     const float4 sh0 = *reinterpret_cast<const float4*>(&tab[1][8 * c8]), sh1 = *reinterpret_cast<const float4*>(&tab[1][8 * c8 + 4]);
     for (long i = t0; i < total; i += (long)gridDim.x * 256) {
@@ -175,6 +177,13 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
             if (res) {
                 const float4 ra = *reinterpret_cast<const float4*>(res + e), rb = *reinterpret_cast<const float4*>(res + e + 4);
                 v[0] += ra.x; v[1] += ra.y; v[2] += ra.z; v[3] += ra.w; v[4] += rb.x; v[5] += rb.y; v[6] += rb.z; v[7] += rb.w;
+            }
+            if (H2 && resp) {                // the residual from its planes: (hi + lo) * 2^-ka, exact in fp32 (both are multiples of the lo ulp)
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                const char* src = resp + (long)(c8 >> 1) * cstride + pp * 64 + (c8 & 1) * 16;
+                const h8 rh = *reinterpret_cast<const h8*>(src), rl = *reinterpret_cast<const h8*>(src + 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += ((float)rh[k] + (float)rl[k]) * r_inv;
             }
             if (relu) {
 #pragma unroll
