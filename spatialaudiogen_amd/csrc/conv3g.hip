@@ -358,7 +358,7 @@ int conv3g_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: too many pixels for 32-bit index arithmetic");
     if ((long)d.p3_np * 96 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the activation planes exceed 2 GiB buffer addressing (use a smaller batch)");
-    const bool mm = tile == TILE_P3GH_MM_64x128_K2 || tile == TILE_P3GH_MM_64x128_K4;
+    const bool mm = tile == TILE_P3GH_MM_64x128_K2 || tile == TILE_P3GH_MM_64x128_K4 || tile == TILE_P3GH_MM_128x128_K2 || tile == TILE_P3GH_MM_128x256_K2;
     if (mm != (d.mm_out != nullptr)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the fused decoder tail and the tile do not match");
     const bool h2 = mm || tile == TILE_P3GH_128x64_K3 || tile == TILE_P3GH_64x64_K4 || tile == TILE_P3GH_128x128_K2 || tile == TILE_P3GH_64x128_K3;
     if (h2 != (d.xp3_fmt == 1)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the planes' format does not match the tile");
@@ -376,6 +376,8 @@ int conv3g_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         case TILE_P3GH_64x128_K3: return launch_conv3g<64, 128, 32, 64, 3, true>(d, s);
         case TILE_P3GH_MM_64x128_K2: return launch_conv3g<64, 128, 32, 64, 2, true, 1>(d, s);
         case TILE_P3GH_MM_64x128_K4: return launch_conv3g<64, 128, 32, 64, 4, true, 1>(d, s);
+        case TILE_P3GH_MM_128x128_K2: return launch_conv3g<128, 128, 64, 64, 2, true, 1>(d, s);
+        case TILE_P3GH_MM_128x256_K2: return launch_conv3g<128, 256, 64, 128, 2, true, 1>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: bad tile id %d", (int)tile);
     }
 }

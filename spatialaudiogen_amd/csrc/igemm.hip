@@ -332,6 +332,7 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 64, 32, "conv3h_kernel<128,64,64,32,2>", true, true, false, true, false, true}, {64, 64, 32, "conv3h_kernel<64,64,32,32,2>", true, true, false, true, false, true},
     {64, 64, 64, "conv3h_kernel<64,64,32,32,4>", true, true, false, true, false, true},
     {64, 128, 16, "conv3g_kernel<64,128,32,64,2,true,1>", true, false, false, true, true, true}, {64, 128, 16, "conv3g_kernel<64,128,32,64,4,true,1>", true, false, false, true, true, true},
+    {128, 128, 16, "conv3g_kernel<128,128,64,64,2,true,1>", true, false, false, true, true, true}, {128, 256, 16, "conv3g_kernel<128,256,64,128,2,true,1>", true, false, false, true, true, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -364,8 +365,9 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     const int bk = kTiles[t].bk;
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
-    const bool mm_tile = t == TILE_P3GH_MM_64x128_K2 || t == TILE_P3GH_MM_64x128_K4;      // conv3g_kernel with the fused decoder tail as epilogue
+    const bool mm_tile = t == TILE_P3GH_MM_64x128_K2 || t == TILE_P3GH_MM_64x128_K4 || t == TILE_P3GH_MM_128x128_K2 || t == TILE_P3GH_MM_128x256_K2;      // conv3g_kernel with the fused decoder tail as epilogue
     if (mm_tile != (d.mm_out != nullptr && kTiles[t].g)) return false;
+    if (mm_tile && (d.Wg % kTiles[t].bm || (d.dsw * d.Cout) % kTiles[t].bn)) return false;          // a tile = one mask frame of one window
     if (d.mm_out != nullptr && !mm_tile) {  // fused decoder tail: igemm3_kernel tiles holding one mask frame of one window
         const bool b3 = kTiles[t].split && !kTiles[t].dw3 && !kTiles[t].s2 && !kTiles[t].p3;
         if (!b3 || kTiles[t].bm > 128 || kTiles[t].bn > 128 || d.Cout != 32 || d.dsh * d.dsw <= 1 || d.Wg % kTiles[t].bm ||

@@ -407,7 +407,9 @@ __device__ __forceinline__ void igemm_epilogue_maskmix(const IgemmDesc& d, f32x1
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = half * 16 + 4 * q4 + u;
-                    const float sg = 1.f / (1.f + expf(-(vv[u] + bs[j])));
+                    // sigmoid on the hardware transcendentals: v_exp_f32 (2^x, 1 ulp) and v_rcp_f32 (1 ulp) - ~2e-7 relative against
+                    // expf + IEEE division, which cost ~3x the instructions in a pass of 25 M sigmoids per batch (the tile's critical path)
+                    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (vv[u] + bs[j])));
 #pragma unroll
                     for (int o = 0; o < 3; ++o) {
                         e[o] = fmaf(wl[o * NTR + j], sg, e[o]);

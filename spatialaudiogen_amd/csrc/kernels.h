@@ -127,7 +127,7 @@ enum IgemmTile {
     // conv3h_kernel with two / four 16-channel chunks per barrier step (the deep, latency-bound layers)
     TILE_P3H_128x64_C2, TILE_P3H_64x64_C2, TILE_P3H_64x64_C4,
     // conv3g_kernel on fp16x2 planes with the fused decoder tail as its epilogue (deconv1 at inference: IgemmDesc::mm_out), 2 / 4 K tiles per group
-    TILE_P3GH_MM_64x128_K2, TILE_P3GH_MM_64x128_K4,
+    TILE_P3GH_MM_64x128_K2, TILE_P3GH_MM_64x128_K4, TILE_P3GH_MM_128x128_K2, TILE_P3GH_MM_128x256_K2,
     TILE_AUTO
 };
 

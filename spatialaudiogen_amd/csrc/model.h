@@ -115,6 +115,7 @@ struct sagen_ctx {
     std::vector<H2Job> h2_jobs;            // the batched fp16x2 filter pack (host copy of the job table)
     int h2_blocks = 0;
     bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
+    int dec_planes_min_batch = 16;         // the scatter-form decoder contracts fp16x2 planes from this batch size on (sagen_set_option("decoder_planes", 1 / 0): always / never)
     bool use_fcm = false;                  // inference: the skinny FC layers (bottleneck / localisation / fc-feats) run fcm_kernel (fcm.hip) chained through partials; SAGEN_NO_FCM=1: the round-4 contraction + reducer launches
     std::map<std::string, int> fcm_slices; // per FC layer: K slices of its fcm launch
     bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels

@@ -458,11 +458,12 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
                      c->bufs.count("cat1p") != 0 && c->h2_slot.count("separation/deconv1") != 0 && getenv("SAGEN_NO_MASKFUSE") == nullptr;
     if (d1_planes && !c->tuning) {             // a plan that names a register-staged tile for deconv1 keeps the round-4 path (no pack pass)
         auto it = c->plan.find("separation/deconv1");
-        if (it != c->plan.end() && it->second.tile != (int)TILE_P3GH_MM_64x128_K2 && it->second.tile != (int)TILE_P3GH_MM_64x128_K4) d1_planes = false;
+        if (it != c->plan.end() && !igemm_tile_p3((IgemmTile)it->second.tile)) d1_planes = false;
     }
     // ... and deconv5 .. deconv2 (scatter form) on planes of the band of cat_(l+1) they contract, the same way
     static const bool no_decp = getenv("SAGEN_NO_DECODER_PLANES") != nullptr;
-    const bool dec_planes = !no_decp && !c->sk_fused && c->freq_mask && !c->train_mode && !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 &&
+    // (from 16 windows on: at deploy.py's batch of 10 the four pack launches cost what the plane-fed GEMMs save - 6 450 against 6 630 ambisonic-s/s)
+    const bool dec_planes = !no_decp && c->B >= c->dec_planes_min_batch && !c->sk_fused && c->freq_mask && !c->train_mode && !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 &&
                             getenv("SAGEN_NO_DECONV_SCATTER") == nullptr;
     const bool want_amax = d1_planes || dec_planes;
     if (want_amax) SAGEN_HIP_CHECK(hipMemsetAsync(c->p("amax"), 0, (10 * H2_AMAX_FLOATS + 64) * sizeof(float), g.s));
@@ -821,6 +822,7 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
     if (n == "fp16x2") { c->use_h2 = value != 0; return SAGEN_OK; }
     if (n == "planes_from_stage") { if (value < 2 || value > 6) return fail(SAGEN_ERR_SHAPE, "planes_from_stage in 2..6"); c->p3_from_stage = value; return SAGEN_OK; }
+    if (n == "decoder_planes") { c->dec_planes_min_batch = value ? 1 : (1 << 30); return SAGEN_OK; }
     if (n == "plane_gather") { c->use_p3g = c->use_p3 && value != 0; return SAGEN_OK; }
     return fail(SAGEN_ERR_UNSUPPORTED, "sagen_set_option: unknown option %s", name);
 }

@@ -555,3 +555,43 @@ def test_skinny_fc_kernel_opt_in_agrees_with_the_oracle(T, monkeypatch):
         kernels = [k for k, layer, us, fl in net.profile_report(B)]
         net.profile_enable(B, False)
         assert sum(1 for k in kernels if k.startswith('fcm_kernel')) == (4 if 'video' not in enc else 5), kernels
+
+
+def test_scatter_form_decoder_on_planes_and_on_fp32_operands_and_the_round4_form_agree(T, monkeypatch):
+    """The mask decoder at inference: deconv5 .. deconv2 in scatter form (GEMM over the live band of input rows + gather), on fp16x2 planes
+    of the concat buffers scaled by the producers' exact maxima (from 16 windows on by default; forced here at B = 3) or on the fp32
+    buffers (igemm3_kernel) - and the round-4 depth-to-space form over the full grids (SAGEN_NO_DECONV_SCATTER=1): all three against
+    the oracle, the kernels that ran checked by name, and no plane element clamped."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc, B = ['audio', 'video'], 3
+    P = init_weights(variable_specs(enc), seed=15, mode='test')
+    inp = synth_inputs(B, enc, seed=55)
+    ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp['video'])
+
+    def run(net):
+        net.profile_enable(B, True)
+        y = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+        rows = net.profile_report(B)
+        net.profile_enable(B, False)
+        return y, {(layer, k.split('<')[0]) for k, layer, us, fl in rows if layer.startswith('separation/deconv')}
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.inference_ops(inp['audio'], inp['video'])
+    y_f32, k_f32 = run(net)                               # B = 3 < 16: scatter form on the fp32 concat buffers
+    assert ('separation/deconv5', 'deconv_gather_kernel') in k_f32 and ('separation/deconv5', 'h2_pack_rows_kernel') not in k_f32
+    net.set_option(B, 'decoder_planes', 1)
+    y_pl, k_pl = run(net)
+    for l in (2, 3, 4, 5):
+        assert ('separation/deconv%d' % l, 'h2_pack_rows_kernel') in k_pl and ('separation/deconv%d' % l, 'conv3g_kernel') in k_pl, k_pl
+    assert ('separation/deconv1', 'conv3g_kernel') in k_pl
+    assert net.counter(B, 'fp16x2_saturations') == 0
+    monkeypatch.setenv('SAGEN_NO_DECONV_SCATTER', '1')
+    monkeypatch.setenv('SAGEN_NO_DECONV1_PLANES', '1')
+    old = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    old.load_variables(P)
+    old.inference_ops(inp['audio'], inp['video'])
+    y_r4, k_r4 = run(old)
+    assert not any(k == 'deconv_gather_kernel' for _, k in k_r4) and ('separation/deconv1', 'igemm3_kernel') in k_r4
+    for y in (y_f32, y_pl, y_r4):
+        check_out(y, ref)
+    assert rel_rms_err(y_pl, y_r4) < 1e-5 and rel_rms_err(y_f32, y_r4) < 1e-5
