@@ -115,6 +115,7 @@ struct sagen_ctx {
     std::vector<H2Job> h2_jobs;            // the batched fp16x2 filter pack (host copy of the job table)
     int h2_blocks = 0;
     bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
+    bool no_scatter = false, no_d1_planes = false, no_lean_trunk = false;      // SAGEN_NO_DECONV_SCATTER / SAGEN_NO_DECONV1_PLANES / SAGEN_NO_LEAN_TRUNK, read when the context is created
     int dec_planes_min_batch = 16;         // the scatter-form decoder contracts fp16x2 planes from this batch size on (sagen_set_option("decoder_planes", 1 / 0): always / never)
     bool use_fcm = false;                  // inference: the skinny FC layers (bottleneck / localisation / fc-feats) run fcm_kernel (fcm.hip) chained through partials; SAGEN_NO_FCM=1: the round-4 contraction + reducer launches
     std::map<std::string, int> fcm_slices; // per FC layer: K slices of its fcm launch
@@ -600,7 +601,7 @@ struct Fwd {
         // fp32 except the trunk's end: the merges read their identity residual from the block-input planes (in place: buffer "p3"
         // holds block inputs / outputs, "p3b" the conv_2 inputs) and write planes only - 4 bytes per element less per merge, no fp32
         // copy of the pooled tensor.  The planes carry the value conv_1 saw (22 significant bits + the residual's sign).
-        static const bool no_lean = getenv("SAGEN_NO_LEAN_TRUNK") != nullptr;
+        const bool no_lean = c->no_lean_trunk;
         const bool lean = !no_lean && h2() && pool_planes && c->use_p3g && c->bufs.count("p3b" + sfx) != 0 && !c->train_mode;
         if (fast8)
             timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s); });

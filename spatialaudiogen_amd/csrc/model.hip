@@ -42,6 +42,10 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
     c->train_h2w = getenv("SAGEN_TRAIN_NO_H2W") == nullptr;
     c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
+    c->no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
+    c->no_d1_planes = getenv("SAGEN_NO_DECONV1_PLANES") != nullptr;
+    c->no_lean_trunk = getenv("SAGEN_NO_LEAN_TRUNK") != nullptr;
+    if (getenv("SAGEN_NO_DECODER_PLANES") != nullptr) c->dec_planes_min_batch = 1 << 30;
     // with two fp16 planes a plane pass writes 4 bytes per element - what the fp32 pass it replaces writes - so the planes pay from
     // stage 2 on (measured, same box: 2 034 against 1 943 ambisonic-s/s); with three bf16 planes (6 bytes) only from stage 3
     if (getenv("SAGEN_P3_FROM_STAGE") == nullptr) c->p3_from_stage = (c->use_h2 && c->use_p3) ? 2 : 3;
@@ -452,7 +456,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
 
     // deconv1 on fp16x2 planes of cat1 (conv3g_kernel + fused decoder tail): the planes' scale is the EXACT maximum of cat1, published by
     // the epilogues of its two producers (conv1: encoder half, deconv2: decoder half) into words zeroed here
-    static const bool no_d1p = getenv("SAGEN_NO_DECONV1_PLANES") != nullptr;
+    const bool no_d1p = c->no_d1_planes;
     // (the opt-in in-launch split-K combine, SAGEN_SK_FUSED=1, has no reducer to publish a maximum from: it keeps the round-4 decoder)
     bool d1_planes = !no_d1p && !c->sk_fused && c->freq_mask && !c->train_mode && !c->materialize_mask && !c->fp32_only && c->nsep == 32 && f.h2() &&
                      c->bufs.count("cat1p") != 0 && c->h2_slot.count("separation/deconv1") != 0 && getenv("SAGEN_NO_MASKFUSE") == nullptr;
@@ -461,10 +465,10 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         if (it != c->plan.end() && !igemm_tile_p3((IgemmTile)it->second.tile)) d1_planes = false;
     }
     // ... and deconv5 .. deconv2 (scatter form) on planes of the band of cat_(l+1) they contract, the same way
-    static const bool no_decp = getenv("SAGEN_NO_DECODER_PLANES") != nullptr;
+    const bool no_decp = c->dec_planes_min_batch > (1 << 29);
     // (from 16 windows on: at deploy.py's batch of 10 the four pack launches cost what the plane-fed GEMMs save - 6 450 against 6 630 ambisonic-s/s)
     const bool dec_planes = !no_decp && c->B >= c->dec_planes_min_batch && !c->sk_fused && c->freq_mask && !c->train_mode && !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 &&
-                            getenv("SAGEN_NO_DECONV_SCATTER") == nullptr;
+                            !c->no_scatter;
     const bool want_amax = d1_planes || dec_planes;
     if (want_amax) SAGEN_HIP_CHECK(hipMemsetAsync(c->p("amax"), 0, (10 * H2_AMAX_FLOATS + 64) * sizeof(float), g.s));
 
@@ -646,7 +650,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // Only rows 10..16 of cat1 reach deconv1's live grid rows (11..16, two vertical taps), hence only rows 4..8 of cat2 (deconv2's
     // taps) and rows 1..4 of cat3: each layer contracts the band of input rows it needs and gathers the output rows that are read.
     // The training step (and SAGEN_FP32_ONLY) keep the round-4 form on the full tensors.
-    static const bool no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
+    const bool no_scatter = c->no_scatter;
     const bool lean = !c->train_mode && !c->fp32_only && !no_scatter;
     int need_lo[7], need_hi[7];                          // rows of cat_l that the layer below reads
     for (int l = 1; l <= 5; ++l) { need_lo[l] = 0; need_hi[l] = c->enc_h[l]; }
