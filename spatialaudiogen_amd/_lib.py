@@ -93,6 +93,14 @@ SIGNATURES = {
 }
 
 _lib = None
+IS_CPU_TWIN = False        # set when SAGEN_LIB names libsagen_cpu.so (ops.py then takes host tensors)
+
+
+def _not_in_the_twin(name):
+    def raiser(*_a, **_k):
+        raise SagenError(-7, '%s: the CPU twin implements the op level of include/sagen.h only - the hot path itself needs '
+                             'libsagen_hip.so and a gfx950 device' % name)
+    return raiser
 
 
 def lib():
@@ -106,10 +114,25 @@ def lib():
         # the one this library binds to, so it has to be loaded first.
         import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
+        l.sagen_build_info.restype = C.c_char_p
+        twin = l.sagen_build_info().decode().startswith('cpu-twin')
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            try:
+                fn = getattr(l, name)      # AttributeError if the symbol is not exported
+            except AttributeError:
+                if not twin:
+                    raise
+                # libsagen_cpu.so (SAGEN_LIB names it explicitly; csrc_cpu/sagen_cpu.cpp) implements the OP LEVEL of the header on host
+                # pointers, for op-level parity tests in a container without a GPU - it has no context, no forward, no training step
+                setattr(l, name, _not_in_the_twin(name))
+                continue
             fn.restype = res
             fn.argtypes = args
+        if twin:
+            global IS_CPU_TWIN
+            IS_CPU_TWIN = True
+            _lib = l
+            return _lib
         info = l.sagen_build_info().decode()
         if not ('-fno-slp-vectorize' in info and '-fno-vectorize' in info) and not os.environ.get('SAGEN_ALLOW_ANY_BUILD'):
             raise RuntimeError('%s was built with [%s]: without -fno-slp-vectorize -fno-vectorize the kernels contain packed-fp32 VALU '

@@ -109,5 +109,21 @@ def build(force=False, verbose=True):
     return LIB
 
 
+CPU_TWIN_SRC = os.path.join(HERE, 'csrc_cpu', 'sagen_cpu.cpp')
+CPU_TWIN_LIB = os.path.join(HERE, 'libsagen_cpu.so')
+
+
+def build_cpu_twin(force=False):
+    """libsagen_cpu.so: the op level of include/sagen.h in plain C++ on host pointers (csrc_cpu/sagen_cpu.cpp) - test infrastructure
+    for a container without a GPU (SAGEN_LIB=<this file> python -m pytest tests/test_gpu_ops.py ...), never a fallback."""
+    if force or _stale(CPU_TWIN_LIB, [CPU_TWIN_SRC, HEADERS[-1]]):
+        cxx = os.environ.get('CXX', 'g++')
+        r = subprocess.run([cxx, '-O2', '-std=c++17', '-shared', '-fPIC', '-Wall', CPU_TWIN_SRC, '-o', CPU_TWIN_LIB], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('the CPU twin failed to compile:\n%s' % r.stderr)
+    return CPU_TWIN_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv))
+    print(build_cpu_twin(force='--force' in sys.argv))

@@ -14,15 +14,22 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _twin():
+    _lib.lib()
+    return _lib.IS_CPU_TWIN
+
+
 def _stream():
+    if _twin():          # libsagen_cpu.so (SAGEN_LIB): host pointers, no stream
+        return None
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _f32(t, name):
     if isinstance(t, torch.Tensor) and t.dtype == torch.float64 and name == 'stats':
         return t
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
-        raise TypeError('%s must be a CUDA float32 tensor' % name)
+    if not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.is_cuda != _twin()):
+        raise TypeError('%s must be a %s float32 tensor' % (name, 'host (the CPU twin is loaded)' if _twin() else 'CUDA'))
     return t.contiguous()
 
 

@@ -11,16 +11,24 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+# SAGEN_LIB=<...>/libsagen_cpu.so: the same cases against the CPU twin of the op level (csrc_cpu/sagen_cpu.cpp) on host tensors, in a
+# container without a GPU (tests/test_cpu_twin_ops.py runs them that way)
+import os
+TWIN = os.path.basename(os.environ.get('SAGEN_LIB', '')) == 'libsagen_cpu.so'
+
+
 @pytest.fixture(scope='module')
 def T():
     import torch
-    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    if not TWIN:
+        assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
     ensure_lib()
     return torch
 
 
 def dev(T, a):
-    return T.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    t = T.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    return t if TWIN else t.cuda()
 
 
 def test_stft_mag_and_spec(T):
