@@ -5,7 +5,7 @@ import pytest
 
 from oracle import np_oracle as O
 from spatialaudiogen_amd.weights import variable_specs, init_weights
-from util import rms, rng, ensure_lib
+from util import rms, rng, ensure_lib, oracle_window
 
 pytestmark = pytest.mark.gpu
 
@@ -43,8 +43,9 @@ def test_deploy_matches_oracle(encoders, secs, duration):
     for g in range(0, len(rows), 10):
         grp = rows[g:g + 10]
         a = np.zeros((10, 52799, 1)); v = np.zeros((10, 1, 224, 448, 3)) if video is not None else None
-        for i, (t, start, pad, fi, _, _) in enumerate(grp):
-            a[i, :, 0] = audio_window(audio, t, 1.0, 52799, 48000)[:, 0]
+        for i, row in enumerate(grp):
+            fi = row[3]
+            a[i, :, 0] = oracle_window(audio, row)[:, 0]
             if v is not None:
                 v[i, 0] = video[fi]
         y = orc.inference_ops(a, P, video=v)
@@ -90,8 +91,9 @@ def test_deploy_cli_from_disk(tmp_path):
     rows = O.deploy_window_table(O.audio_pow_times(3), 0., 1.2)
     assert len(rows) == 7
     a = np.zeros((10, 52799, 1)); v = np.zeros((10, 1, 224, 448, 3))             # one group of 10: 7 real windows + 3 zero windows
-    for i, (t, start, pad, fi, _, _) in enumerate(rows):
-        a[i, :, 0] = audio_window(audio, t, 1.0, 52799, 48000)[:, 0]
+    for i, row in enumerate(rows):
+        fi = row[3]
+        a[i, :, 0] = oracle_window(audio, row)[:, 0]
         v[i, 0] = video[fi]
     y = O.SptAudioGenOracle(encoders=enc).inference_ops(a, P, video=v)
     ref = np.concatenate([a[:7, 24000:28800, :1], y[:7]], 2).reshape(-1, 4)

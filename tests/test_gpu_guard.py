@@ -12,7 +12,7 @@ import pytest
 
 from oracle import np_oracle as O
 from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
-from util import rms, rel_rms_err, ensure_lib
+from util import rms, rel_rms_err, ensure_lib, oracle_window
 
 pytestmark = pytest.mark.gpu
 
@@ -150,8 +150,9 @@ def test_deploy_cli_with_adversarial_batch_norm_parameters(T, tmp_path):
     for g0 in range(0, 15, 10):
         grp = rows[g0:g0 + 10]
         a = np.zeros((10, 52799, 1)); v = np.zeros((10, 1, 224, 448, 3))
-        for i, (t, start, pad, fi, _, _) in enumerate(grp):
-            a[i, :, 0] = audio_window(audio, t, 1.0, 52799, 48000)[:, 0]
+        for i, row in enumerate(grp):
+            fi = row[3]
+            a[i, :, 0] = oracle_window(audio, row)[:, 0]
             v[i, 0] = video[fi]
         y = orc.inference_ops(a, P, video=v)
         ref.append(np.concatenate([a[:len(grp), 24000:28800, :1], y[:len(grp)]], 2).reshape(-1, 4))

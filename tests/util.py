@@ -27,3 +27,14 @@ def ensure_lib():
         got, want = l.sagen_source_digest().decode(), build.source_digest()
         assert got == want, 'libsagen_hip.so was built from other sources (digest %s, tree %s): rebuild it' % (got, want)
     return l
+
+
+def oracle_window(audio, row, size=52799):
+    """One input window cut by the ORACLE's window table (oracle.np_oracle.deploy_window_table row: t, start_frame, pad_before,
+    frame_idx, batch_id, read_start) - not by the product's deploy.audio_window: `pad_before` zeros, then the samples from
+    `read_start`, zero-filled to `size` at the end of the clip.  audio [n, C]."""
+    pad_before, read_start = int(row[2]), int(row[5])
+    out = np.zeros((size, audio.shape[1]), audio.dtype)
+    chunk = audio[read_start:read_start + size - pad_before]
+    out[pad_before:pad_before + chunk.shape[0]] = chunk
+    return out
