@@ -593,21 +593,36 @@ def main():
                 if bool(((u8.double() / 255.0 - 0.5).float() == t).all()):
                     t = u8
             host.append(t.cpu().pin_memory())
-        devb = [[torch.empty_like(t, device='cuda') for t in host] for _ in range(NF)]
+        # one copy stream shared by the contexts (the link is serial anyway) and two device buffer sets per context: the copy of a
+        # context's next batch travels under its current forward (round 5; before, copy and forward of a batch were serial on the
+        # step's stream: 2 059 against 2 459 device-resident)
+        devb = [[[torch.empty_like(t, device='cuda') for t in host] for _ in range(2)] for _ in range(NF)]
+        copy_stream = torch.cuda.Stream()
+        ready = [[torch.cuda.Event() for _ in range(2)] for _ in range(NF)]
+        consumed = [[torch.cuda.Event() for _ in range(2)] for _ in range(NF)]
+        mb = sum(h.numel() * h.element_size() for h in host) / 1e6
+
+        def h2d_loop(n):
+            for i in range(n):
+                j, par = i % NF, (i // NF) % 2
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(consumed[j][par])          # (never recorded yet: no wait) the forward that last read this set is done
+                    for d_, h_ in zip(devb[j][par], host):
+                        d_.copy_(h_, non_blocking=True)
+                    ready[j][par].record(copy_stream)
+                st = streams[j] if NF > 1 else torch.cuda.current_stream()
+                with torch.cuda.stream(st):
+                    st.wait_event(ready[j][par])
+                    nets[j].inference_ops(*devb[j][par], out=outs[j])
+                    consumed[j][par].record(st)
+        h2d_loop(2 * NF)                                              # (touches every buffer set once)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(ks):
-            j = i % NF
-            ctx = torch.cuda.stream(streams[j]) if NF > 1 else torch.cuda.stream(torch.cuda.current_stream())
-            with ctx:
-                for d_, h_ in zip(devb[j], host):
-                    d_.copy_(h_, non_blocking=True)
-                nets[j].inference_ops(*devb[j], out=outs[j])
+        h2d_loop(ks)
         torch.cuda.synchronize()
-        mb = sum(h.numel() * h.element_size() for h in host) / 1e6
         extra['h2d_inclusive'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
-                                  'note': 'inputs start in pinned host memory (video frames as uint8, normalised on the device): %.1f MB copied per batch on the step stream, then the forward; '
-                                          '%d batches in flight, %d steps' % (mb, NF, ks)}
+                                  'note': 'inputs start in pinned host memory (video frames as uint8, normalised on the device): %.1f MB copied per batch on a copy stream into '
+                                          'the second of two device buffer sets while the previous batch of the context runs; %d batches in flight, %d steps' % (mb, NF, ks)}
 
     # ---- roofline of the dominant kernel: per-launch HIP events recorded by the native runtime on the
     #      launch stream (sagen_profile_*), three extra forwards outside the timed region ----
