@@ -379,7 +379,8 @@ def main():
 
     if args.in_flight > 1:
         # several batches in flight: each context stays on its caller's stream (the other batch is the overlap)
-        os.environ['SAGEN_ONE_STREAM'] = '1'
+        if not os.environ.get('BENCH_TWO_STREAM_CONTEXTS'):      # (experiment switch: keep each context's own second stream as well)
+            os.environ['SAGEN_ONE_STREAM'] = '1'
     import torch
     import torch.distributed as dist
     from spatialaudiogen_amd.model import SptAudioGen
