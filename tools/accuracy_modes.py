@@ -10,6 +10,10 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     from oracle.np_oracle import SptAudioGenOracle
     mode = 'fp32_only' if os.environ.get('SAGEN_FP32_ONLY') else ('bf16x3' if os.environ.get('SAGEN_NO_H2') else
             'bf16x3 + fp16x2 trunk planes from stage %s' % os.environ.get('SAGEN_P3_FROM_STAGE', '2 (default)'))
+    if os.environ.get('SAGEN_NO_DECONV_SCATTER'):
+        mode += ', round-4 decoder and trunk (no scatter form, no deconv1 planes, fp32 residuals)'
+    elif not os.environ.get('SAGEN_FP32_ONLY') and not os.environ.get('SAGEN_NO_H2'):
+        mode += ', round-5 decoder' + (' with the scatter GEMMs forced onto fp16x2 planes (the B >= 16 default)' if os.environ.get('ACC_DECODER_PLANES') else ' (B = 4: scatter GEMMs on fp32 operands, deconv1 on planes)')
     also_conv5 = True
     for enc in (['audio'], ['audio', 'video'], ['audio', 'video', 'flow']):
         for seed in (0, 1):
@@ -18,7 +22,11 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
             ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp.get('video'), flow=inp.get('flow'))
             net = SptAudioGen(1, encoders=enc, separation='unet_mask')
             net.load_variables(P)
-            out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow')).cpu().numpy().astype(np.float64)
+            out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow'))
+            if os.environ.get('ACC_DECODER_PLANES'):
+                net.set_option(4, 'decoder_planes', 1)
+                out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow'))
+            out = out.cpu().numpy().astype(np.float64)
             err = float(np.sqrt(np.mean((out - ref) ** 2))); rms = float(np.sqrt(np.mean(ref ** 2)))
             trunk = None
             if 'video' in enc:
@@ -28,6 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
             print(json.dumps({'mode': mode, 'trunk_conv5_2_rel_err': trunk, 'encoders': '+'.join(e[0].upper() for e in enc), 'seed': seed, 'rms_err': err,
                               'out_rms': rms, 'rel': err / rms, 'max_abs_err': float(np.abs(out - ref).max())}), flush=True)
 else:
-    for env in ({}, {'SAGEN_P3_FROM_STAGE': '3'}, {'SAGEN_NO_H2': '1'}, {'SAGEN_FP32_ONLY': '1'}):
+    for env in ({}, {'ACC_DECODER_PLANES': '1'}, {'SAGEN_NO_DECONV_SCATTER': '1', 'SAGEN_NO_DECONV1_PLANES': '1', 'SAGEN_NO_LEAN_TRUNK': '1'},
+                {'SAGEN_NO_H2': '1'}, {'SAGEN_FP32_ONLY': '1'}):
         e = dict(os.environ); e.update(env)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), 'child'], env=e)
