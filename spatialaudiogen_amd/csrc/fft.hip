@@ -86,9 +86,13 @@ __device__ __forceinline__ float2* fft1024(float2* a, float2* b, int tid) {
 // STFT: grid (ceil(nframes/2), B). hop 256, window 1024, periodic Hann.
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ audio, int n_samples, int f0, int f1,
-                                                   float* __restrict__ mag, int c0, int c1, float2* __restrict__ spec) {
+                                                   float* __restrict__ mag, int c0, int c1, float2* __restrict__ spec,
+                                                   float* __restrict__ zero_ptr, int zero_n) {
     __shared__ float2 bufA[1024], bufB[1024];
     const int tid = threadIdx.x;
+    // (the forward's first kernel on this stream also clears a small buffer for it - the maxima words of the decoder's concat
+    //  buffers - instead of a fill launch of its own)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < zero_n; i += gridDim.x * gridDim.y * 256) zero_ptr[i] = 0.f;
     const int b = blockIdx.y;
     const int fa = f0 + 2 * blockIdx.x, fb = fa + 1;
     const bool has_b = fb < f1;
@@ -125,14 +129,14 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ aud
 }
 
 int stft_launch(const float* audio, int B, int n_samples, int f0, int f1, float* mag, int c0, int c1, float* spec,
-                hipStream_t s) {
+                hipStream_t s, float* zero_ptr, int zero_n) {
     if (f1 <= f0 || 256L * (f1 - 1) + 1024 > n_samples)
         return fail(SAGEN_ERR_SHAPE, "stft: frames [%d,%d) do not fit %d samples", f0, f1, n_samples);
     if (spec && (c0 < f0 || c1 > f1 || c1 <= c0)) return fail(SAGEN_ERR_SHAPE, "stft: spec frames must lie in [f0,f1)");
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     hipLaunchKernelGGL(stft_kernel, dim3(cdiv(f1 - f0, 2), B), dim3(256), 0, s, audio, n_samples, f0, f1, mag, c0, c1,
-                       (float2*)spec);
+                       (float2*)spec, zero_ptr, zero_ptr ? zero_n : 0);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

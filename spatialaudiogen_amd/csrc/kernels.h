@@ -234,7 +234,7 @@ int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W
 int stempool_launch(const float* xpad, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
 // the stem for uint8 frames (stem8.hip): centred bf16 plane of the decoded frame, then conv + statistics + raw pool with one operand plane
 size_t stem8_plane_bytes(int B);
-int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s);
+int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr = nullptr, long zero_n = 0);   // zero_ptr: zero_n floats cleared by the same launch (the batch-norm accumulators)
 int stem8pool_launch(const void* plane, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
 int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats, int B, hipStream_t s);      // no pool: the raw output (training step)
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
@@ -287,7 +287,7 @@ int p3_maxpool_launch(const float* x, const float* scale, const float* shift, co
 // fills the twiddle / Hann tables once per device (first call synchronises the stream)
 int fft_tables_ensure(hipStream_t s);
 int stft_launch(const float* audio, int B, int n_samples, int f0, int f1, float* mag,
-                int c0, int c1, float* spec, hipStream_t s);
+                int c0, int c1, float* spec, hipStream_t s, float* zero_ptr = nullptr, int zero_n = 0);      // zero_ptr: zero_n floats cleared by the same launch
 // frames: scratch [B][NF][3][1024]; see fft.hip
 size_t mask_istft_scratch_bytes(int B);
 int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, const float* spec,

@@ -591,11 +591,12 @@ struct Fwd {
     const float* resnet(const float* img, const std::string& scope) {
         const int B = c->B;
         int li = 0;
-        if (!rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
-            rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
-        layer = scope + "/pad";
         // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
         const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode;
+        // the batch-norm accumulators start at zero: cleared by the trunk's first kernel where that is stem8_prep_kernel, else by a fill
+        if (!fast8 && !rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
+            rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
+        layer = scope + "/pad";
         const bool pool_planes = c->use_p3 && c->p3_from_stage <= 2;       // the pooled tensor is also wanted as planes (operand of conv2_1/conv_1)
         // Lean trunk (round 5): with fp16x2 planes from stage 2 on and the plane-fed stride-2 kernels, NOTHING reads a block output as
         // fp32 except the trunk's end: the merges read their identity residual from the block-input planes (in place: buffer "p3"
@@ -604,7 +605,8 @@ struct Fwd {
         const bool no_lean = c->no_lean_trunk;
         const bool lean = !no_lean && h2() && pool_planes && c->use_p3g && c->bufs.count("p3b" + sfx) != 0 && !c->train_mode;
         if (fast8)
-            timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s); });
+            timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s,
+                                                                          c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n); });
         else if (c->video_u8 && scope == "video_encoder")
             timed("pad_u8_nhwc3to4_kernel", 0.0, [&] { return pad_u8_nhwc3to4_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         else

@@ -470,11 +470,12 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     const bool dec_planes = !no_decp && c->B >= c->dec_planes_min_batch && !c->sk_fused && c->freq_mask && !c->train_mode && !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 &&
                             !c->no_scatter;
     const bool want_amax = d1_planes || dec_planes;
-    if (want_amax) SAGEN_HIP_CHECK(hipMemsetAsync(c->p("amax"), 0, (10 * H2_AMAX_FLOATS + 64) * sizeof(float), g.s));
+    // (the words are cleared by the STFT launch below - the first kernel of the stream that carries the audio chain - not by a fill)
 
     // ---- stream g: STFT (myutils.py:119-147) -> |.| of frames 46:173 (model.py:166-178) + spectrum of frames 89:117
     g.layer = "stft";
-    g.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), g.s); });
+    g.timed("stft_kernel", 0.0, [&] { return stft_launch(audio, B, c->snd_size, 46, 173, c->p("mag"), 89, 117, c->p("spec"), g.s,
+                                                         want_amax ? c->p("amax") : nullptr, 10 * H2_AMAX_FLOATS + 64); });
     if (forked) {
         // The LDS FFT kernels give wrong results when bf16x3 contraction waves of ANOTHER stream share their CUs
         // (open): the first matrix launch of the main stream waits for the STFT (it overlaps the pad kernel).

@@ -39,8 +39,10 @@ constexpr int S8_LDS = S8_W_BYTES + S8_CT_BYTES + 2 * 8 * S8_NH * 4 + S8_NH * 4;
 size_t stem8_plane_bytes(int B) { return (size_t)B * S8_UH * S8_UW * 8; }
 
 // uint8 frames [B,224,448,3] -> the centred plane [B,229,456,4] bf16: u - 128 inside, -0.5 (= x 0) in the border, 0 in channel 3
-__global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __restrict__ x, u32x2* __restrict__ plane, int B) {
+__global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __restrict__ x, u32x2* __restrict__ plane, int B,
+                                                         float* __restrict__ zero_ptr, long zero_n) {
     const long total = (long)B * S8_UH * S8_UW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero_ptr[i] = 0.f;     // (instead of a fill launch)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         long p = i;
         const int w = (int)(p % S8_UW) - 2; p /= S8_UW;
@@ -226,11 +228,11 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     }
 }
 
-int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s) {
+int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr, long zero_n) {
     if (!x || !plane) return fail(SAGEN_ERR_NULL, "stem8_prep: null argument");
     const long total = (long)B * S8_UH * S8_UW;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
-    hipLaunchKernelGGL(stem8_prep_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B);
+    hipLaunchKernelGGL(stem8_prep_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
