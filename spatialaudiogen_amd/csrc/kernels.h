@@ -236,6 +236,11 @@ int stempool_launch(const float* xpad, const float* wp, const float* gamma, floa
 size_t stem8_plane_bytes(int B);
 int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr = nullptr, long zero_n = 0);   // zero_ptr: zero_n floats cleared by the same launch (the batch-norm accumulators)
 int stem8pool_launch(const void* plane, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
+// float frames on the same kernel structure (stem8.hip, F16 variant): two fp16 planes of the frame scaled by its exact maximum
+int stem16_prep_launch(const float* x, void* planes, float* part, float* a_inv, int B, hipStream_t s, float* zero_ptr = nullptr, long zero_n = 0);
+int stem16pool_launch(const void* planes, const void* wh2, const float* gamma, float* pooled, double* stats, const float* a_inv, const float* w_inv,
+                      int B, hipStream_t s);
+constexpr int STEM16_PARTS = 1024;
 int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats, int B, hipStream_t s);      // no pool: the raw output (training step)
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);

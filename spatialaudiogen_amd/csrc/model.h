@@ -119,6 +119,7 @@ struct sagen_ctx {
     int dec_planes_min_batch = 16;         // the scatter-form decoder contracts fp16x2 planes from this batch size on (sagen_set_option("decoder_planes", 1 / 0): always / never)
     bool use_fcm = false;                  // inference: the skinny FC layers (bottleneck / localisation / fc-feats) run fcm_kernel (fcm.hip) chained through partials; SAGEN_NO_FCM=1: the round-4 contraction + reducer launches
     std::map<std::string, int> fcm_slices; // per FC layer: K slices of its fcm launch
+    bool stem16 = true;                    // float frames run the fp16x2 variant of that kernel (stem8.hip, F16: two planes of the frame scaled by its exact maximum); sagen_set_option("f16_fast_stem", 0) / SAGEN_NO_STEM16=1: igemm3s2_kernel + the pool pass
     bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels
     size_t tws_floats = 0;
     float* tws = nullptr;
@@ -593,8 +594,11 @@ struct Fwd {
         int li = 0;
         // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
         const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode;
-        // the batch-norm accumulators start at zero: cleared by the trunk's first kernel where that is stem8_prep_kernel, else by a fill
-        if (!fast8 && !rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
+        // float frames (the flow encoder; video handed over as float32): the same kernel on two fp16 planes of the frame (stem8.hip, F16)
+        const bool fast16 = !fast8 && !(c->video_u8 && scope == "video_encoder") && c->stem16 && !c->tuning && !c->fp32_only && !c->train_mode && h2() &&
+                            c->use_p3 && c->p3_from_stage <= 2 && c->bufs.count("s16:part" + sfx) != 0 && c->h2_slot.count(scope + "/conv1/conv") != 0;
+        // the batch-norm accumulators start at zero: cleared by the trunk's first kernel where that is stem8_prep / stem16_amax, else by a fill
+        if (!fast8 && !fast16 && !rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)
             rc = fail(SAGEN_ERR_HIP, "hipMemsetAsync(bn accumulators) failed");
         layer = scope + "/pad";
         const bool pool_planes = c->use_p3 && c->p3_from_stage <= 2;       // the pooled tensor is also wanted as planes (operand of conv2_1/conv_1)
@@ -604,7 +608,11 @@ struct Fwd {
         // copy of the pooled tensor.  The planes carry the value conv_1 saw (22 significant bits + the residual's sign).
         const bool no_lean = c->no_lean_trunk;
         const bool lean = !no_lean && h2() && pool_planes && c->use_p3g && c->bufs.count("p3b" + sfx) != 0 && !c->train_mode;
-        if (fast8)
+        float* const s16_a_inv = c->p("h2s") + 238 + (sfx.empty() ? 0 : 1);        // 2^-ka of the frame planes
+        if (fast16)
+            timed("stem16_amax_kernel+stem16_prep_kernel", 0.0, [&] { return stem16_prep_launch(img, c->p("xpad" + sfx), c->p("s16:part" + sfx), s16_a_inv, B, s,
+                                                                                               c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n); });
+        else if (fast8)
             timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s,
                                                                           c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n); });
         else if (c->video_u8 && scope == "video_encoder")
@@ -620,9 +628,14 @@ struct Fwd {
         {
             const std::string name = scope + "/conv1/conv";
             const bool fused = c->stem_fused && !c->tuning && !c->fp32_only && !(c->use_p3 && c->p3_from_stage <= 2);
-            if (fast8) {
+            if (fast8 || fast16) {
                 H = 112; W = 224;
                 layer = name + "+pool";
+                if (fast16)
+                    timed("stem8pool_kernel<f16>", 2.0 * B * H * W * 64 * 224, [&] {
+                        return stem16pool_launch(c->p("xpad" + sfx), c->p("pkh:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li),
+                                                 s16_a_inv, c->p("h2s") + c->h2_slot.at(name), B, s); });
+                else
                 timed("stem8pool_kernel", 2.0 * B * H * W * 64 * 224, [&] {
                     return stem8pool_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });
                 const BnRef bnf = bn_ref(li, name, (long)B * H * W);

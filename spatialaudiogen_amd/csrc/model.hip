@@ -37,6 +37,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     // (SAGEN_ONE_STREAM=1 hosts, bench.py) its one-workgroup-per-CU LDS footprint blocks co-residency and it is a wash (-0.3 %)
     c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
     c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
+    c->stem16 = getenv("SAGEN_NO_STEM16") == nullptr;
     c->use_h2 = getenv("SAGEN_NO_H2") == nullptr;
     c->train_h2 = getenv("SAGEN_TRAIN_NO_H2") == nullptr;
     c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
@@ -151,7 +152,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         // the 3x3 convs (and 1x1 projections) of the ResNet trunks also as two fp16 planes of w * 2^kw (conv3h.hip): N * Kpad * 2 halves
         // ... and deconv1 of the mask decoder (conv3g_kernel with the fused decoder tail on planes of cat1: sagen_forward_impl)
         if ((vs.ndim == 4 && ((vs.shape[0] == 3 && vs.shape[1] == 3) || (vs.shape[0] == 1 && vs.shape[1] == 1)) && vs.shape[2] % 16 == 0 &&
-             vs.name.find("_encoder/conv") != std::string::npos) || vs.name == "separation/deconv1/weights") {
+             vs.name.find("_encoder/conv") != std::string::npos) || vs.name == "separation/deconv1/weights" ||
+            (vs.ndim == 4 && vs.shape[2] == 3 && vs.name.find("_encoder/conv1/conv/weights") != std::string::npos)) {      // ... and the stem, for float frames (stem8.hip, F16)
             c->alloc("pkh:" + vs.name, n);
             h2_pack_blocks += n / 1024 + 1;
             c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = -1;
@@ -219,7 +221,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     for (int set = 0; set < 2; ++set) {
         const std::string x = set ? "_b" : "";
         if (set == 0 ? !(c->has_video || c->has_flow) : !(c->has_video && c->has_flow)) continue;   // "_b": flow trunk next to the video trunk
-        c->alloc("xpad" + x, (size_t)B * 229 * 454 * 4);
+        c->alloc("xpad" + x, (size_t)B * 229 * 456 * 4);      // zero-bordered 4-channel fp32 frame [229][454][4] | one bf16 plane [229][456][4] (uint8 frames) | two fp16 planes (float frames)
+        c->alloc("s16:part" + x, STEM16_PARTS + 64);
         c->alloc("y0" + x, (size_t)B * 112 * 224 * 64);
         const size_t stage = (size_t)B * 56 * 112 * 64;
         for (const char* nm : {"rx0", "rx1", "ry1", "ry2", "rsc", "ry1n"}) c->alloc(nm + x, stage);
@@ -394,6 +397,7 @@ int sagen_repack_part(sagen_ctx* c, hipStream_t s, int part) {
                 continue;
             }
             j.N = (int)vs->shape[3]; j.Kpad = (int)(vs->shape[0] * vs->shape[1] * vs->shape[2]);
+            if (vs->shape[2] == 3) j.Kpad = (int)(vs->shape[0] * (vs->shape[1] + 1) * 4);      // the stem's pack: tap rows padded 7 -> 8, channels 3 -> 4
             if (vs->name.find("/deconv") != std::string::npos) {      // depth-to-space pack: N = (ry, rx, o), K = (dp, dq, c)
                 const int l = vs->name[vs->name.find("/deconv") + 7] - '1';
                 j.N = AENC_S[l][0] * AENC_S[l][1] * (int)vs->shape[2];
@@ -825,6 +829,7 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     const std::string n = name;
     if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
+    if (n == "f16_fast_stem") { c->stem16 = value != 0; return SAGEN_OK; }
     if (n == "fp16x2") { c->use_h2 = value != 0; return SAGEN_OK; }
     if (n == "planes_from_stage") { if (value < 2 || value > 6) return fail(SAGEN_ERR_SHAPE, "planes_from_stage in 2..6"); c->p3_from_stage = value; return SAGEN_OK; }
     if (n == "decoder_planes") { c->dec_planes_min_batch = value ? 1 : (1 << 30); return SAGEN_OK; }

@@ -22,6 +22,7 @@
 // ds_read_b128 - in the space the raw tile occupies afterwards; raw tile -> LDS once, pooled with max or min per channel by the
 // sign of gamma (relu(bn(.)) is monotone per channel: stempool.hip), statistics over the 16 x 14 pixels the patch owns.
 #include "igemm3_common.h"
+#include "h2_planes.h"
 
 namespace sagen {
 
@@ -31,10 +32,11 @@ constexpr int S8_RW = 2 * S8_PW + 1;           // raw cols per patch (15)
 constexpr int S8_M = S8_RH * S8_RW;            // 255
 constexpr int S8_UH = 229, S8_UW = 456;        // plane geometry: 2 + 224 + 3 rows, 2 + 448 + 6 pixels per row (row pitch 3648 B = 16 * 228)
 constexpr int S8_NH = 32;                      // output channels per workgroup: the two halves of the 64 run as separate workgroups
-constexpr int S8_W_BYTES = 14 * 3 * S8_NH * 32;   // this half's filter planes [K/16][plane][n][16] bf16 (43 KB)
+constexpr int S8_W_BYTES = 14 * 3 * S8_NH * 32;   // this half's filter planes [K/16][plane][n][16] bf16 (43 KB; the fp16x2 variant: two planes, 29 KB)
 constexpr int S8_CT_BYTES = 256 * S8_NH * 4;   // raw tile [256][32] fp32
 constexpr int S8_THREADS = 512;
 constexpr int S8_LDS = S8_W_BYTES + S8_CT_BYTES + 2 * 8 * S8_NH * 4 + S8_NH * 4;   // 77.9 KB: TWO workgroups per CU - one pools while the other multiplies
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 
 size_t stem8_plane_bytes(int B) { return (size_t)B * S8_UH * S8_UW * 8; }
 
@@ -61,13 +63,20 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
 
 // RAW: no pool - the owned 16 x 14 raw outputs of every patch go to y0 [B,112,224,64] (the training step keeps the raw stem output for
 // the batch-norm backward and pools it in the pass that also writes the planes of the pooled tensor)
-template <bool RAW>
+// F16 (round 5): FLOAT frames (the flow encoder's input; video handed over as float32) on the same structure - the frame as TWO fp16
+// planes of x * 2^ka (ka from the exact maximum of the batch: stem16_prep), the filter as two fp16 planes of w * 2^kw: three products
+// per multiply on v_mfma_f32_32x32x16_f16 like conv3h_kernel, zero padding is a zero in the planes, the tile is scaled back by
+// 2^-(ka + kw).  Replaces igemm3s2_kernel (in-loop bf16x3 split, six products, 155 us) + the separate pool pass for such frames.
+template <bool RAW, bool F16 = false>
 __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
                                                                   const char* __restrict__ wplanes, const float* __restrict__ gamma,
-                                                                  float* __restrict__ pooled, double* __restrict__ stats, int B) {
+                                                                  float* __restrict__ pooled, double* __restrict__ stats, int B,
+                                                                  long plane_stride, const float* __restrict__ a_inv, const float* __restrict__ w_inv) {
+    constexpr int NPLA = F16 ? 2 : 1, NPLW = F16 ? 2 : 3;             // operand planes: activation, filter
+    constexpr int W_BYTES = 14 * NPLW * S8_NH * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wl = smem;
-    char* const pa = smem + S8_W_BYTES;                                                                 // the patch of the plane (K loop) ...
+    char* const pa = smem + S8_W_BYTES;                                                                 // the patch of the plane(s) (K loop) ...
     float* const ct = reinterpret_cast<float*>(smem + S8_W_BYTES);                                      // ... and the raw tile (epilogue) share this space
     float* const red = reinterpret_cast<float*>(smem + S8_W_BYTES + S8_CT_BYTES);                       // [2][8][32]
     float* const cb = reinterpret_cast<float*>(smem + S8_W_BYTES + S8_CT_BYTES + 2 * 8 * S8_NH * 4);    // [32]: (0.5 / 255) * sum_k W[n][k]
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     const int wg = blockIdx.x >> 1, nwg = gridDim.x >> 1;
 
     // this half's filter planes, once: global row ((ks*3 + pl)*64 + nh*32 + n) -> LDS row ((ks*3 + pl)*32 + n), 32 B each
-    for (int i = tid; i < S8_W_BYTES / 16; i += S8_THREADS) {
+    for (int i = tid; i < W_BYTES / 16; i += S8_THREADS) {
         const int row = i >> 1, hf = i & 1;
         const int kp = row >> 5, n = row & 31;
         // (the two 16-byte halves of a 32-byte row swapped in rows 8-15 / 24-31: lanes li and li + 8 of a fragment read would
@@ -88,9 +97,11 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     }
     if (tid < S8_NH) {
         double s = 0.0;
-        for (int k = 0; k < 224; ++k) s += (double)wf32[(nh * S8_NH + tid) * 224 + k];
-        cb[tid] = (float)(s * (0.5 / 255.0));
+        if (!F16)
+            for (int k = 0; k < 224; ++k) s += (double)wf32[(nh * S8_NH + tid) * 224 + k];
+        cb[tid] = (float)(s * (0.5 / 255.0));       // (float frames: zero padding IS zero, no constant term)
     }
+    const float osc = F16 ? a_inv[0] * w_inv[0] : 1.f / 255.f;
     const int pch4 = tid & 7;                        // pooling: this thread's 4 channels, max or min per channel
     bool use_min[4];
 #pragma unroll
@@ -115,7 +126,8 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     const int npatch = B * 7 * 16;
     constexpr int PROWS = 2 * (S8_RH - 1) + 7, PCH = (2 * (S8_RW - 1) + 8) / 2;     // 39 rows x 18 chunks (36 pixels)
     constexpr int NCHUNK = PROWS * PCH;                                             // 702
-    static_assert(NCHUNK <= 2 * S8_THREADS && PROWS * PCH * 16 <= S8_CT_BYTES, "patch staging");
+    constexpr int PATCH_BYTES = NCHUNK * 16;
+    static_assert(NCHUNK <= 2 * S8_THREADS && NPLA * PATCH_BYTES <= S8_CT_BYTES, "patch staging");
     const int ck0 = tid, ck1 = tid + S8_THREADS;
     const int cr0 = ck0 / PCH, cc0 = ck0 - cr0 * PCH, cr1 = ck1 / PCH, cc1 = ck1 - cr1 * PCH;
     auto patch_src = [&](int patch, int crow, int ccol) {
@@ -124,10 +136,14 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
         const int row = min(2 * 16 * pr + crow, S8_UH - 1);       // (rows past the plane only feed the raw row below the image, which is never pooled)
         return plane + (((long)b * S8_UH + row) * S8_UW + 2 * 14 * pc) * 8 + ccol * 16;
     };
-    f32x4 ld0 = f32x4{0.f, 0.f, 0.f, 0.f}, ld1 = ld0;
-    if (wg < npatch) {
-        ld0 = *reinterpret_cast<const f32x4*>(patch_src(wg, cr0, cc0));
-        if (ck1 < NCHUNK) ld1 = *reinterpret_cast<const f32x4*>(patch_src(wg, cr1, cc1));
+    f32x4 ld0[NPLA], ld1[NPLA];
+#pragma unroll
+    for (int p = 0; p < NPLA; ++p) {
+        ld0[p] = f32x4{0.f, 0.f, 0.f, 0.f}; ld1[p] = ld0[p];
+        if (wg < npatch) {
+            ld0[p] = *reinterpret_cast<const f32x4*>(patch_src(wg, cr0, cc0) + p * plane_stride);
+            if (ck1 < NCHUNK) ld1[p] = *reinterpret_cast<const f32x4*>(patch_src(wg, cr1, cc1) + p * plane_stride);
+        }
     }
     // this lane's raw pixel (row `li` of the wave's MFMA tile): byte offset of its K-step-0 fragment inside the LDS patch
     int aoff;
@@ -141,13 +157,19 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
         const int b = patch / 112, rem = patch - b * 112;
         const int pr = rem >> 4, pc = rem & 15;
         const int R0 = 16 * pr, C0 = 14 * pc;
-        reinterpret_cast<f32x4*>(pa)[ck0] = ld0;
-        if (ck1 < NCHUNK) reinterpret_cast<f32x4*>(pa)[ck1] = ld1;
+#pragma unroll
+        for (int p = 0; p < NPLA; ++p) {
+            reinterpret_cast<f32x4*>(pa + p * PATCH_BYTES)[ck0] = ld0[p];
+            if (ck1 < NCHUNK) reinterpret_cast<f32x4*>(pa + p * PATCH_BYTES)[ck1] = ld1[p];
+        }
         __syncthreads();
         const int next_patch = patch + nwg;
         if (next_patch < npatch) {                                // flies under this patch's K loop and epilogue
-            ld0 = *reinterpret_cast<const f32x4*>(patch_src(next_patch, cr0, cc0));
-            if (ck1 < NCHUNK) ld1 = *reinterpret_cast<const f32x4*>(patch_src(next_patch, cr1, cc1));
+#pragma unroll
+            for (int p = 0; p < NPLA; ++p) {
+                ld0[p] = *reinterpret_cast<const f32x4*>(patch_src(next_patch, cr0, cc0) + p * plane_stride);
+                if (ck1 < NCHUNK) ld1[p] = *reinterpret_cast<const f32x4*>(patch_src(next_patch, cr1, cc1) + p * plane_stride);
+            }
         }
         f32x16 acc[2];                               // no accumulator twice in a row
 #pragma unroll
@@ -157,21 +179,28 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
 #pragma unroll
         for (int ks = 0; ks < 14; ++ks) {
             // K step ks of raw pixel (r, c): the 8 bf16 at patch row 2r + ks/2, pixels 2c + 4 (ks & 1) + 2g, +1
-            const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + aoff + ((ks >> 1) * (2 * PCH) + (ks & 1) * 4) * 8);
-            bf16x8 fb[3];
+            bf16x8 fa[NPLA], fb[NPLW];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + ((ks * 3 + pl) * S8_NH + li) * 32 + 16 * (g ^ ((li >> 3) & 1)));
+            for (int p = 0; p < NPLA; ++p) fa[p] = *reinterpret_cast<const bf16x8*>(pa + p * PATCH_BYTES + aoff + ((ks >> 1) * (2 * PCH) + (ks & 1) * 4) * 8);
+#pragma unroll
+            for (int pl = 0; pl < NPLW; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + ((ks * NPLW + pl) * S8_NH + li) * 32 + 16 * (g ^ ((li >> 3) & 1)));
             const int a = ks & 1;                    // u' x W_lo, x W_mid, x W_hi on accumulators a, a^1, a | a^1, a, a^1 | ...
-            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[2], acc[a], 0, 0, 0);
-            acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[1], acc[a ^ 1], 0, 0, 0);
-            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[0], acc[a], 0, 0, 0);
+            if constexpr (F16) {                     // lo x hi, hi x lo, hi x hi (conv3h.hip)
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[NPLA - 1]), __builtin_bit_cast(f16x8s, fb[0]), acc[a], 0, 0, 0);
+                acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[0]), __builtin_bit_cast(f16x8s, fb[NPLW - 1]), acc[a ^ 1], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[0]), __builtin_bit_cast(f16x8s, fb[0]), acc[a], 0, 0, 0);
+            } else {
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[NPLW - 1], acc[a], 0, 0, 0);
+                acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[a ^ 1], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[a], 0, 0, 0);
+            }
         }
         __syncthreads();                       // every wave is done with the patch: its space becomes the raw tile
         // raw output = acc / 255 + (0.5 / 255) sum(W) -> LDS [pixel][32] + this lane's share of the statistics.
         // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float v = fmaf(acc[0][e] + acc[1][e], 1.f / 255.f, cbl);
+            const float v = fmaf(acc[0][e] + acc[1][e], osc, cbl);
             ct[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * S8_NH + li] = v;
             const float vo = ((own >> e) & 1u) ? v : 0.f;
             ssum += vo;
@@ -249,7 +278,7 @@ int stem8pool_launch(const void* plane, const float* wp, const float* gamma, flo
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
     hipLaunchKernelGGL(stem8pool_kernel<false>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
-                       pooled, stats, B);
+                       pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -265,7 +294,84 @@ int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
     hipLaunchKernelGGL(stem8pool_kernel<true>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
-                       (const float*)nullptr, y0, stats, B);
+                       (const float*)nullptr, y0, stats, B, 0L, (const float*)nullptr, (const float*)nullptr);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// ---- float frames (F16 variant): the batch's exact maximum, then the two fp16 planes ----
+constexpr int S16_PARTS = 1024;                   // per-workgroup partial maxima (no atomics, nothing to clear)
+__global__ __launch_bounds__(256) void stem16_amax_kernel(const float* __restrict__ x, long n4, float* __restrict__ part, float* __restrict__ zero_ptr, long zero_n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero_ptr[i] = 0.f;     // (the trunk's batch-norm accumulators)
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wave_max_f(m);
+    __shared__ float s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+// float frames [B,224,448,3] -> planes hi / lo [B,229,456,4] fp16 of x * 2^ka (max |x| * 2^ka in [512, 1024): exact bound), zero border,
+// zero channel 3; 2^-ka -> a_inv[0]
+__global__ __launch_bounds__(256) void stem16_prep_kernel(const float* __restrict__ x, u32x2* __restrict__ hi, u32x2* __restrict__ lo, int B,
+                                                          const float* __restrict__ part, float* __restrict__ a_inv) {
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < S16_PARTS; i += 64) m = fmaxf(m, part[i]);
+    m = wave_max_f(m);
+    const float sa = h2_scale_of_bound(m);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a_inv[0] = 1.f / sa;
+    const long total = (long)B * S8_UH * S8_UW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i;
+        const int w = (int)(p % S8_UW) - 2; p /= S8_UW;
+        const int h = (int)(p % S8_UH) - 2;
+        const int b = (int)(p / S8_UH);
+        unsigned short hh[3] = {0, 0, 0}, ll[3] = {0, 0, 0};
+        if ((unsigned)h < 224u && (unsigned)w < 448u) {
+            const float* src = x + (((long)b * 224 + h) * 448 + w) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = src[c] * sa;
+                const _Float16 a = __builtin_isfinite(v) ? (_Float16)v : __builtin_bit_cast(_Float16, (unsigned short)0x7e00);    // (a NaN stays one)
+                const _Float16 r = __builtin_isfinite(v) ? (_Float16)(v - (float)a) : (_Float16)0.f;
+                hh[c] = __builtin_bit_cast(unsigned short, a); ll[c] = __builtin_bit_cast(unsigned short, r);
+            }
+        }
+        hi[i] = u32x2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2]};
+        lo[i] = u32x2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2]};
+    }
+}
+
+// x: float frames [B,224,448,3]; planes: 2 * stem8_plane_bytes(B) bytes; part: S16_PARTS floats; a_inv: where 2^-ka goes;
+// zero_ptr / zero_n: a buffer the first launch clears on the way (the batch-norm accumulators)
+int stem16_prep_launch(const float* x, void* planes, float* part, float* a_inv, int B, hipStream_t s, float* zero_ptr, long zero_n) {
+    if (!x || !planes || !part || !a_inv) return fail(SAGEN_ERR_NULL, "stem16_prep: null argument");
+    const long n = (long)B * 224 * 448 * 3;
+    if (n % 4 || ((uintptr_t)x % 16)) return fail(SAGEN_ERR_UNSUPPORTED, "stem16_prep: the frames must be 16-byte aligned");
+    hipLaunchKernelGGL(stem16_amax_kernel, dim3(S16_PARTS), dim3(256), 0, s, x, n / 4, part, zero_ptr, zero_ptr ? zero_n : 0L);
+    const long total = (long)B * S8_UH * S8_UW;
+    char* p = reinterpret_cast<char*>(planes);
+    hipLaunchKernelGGL(stem16_prep_kernel, dim3((int)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(p),
+                       reinterpret_cast<u32x2*>(p + stem8_plane_bytes(B)), B, part, a_inv);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// planes: stem16_prep's output; wh2: the stem's filter as two fp16 planes [224/16][2][64][16] of w * 2^kw; a_inv / w_inv: the scales
+int stem16pool_launch(const void* planes, const void* wh2, const float* gamma, float* pooled, double* stats, const float* a_inv, const float* w_inv,
+                      int B, hipStream_t s) {
+    if (!planes || !wh2 || !gamma || !pooled || !stats || !a_inv || !w_inv) return fail(SAGEN_ERR_NULL, "stem16pool: null argument");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        attr_set = true;
+    }
+    const int npatch = B * 7 * 16;
+    hipLaunchKernelGGL((stem8pool_kernel<false, true>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
+                       (const float*)nullptr, reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, (long)stem8_plane_bytes(B), a_inv, w_inv);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -411,6 +411,8 @@ def test_uint8_video_entry_point(T):
     f32 = (u8 / 255. - 0.5).astype(np.float32)                      # feeder.img_prep_fcn on the decoded frame
     net = SptAudioGen(1, encoders=enc, separation='unet_mask')
     net.load_variables(P)
+    net.inference_ops(inp['audio'], f32)
+    net.set_option(B, 'f16_fast_stem', 0)                           # the general float-frame kernels (igemm3s2 + pool pass) for (a)
     a = net.inference_ops(inp['audio'], f32).cpu().numpy()
     net.set_option(B, 'u8_fast_stem', 0)
     b = net.inference_ops(inp['audio'], u8).cpu().numpy()
@@ -459,6 +461,45 @@ def test_uint8_stem_geometry_and_negative_gammas(T, B):
         ref = net.inference_ops(inp['audio'], f32).cpu().numpy()
         assert rel_rms_err(got, ref) < 1e-5
         assert rel_rms_err(trunk, net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('B,scale', [(1, 1.0), (5, 37.0), (32, 1.0)])
+def test_float_frame_stem_on_fp16x2_planes(T, B, scale):
+    """Float frames (the flow encoder's input; video handed over as float32) run the F16 variant of the fused stem kernel: the frame as
+    two fp16 planes scaled by the batch's exact maximum (stem8.hip).  Arbitrary float values (not images of uint8), a frame scale far
+    from 1, loud borders, negative / zero gammas, batch sizes that starve or crowd the persistent workgroups: against the oracle (small
+    batches) and against the general float-frame kernels (sagen_set_option 'f16_fast_stem' = 0) - and the kernel really ran."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=18 + B, mode='test')
+    g = P['video_encoder/conv1/conv/bn/gamma'].copy()
+    g[1::2] *= -1.0
+    g[6] = 0.0
+    P['video_encoder/conv1/conv/bn/gamma'] = g
+    inp = synth_inputs(B, enc, seed=61 + B)
+    r = np.random.Generator(np.random.PCG64(40 + B))
+    f32 = (scale * r.uniform(-0.5, 0.5, size=(B, 1, 224, 448, 3))).astype(np.float32)
+    f32[:, :, :3] = 0.5 * scale; f32[:, :, -3:] = -0.5 * scale; f32[:, :, :, :3] = -0.5 * scale; f32[:, :, :, -3:] = 0.5 * scale   # loud borders
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.profile_enable(B, True)
+    got = net.inference_ops(inp['audio'], f32).cpu().numpy()
+    kernels = {k for k, layer, us, fl in net.profile_report(B)}
+    net.profile_enable(B, False)
+    assert 'stem8pool_kernel<f16>' in kernels, kernels
+    trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    assert net.counter(B, 'fp16x2_saturations') == 0
+    net.set_option(B, 'f16_fast_stem', 0)
+    other = net.inference_ops(inp['audio'], f32).cpu().numpy()
+    trunk_o = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    assert not np.array_equal(got, other)
+    assert rel_rms_err(got, other) < 1e-5 and rel_rms_err(trunk, trunk_o) < 1e-5
+    if B <= 5:
+        orc = SptAudioGenOracle(encoders=enc)
+        ref = orc.inference_ops(inp['audio'], P, video=f32)
+        check_out(got, ref)
+        assert rel_rms_err(trunk, orc.ends['video_encoder/conv5_2']) < 1e-4
+        assert rms(got - ref) <= 1.5 * rms(other - ref) + 1e-7
 
 
 def test_fused_stem_pool_with_negative_gammas(T):
