@@ -92,11 +92,13 @@ size_t reduce_scratch_floats(int C) { return (size_t)RED_MAX_BLOCKS * 2 * ((C + 
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ ga, int lda, const float* __restrict__ gb, int ldb,
                                                        const float* __restrict__ act, int ldact, float* __restrict__ dy, int lddy,
-                                                       long n4, int C4, double* __restrict__ colsum, int C, float* __restrict__ part) {
+                                                       long n4, int C4, double* __restrict__ colsum, int C, float* __restrict__ part,
+                                                       long band_rows, long batch_rows, long row0) {
     const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
     float4 sum[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const long row = i / C4;
+        long row = i / C4;
+        if (band_rows) row = row / band_rows * batch_rows + row0 + row % band_rows;      // a band of rows per batch element: the rest is never touched
         float4 v = *reinterpret_cast<const float4*>(ga + row * lda + 4 * c4);
         if (gb) v = add4(v, *reinterpret_cast<const float4*>(gb + row * ldb + 4 * c4));
         if (act) {
@@ -119,13 +121,15 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 // sum finished inside the workgroup in a fixed order (the two-launch form above spends 12 + 5 us on a few KB).
 __global__ __launch_bounds__(256) void relu_bwd_small_kernel(const float* __restrict__ ga, int lda, const float* __restrict__ gb, int ldb,
                                                              const float* __restrict__ act, int ldact, float* __restrict__ dy, int lddy,
-                                                             int R, int C4, double* __restrict__ colsum, float* __restrict__ colsum_f32, int C) {
+                                                             int R, int C4, double* __restrict__ colsum, float* __restrict__ colsum_f32, int C,
+                                                             long band_rows, long batch_rows, long row0) {
     __shared__ float4 red[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c4 = blockIdx.x * 32 + cl;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < C4) {
-        for (int row = sl; row < R; row += 8) {
+        for (int r = sl; r < R; r += 8) {
+            const long row = band_rows ? (long)r / band_rows * batch_rows + row0 + (long)r % band_rows : (long)r;
             float4 v = *reinterpret_cast<const float4*>(ga + (long)row * lda + 4 * c4);
             if (gb) v = add4(v, *reinterpret_cast<const float4*>(gb + (long)row * ldb + 4 * c4));
             if (act) {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void relu_bwd_small_kernel(const float* __rest
 }
 
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
-                    int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32) {
+                    int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32, long band_rows, long batch_rows, long row0) {
     if (!ga || (!dy && !colsum)) return fail(SAGEN_ERR_NULL, "relu_bwd: null argument");
     const int Cp = (C + 3) / 4 * 4;
     if (lda % 4 || (gb && ldb % 4) || (act && ldact % 4) || (dy && lddy % 4) || lda < Cp)
@@ -162,14 +166,15 @@ int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const fl
     static const bool no_small = getenv("SAGEN_RELU_BWD_TWO_LAUNCHES") != nullptr;
     if (colsum && !no_small && n4 <= 32768 && R <= (1 << 20)) {
         hipLaunchKernelGGL(relu_bwd_small_kernel, dim3(cdiv(C4, 32)), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, (int)R, C4, colsum,
-                           colsum_f32, C);
+                           colsum_f32, C, band_rows, batch_rows, row0);
         SAGEN_LAUNCH_CHECK();
         return SAGEN_OK;
     }
     const bool fast = colsum && scratch && 256 % C4 == 0;
     if (colsum && !fast) SAGEN_HIP_CHECK(hipMemsetAsync(colsum, 0, (size_t)Cp * sizeof(double), s));
     const int grid = colsum ? reduce_grid(n4, C4) : aligned_grid(n4, C4);
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, n4, C4, colsum, C, fast ? scratch : nullptr);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid), dim3(256), 0, s, ga, lda, gb, ldb, act, ldact, dy, lddy, n4, C4, colsum, C, fast ? scratch : nullptr,
+                       band_rows, batch_rows, row0);
     SAGEN_LAUNCH_CHECK();
     if (fast) {
         hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(Cp, 8)), dim3(256), 0, s, scratch, grid, Cp, colsum, colsum_f32);

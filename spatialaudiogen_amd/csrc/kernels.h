@@ -234,7 +234,9 @@ int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W
 int stempool_launch(const float* xpad, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
 // the stem for uint8 frames (stem8.hip): centred bf16 plane of the decoded frame, then conv + statistics + raw pool with one operand plane
 size_t stem8_plane_bytes(int B);
-int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr = nullptr, long zero_n = 0);   // zero_ptr: zero_n floats cleared by the same launch (the batch-norm accumulators)
+int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr = nullptr, long zero_n = 0, int half = 0);   // half: fp16 plane (stem8pool_h2_launch)
+int stem8pool_h2_launch(const void* plane, const float* wp, const void* wh2, const float* w_inv, const float* gamma, float* pooled, double* stats, int B,
+                        hipStream_t s);    // uint8 frames, one fp16 plane x two fp16 filter planes: two products per multiply   // zero_ptr: zero_n floats cleared by the same launch (the batch-norm accumulators)
 int stem8pool_launch(const void* plane, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s);
 // float frames on the same kernel structure (stem8.hip, F16 variant): two fp16 planes of the frame scaled by its exact maximum
 int stem16_prep_launch(const float* x, void* planes, float* part, float* a_inv, int B, hipStream_t s, float* zero_ptr = nullptr, long zero_n = 0);
@@ -362,7 +364,8 @@ size_t reduce_scratch_floats(int C);
 // scratch >= reduce_scratch_floats(C) floats (without it, or for widths that do not divide 256 lanes: fp64 atomics)
 // colsum_f32 (nullable): the sums also as fp32 (the bias gradient at its place in the gradient bucket)
 int relu_bwd_launch(const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy, int lddy, long R,
-                    int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32 = nullptr);
+                    int C, double* colsum, float* scratch, hipStream_t s, float* colsum_f32 = nullptr,
+                    long band_rows = 0, long batch_rows = 0, long row0 = 0);      // band_rows > 0: row r stands for row (r / band_rows) * batch_rows + row0 + r % band_rows of every operand
 // training-mode batch-norm backward (core.py:6,209-210 under tf.gradients).  dz = (ga + gb) * (act > 0) (act nullable);
 // xhat = (y - mean) * invstd from the forward accumulators `bn`;  acc[2][C] (fp64) = (sum dz, sum dz*xhat) (overwritten);
 // scratch >= reduce_scratch_floats(C) floats

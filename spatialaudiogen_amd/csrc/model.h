@@ -115,10 +115,13 @@ struct sagen_ctx {
     std::vector<H2Job> h2_jobs;            // the batched fp16x2 filter pack (host copy of the job table)
     int h2_blocks = 0;
     bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
+    bool train_bands = true;               // the training step's decoder on the live rows only, forward and backward (SAGEN_TRAIN_NO_BANDS=1: full tensors)
+    int dec_lo[7] = {0, 0, 0, 0, 0, 0, 0}, dec_hi[7] = {0, 0, 0, 0, 0, 0, 0};      // rows of cat_l the last forward's decoder read (the backward of the same step follows them)
     bool no_scatter = false, no_d1_planes = false, no_lean_trunk = false;      // SAGEN_NO_DECONV_SCATTER / SAGEN_NO_DECONV1_PLANES / SAGEN_NO_LEAN_TRUNK, read when the context is created
     int dec_planes_min_batch = 16;         // the scatter-form decoder contracts fp16x2 planes from this batch size on (sagen_set_option("decoder_planes", 1 / 0): always / never)
     bool use_fcm = false;                  // inference: the skinny FC layers (bottleneck / localisation / fc-feats) run fcm_kernel (fcm.hip) chained through partials; SAGEN_NO_FCM=1: the round-4 contraction + reducer launches
     std::map<std::string, int> fcm_slices; // per FC layer: K slices of its fcm launch
+    bool stem8h = true;                    // uint8 frames: one fp16 plane x two fp16 filter planes (stem8.hip, MODE 2); sagen_set_option("u8_stem_h2", 0) / SAGEN_NO_STEM8_H2=1: the bf16 plane x three bf16 filter planes of round 4
     bool stem16 = true;                    // float frames run the fp16x2 variant of that kernel (stem8.hip, F16: two planes of the frame scaled by its exact maximum); sagen_set_option("f16_fast_stem", 0) / SAGEN_NO_STEM16=1: igemm3s2_kernel + the pool pass
     bool stem8 = true;                     // uint8 frames run the one-operand-plane stem (stem8.hip); sagen_set_option("u8_fast_stem", 0) / SAGEN_NO_STEM8=1: the general kernels
     size_t tws_floats = 0;
@@ -594,6 +597,8 @@ struct Fwd {
         int li = 0;
         // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
         const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode;
+        // ... with the filter as two fp16 planes where they exist: two products per multiply instead of three (stem8.hip, MODE 2)
+        const bool fast8h = fast8 && c->stem8h && h2() && c->h2_slot.count(scope + "/conv1/conv") != 0;
         // float frames (the flow encoder; video handed over as float32): the same kernel on two fp16 planes of the frame (stem8.hip, F16)
         const bool fast16 = !fast8 && !(c->video_u8 && scope == "video_encoder") && c->stem16 && !c->tuning && !c->fp32_only && !c->train_mode && h2() &&
                             c->use_p3 && c->p3_from_stage <= 2 && c->bufs.count("s16:part" + sfx) != 0 && c->h2_slot.count(scope + "/conv1/conv") != 0;
@@ -614,7 +619,7 @@ struct Fwd {
                                                                                                c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n); });
         else if (fast8)
             timed("stem8_prep_kernel", 0.0, [&] { return stem8_prep_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, s,
-                                                                          c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n); });
+                                                                          c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n, fast8h ? 1 : 0); });
         else if (c->video_u8 && scope == "video_encoder")
             timed("pad_u8_nhwc3to4_kernel", 0.0, [&] { return pad_u8_nhwc3to4_launch(reinterpret_cast<const unsigned char*>(img), c->p("xpad" + sfx), B, 224, 448, 2, 3, 2, 4, s); });
         else
@@ -635,6 +640,10 @@ struct Fwd {
                     timed("stem8pool_kernel<f16>", 2.0 * B * H * W * 64 * 224, [&] {
                         return stem16pool_launch(c->p("xpad" + sfx), c->p("pkh:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li),
                                                  s16_a_inv, c->p("h2s") + c->h2_slot.at(name), B, s); });
+                else if (fast8h)
+                    timed("stem8pool_kernel<h2>", 2.0 * B * H * W * 64 * 224, [&] {
+                        return stem8pool_h2_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->p("pkh:" + name + "/weights"), c->p("h2s") + c->h2_slot.at(name),
+                                                   c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });
                 else
                 timed("stem8pool_kernel", 2.0 * B * H * W * 64 * 224, [&] {
                     return stem8pool_launch(c->p("xpad" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("rx0" + sfx), bn_acc(li), B, s); });

@@ -38,12 +38,14 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->stem_fused = getenv("SAGEN_NO_STEMPOOL") == nullptr && (getenv("SAGEN_ONE_STREAM") == nullptr || getenv("SAGEN_STEMPOOL") != nullptr);
     c->stem8 = getenv("SAGEN_NO_STEM8") == nullptr;
     c->stem16 = getenv("SAGEN_NO_STEM16") == nullptr;
+    c->stem8h = getenv("SAGEN_NO_STEM8_H2") == nullptr;
     c->use_h2 = getenv("SAGEN_NO_H2") == nullptr;
     c->train_h2 = getenv("SAGEN_TRAIN_NO_H2") == nullptr;
     c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
     c->train_h2w = getenv("SAGEN_TRAIN_NO_H2W") == nullptr;
     c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
     c->no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
+    c->train_bands = getenv("SAGEN_TRAIN_NO_BANDS") == nullptr;
     c->no_d1_planes = getenv("SAGEN_NO_DECONV1_PLANES") != nullptr;
     c->no_lean_trunk = getenv("SAGEN_NO_LEAN_TRUNK") != nullptr;
     if (getenv("SAGEN_NO_DECODER_PLANES") != nullptr) c->dec_planes_min_batch = 1 << 30;
@@ -654,9 +656,10 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // stride-1 layers (5.4 of 15 taps of deconv5 land inside its 3x6 input), and the strided layers' depth-to-space form cannot split K.
     // Only rows 10..16 of cat1 reach deconv1's live grid rows (11..16, two vertical taps), hence only rows 4..8 of cat2 (deconv2's
     // taps) and rows 1..4 of cat3: each layer contracts the band of input rows it needs and gathers the output rows that are read.
-    // The training step (and SAGEN_FP32_ONLY) keep the round-4 form on the full tensors.
+    // SAGEN_FP32_ONLY keeps the round-4 form on the full tensors.  The training step follows the same bands, forward AND backward
+    // (train_model.hip: the dead rows carry no gradient; the buffers behind them are zeroed once, at sagen_train_bind).
     const bool no_scatter = c->no_scatter;
-    const bool lean = !c->train_mode && !c->fp32_only && !no_scatter;
+    const bool lean = (!c->train_mode || c->train_bands) && !c->fp32_only && !no_scatter;
     int need_lo[7], need_hi[7];                          // rows of cat_l that the layer below reads
     for (int l = 1; l <= 5; ++l) { need_lo[l] = 0; need_hi[l] = c->enc_h[l]; }
     if (lean) {
@@ -667,6 +670,7 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
             need_hi[l + 1] = std::min((need_hi[l] - 1) / sh + 1, c->enc_h[l + 1]);           // largest y with y*sh <= need_hi - 1
         }
     }
+    for (int l = 1; l <= 5; ++l) { c->dec_lo[l] = need_lo[l]; c->dec_hi[l] = need_hi[l]; }
     for (int l = 4; l >= 1; --l) {
         const int Cin = 2 * c->enc_c[l + 1];
         float* const am = want_amax ? f.cat_amax(l, 0) : nullptr;        // max |deconv(l+1)| = the decoder half of cat_l
@@ -830,6 +834,7 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
     if (n == "f16_fast_stem") { c->stem16 = value != 0; return SAGEN_OK; }
+    if (n == "u8_stem_h2") { c->stem8h = value != 0; return SAGEN_OK; }
     if (n == "fp16x2") { c->use_h2 = value != 0; return SAGEN_OK; }
     if (n == "planes_from_stage") { if (value < 2 || value > 6) return fail(SAGEN_ERR_SHAPE, "planes_from_stage in 2..6"); c->p3_from_stage = value; return SAGEN_OK; }
     if (n == "decoder_planes") { c->dec_planes_min_batch = value ? 1 : (1 << 30); return SAGEN_OK; }

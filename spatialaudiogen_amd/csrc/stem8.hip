@@ -41,6 +41,7 @@ typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 size_t stem8_plane_bytes(int B) { return (size_t)B * S8_UH * S8_UW * 8; }
 
 // uint8 frames [B,224,448,3] -> the centred plane [B,229,456,4] bf16: u - 128 inside, -0.5 (= x 0) in the border, 0 in channel 3
+template <bool HALF>      // HALF: the plane is fp16 (stem8pool_kernel MODE 2) instead of bf16 - the values are exact in both
 __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __restrict__ x, u32x2* __restrict__ plane, int B,
                                                          float* __restrict__ zero_ptr, long zero_n) {
     const long total = (long)B * S8_UH * S8_UW;
@@ -50,12 +51,18 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
         const int w = (int)(p % S8_UW) - 2; p /= S8_UW;
         const int h = (int)(p % S8_UH) - 2;
         const int b = (int)(p / S8_UH);
-        unsigned c0 = 0xBF00u, c1 = 0xBF00u, c2 = 0xBF00u;                    // bf16(-0.5)
+        unsigned c0 = HALF ? 0xB800u : 0xBF00u, c1 = c0, c2 = c0;             // -0.5 as fp16 / bf16
         if ((unsigned)h < 224u && (unsigned)w < 448u) {
             const unsigned char* src = x + (((long)b * 224 + h) * 448 + w) * 3;
-            c0 = __builtin_bit_cast(unsigned, (float)((int)src[0] - 128)) >> 16;   // |u - 128| <= 128: 8 significant bits, exact
-            c1 = __builtin_bit_cast(unsigned, (float)((int)src[1] - 128)) >> 16;
-            c2 = __builtin_bit_cast(unsigned, (float)((int)src[2] - 128)) >> 16;
+            if (HALF) {
+                c0 = __builtin_bit_cast(unsigned short, (_Float16)(float)((int)src[0] - 128));   // |u - 128| <= 128: 8 significant bits, exact
+                c1 = __builtin_bit_cast(unsigned short, (_Float16)(float)((int)src[1] - 128));
+                c2 = __builtin_bit_cast(unsigned short, (_Float16)(float)((int)src[2] - 128));
+            } else {
+                c0 = __builtin_bit_cast(unsigned, (float)((int)src[0] - 128)) >> 16;
+                c1 = __builtin_bit_cast(unsigned, (float)((int)src[1] - 128)) >> 16;
+                c2 = __builtin_bit_cast(unsigned, (float)((int)src[2] - 128)) >> 16;
+            }
         }
         plane[i] = u32x2{c0 | (c1 << 16), c2};
     }
@@ -67,12 +74,17 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
 // planes of x * 2^ka (ka from the exact maximum of the batch: stem16_prep), the filter as two fp16 planes of w * 2^kw: three products
 // per multiply on v_mfma_f32_32x32x16_f16 like conv3h_kernel, zero padding is a zero in the planes, the tile is scaled back by
 // 2^-(ka + kw).  Replaces igemm3s2_kernel (in-loop bf16x3 split, six products, 155 us) + the separate pool pass for such frames.
-template <bool RAW, bool F16 = false>
+// MODE 0: uint8 frames, one bf16 plane of u - 128 x three bf16 filter planes (round 4; the training step's raw variant)
+// MODE 1: float frames, two fp16 planes x two fp16 filter planes (three products)
+// MODE 2: uint8 frames, ONE fp16 plane of u - 128 (|u - 128| <= 128 and -0.5 are exact in fp16 as well) x two fp16 filter planes of
+//         w * 2^kw: TWO products per multiply instead of three - the operand is exact, the filter keeps 22 bits + its residual's sign
+template <bool RAW, int MODE = 0>
 __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
                                                                   const char* __restrict__ wplanes, const float* __restrict__ gamma,
                                                                   float* __restrict__ pooled, double* __restrict__ stats, int B,
                                                                   long plane_stride, const float* __restrict__ a_inv, const float* __restrict__ w_inv) {
-    constexpr int NPLA = F16 ? 2 : 1, NPLW = F16 ? 2 : 3;             // operand planes: activation, filter
+    constexpr bool F16 = MODE != 0;
+    constexpr int NPLA = MODE == 1 ? 2 : 1, NPLW = MODE == 0 ? 3 : 2;             // operand planes: activation, filter
     constexpr int W_BYTES = 14 * NPLW * S8_NH * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wl = smem;
@@ -97,11 +109,11 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     }
     if (tid < S8_NH) {
         double s = 0.0;
-        if (!F16)
+        if (MODE != 1)
             for (int k = 0; k < 224; ++k) s += (double)wf32[(nh * S8_NH + tid) * 224 + k];
         cb[tid] = (float)(s * (0.5 / 255.0));       // (float frames: zero padding IS zero, no constant term)
     }
-    const float osc = F16 ? a_inv[0] * w_inv[0] : 1.f / 255.f;
+    const float osc = MODE == 1 ? a_inv[0] * w_inv[0] : (MODE == 2 ? w_inv[0] * (1.f / 255.f) : 1.f / 255.f);
     const int pch4 = tid & 7;                        // pooling: this thread's 4 channels, max or min per channel
     bool use_min[4];
 #pragma unroll
@@ -185,7 +197,10 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
 #pragma unroll
             for (int pl = 0; pl < NPLW; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(wl + ((ks * NPLW + pl) * S8_NH + li) * 32 + 16 * (g ^ ((li >> 3) & 1)));
             const int a = ks & 1;                    // u' x W_lo, x W_mid, x W_hi on accumulators a, a^1, a | a^1, a, a^1 | ...
-            if constexpr (F16) {                     // lo x hi, hi x lo, hi x hi (conv3h.hip)
+            if constexpr (MODE == 2) {               // u' x W_lo, u' x W_hi: two products, alternating accumulators
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[0]), __builtin_bit_cast(f16x8s, fb[1]), acc[a], 0, 0, 0);
+                acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[0]), __builtin_bit_cast(f16x8s, fb[0]), acc[a ^ 1], 0, 0, 0);
+            } else if constexpr (F16) {              // lo x hi, hi x lo, hi x hi (conv3h.hip)
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[NPLA - 1]), __builtin_bit_cast(f16x8s, fb[0]), acc[a], 0, 0, 0);
                 acc[a ^ 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[0]), __builtin_bit_cast(f16x8s, fb[NPLW - 1]), acc[a ^ 1], 0, 0, 0);
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, fa[0]), __builtin_bit_cast(f16x8s, fb[0]), acc[a], 0, 0, 0);
@@ -257,11 +272,12 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     }
 }
 
-int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr, long zero_n) {
+int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s, float* zero_ptr, long zero_n, int half) {
     if (!x || !plane) return fail(SAGEN_ERR_NULL, "stem8_prep: null argument");
     const long total = (long)B * S8_UH * S8_UW;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
-    hipLaunchKernelGGL(stem8_prep_kernel, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L);
+    if (half) hipLaunchKernelGGL(stem8_prep_kernel<true>, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L);
+    else hipLaunchKernelGGL(stem8_prep_kernel<false>, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -279,6 +295,22 @@ int stem8pool_launch(const void* plane, const float* wp, const float* gamma, flo
     const int npatch = B * 7 * 16;
     hipLaunchKernelGGL(stem8pool_kernel<false>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
                        pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// MODE 2: plane = stem8_prep's fp16 plane (half = 1); wp = the packed fp32 filter (for the constant term), wh2 = its two fp16 planes, w_inv = 2^-kw
+int stem8pool_h2_launch(const void* plane, const float* wp, const void* wh2, const float* w_inv, const float* gamma, float* pooled, double* stats, int B,
+                        hipStream_t s) {
+    if (!plane || !wp || !wh2 || !w_inv || !gamma || !pooled || !stats) return fail(SAGEN_ERR_NULL, "stem8pool_h2: null argument");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        attr_set = true;
+    }
+    const int npatch = B * 7 * 16;
+    hipLaunchKernelGGL((stem8pool_kernel<false, 2>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp,
+                       reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, 0L, (const float*)nullptr, w_inv);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -366,11 +398,11 @@ int stem16pool_launch(const void* planes, const void* wh2, const float* gamma, f
     if (!planes || !wh2 || !gamma || !pooled || !stats || !a_inv || !w_inv) return fail(SAGEN_ERR_NULL, "stem16pool: null argument");
     static bool attr_set = false;
     if (!attr_set) {
-        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL((stem8pool_kernel<false, true>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
+    hipLaunchKernelGGL((stem8pool_kernel<false, 1>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
                        (const float*)nullptr, reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, (long)stem8_plane_bytes(B), a_inv, w_inv);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;

@@ -287,13 +287,15 @@ struct Bwd : Fwd {
     }
 
     // dy = (ga + gb) * (act > 0); with `bias_var` also the bias gradient sum_rows dy
+    // band_rows > 0: only rows [row0, row0 + band_rows) of each batch element's batch_rows (R = B * band_rows); the rest of dy is not touched
     void relu_bwd(const std::string& label, const float* ga, int lda, const float* gb, int ldb, const float* act, int ldact, float* dy,
-                  int lddy, long R, int C, const std::string& bias_var) {
+                  int lddy, long R, int C, const std::string& bias_var, long band_rows = 0, long batch_rows = 0, long row0 = 0) {
         if (rc) return;
         layer = label;
         double* acc = bias_var.empty() ? nullptr : cacc_next();
         if (rc) return;
-        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p(redws), s, acc ? grad(bias_var) : nullptr); });
+        timed("relu_bwd_kernel", 0.0, [&] { return relu_bwd_launch(ga, lda, gb, ldb, act, ldact, dy, lddy, R, C, acc, c->p(redws), s, acc ? grad(bias_var) : nullptr,
+                                                                   band_rows, batch_rows, row0); });
     }
 
     WgradDesc wdesc(const float* g, int HG, int WG, int ldg, int Cg, const float* dd, int Hd, int Wd, int ldd, int Cd, int kh, int kw,
@@ -611,13 +613,42 @@ struct Bwd : Fwd {
             const int Cn = 2 * c->enc_c[l + 1], Hn = c->enc_h[l + 1], Wn = c->enc_w[l + 1];
             const float* dcat = c->p("t:dcat" + std::to_string(l));
             float* dyd = c->p("t:dydec" + std::to_string(l));
-            relu_bwd("relu:" + name, dcat, 2 * C, nullptr, 0, c->p("cat" + std::to_string(l)), 2 * C, dyd, C, (long)B * H * W, C, name + "/biases");
-            wgrad("wgrad:" + name, wdesc(dyd, H, W, C, C, c->p("cat" + std::to_string(l + 1)), Hn, Wn, Cn, Cn, AENC_K[l][0], AENC_K[l][1],
-                                         AENC_S[l][0], AENC_S[l][1], 0, 0), grad(name + "/weights"));
+            const int kh = AENC_K[l][0], sh = AENC_S[l][0];
+            // The forward of this step read rows [lo, hi) of cat_l (model.hip: only those reach the cropped window) from rows [lon, hin) of
+            // cat_(l+1): outside them the gradient is exactly zero.  The ReLU pass writes the band of d(deconv output), the two contractions
+            // run over the band's rows of cat_(l+1), and the rows they never write keep the zeros of sagen_train_bind.
+            const int lo = c->dec_lo[l], hi = c->dec_hi[l], lon = c->dec_lo[l + 1], hin = c->dec_hi[l + 1];
+            const bool band = (lo > 0 || hi < H || lon > 0 || hin < Hn) && hi > lo && hin > lon;
+            if (!band) {
+                relu_bwd("relu:" + name, dcat, 2 * C, nullptr, 0, c->p("cat" + std::to_string(l)), 2 * C, dyd, C, (long)B * H * W, C, name + "/biases");
+                wgrad("wgrad:" + name, wdesc(dyd, H, W, C, C, c->p("cat" + std::to_string(l + 1)), Hn, Wn, Cn, Cn, AENC_K[l][0], AENC_K[l][1],
+                                             AENC_S[l][0], AENC_S[l][1], 0, 0), grad(name + "/weights"));
+                int Ho, Wo;
+                IgemmDesc d = conv_desc(dyd, H, W, C, C, c->p("pkd:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1], AENC_S[l][0], AENC_S[l][1],
+                                        false, Cn, c->p("t:dcat" + std::to_string(l + 1)), Cn, Ho, Wo);
+                if (Ho != Hn || Wo != Wn) { rc = fail(SAGEN_ERR_SHAPE, "deconv%d backward geometry", l + 1); return; }
+                layer = "dgrad:" + name;
+                contract(d);
+                continue;
+            }
+            const int Hb = hin - lon;                         // rows of cat_(l+1) in the band
+            const int g0 = lon * sh;                          // ... whose taps start at this row of d(deconv output)
+            const int Hgb = (Hb - 1) * sh + kh;               // ... and span this many rows (all inside the tensor: the encoder's conv was VALID)
+            if (g0 > lo || g0 + Hgb < hi || g0 + Hgb > H) { rc = fail(SAGEN_ERR_SHAPE, "deconv%d backward band", l + 1); return; }
+            relu_bwd("relu:" + name, dcat, 2 * C, nullptr, 0, c->p("cat" + std::to_string(l)), 2 * C, dyd, C, (long)B * (hi - lo) * W, C, name + "/biases",
+                     (long)(hi - lo) * W, (long)H * W, (long)lo * W);
+            const float* gband = dyd + (size_t)g0 * W * C;
+            const float* xband = c->p("cat" + std::to_string(l + 1)) + (size_t)lon * Wn * Cn;
+            WgradDesc w = wdesc(gband, Hgb, W, C, C, xband, Hb, Wn, Cn, Cn, AENC_K[l][0], AENC_K[l][1], AENC_S[l][0], AENC_S[l][1], 0, 0);
+            w.g_bstride = (unsigned)((long)H * W * C);
+            w.d_bstride = (unsigned)((long)Hn * Wn * Cn);
+            wgrad("wgrad:" + name, w, grad(name + "/weights"));
             int Ho, Wo;
-            IgemmDesc d = conv_desc(dyd, H, W, C, C, c->p("pkd:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1], AENC_S[l][0], AENC_S[l][1],
-                                    false, Cn, c->p("t:dcat" + std::to_string(l + 1)), Cn, Ho, Wo);
-            if (Ho != Hn || Wo != Wn) { rc = fail(SAGEN_ERR_SHAPE, "deconv%d backward geometry", l + 1); return; }
+            IgemmDesc d = conv_desc(gband, Hgb, W, C, C, c->p("pkd:" + name + "/weights"), AENC_K[l][0], AENC_K[l][1], AENC_S[l][0], AENC_S[l][1],
+                                    false, Cn, c->p("t:dcat" + std::to_string(l + 1)) + (size_t)lon * Wn * Cn, Cn, Ho, Wo);
+            if (Ho != Hb || Wo != Wn) { rc = fail(SAGEN_ERR_SHAPE, "deconv%d backward geometry (band)", l + 1); return; }
+            d.x_bstride = (long)H * W * C;
+            d.y_bstride = (long)Hn * Wn * Cn;
             layer = "dgrad:" + name;
             contract(d);
         }
@@ -741,8 +772,9 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
     c->grad_ptr = gp;
     c->mov_ptr = mp;
     // buffers whose untouched parts must be zero: the border rows of d(mask), the pad column of d(coeffs), the dead rows of d(cat1)
-    for (const char* nm : {"t:ddmask", "t:dcoeffs", "t:dcat1"})
-        SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
+    // ... and of d(cat2..5) / d(deconv5..2 outputs) (the decoder's bands)
+    for (const char* nm : {"t:ddmask", "t:dcoeffs", "t:dcat1", "t:dcat2", "t:dcat3", "t:dcat4", "t:dcat5", "t:dydec1", "t:dydec2", "t:dydec3", "t:dydec4"})
+        if (c->tbufs.count(nm)) SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));
     // ... and the three output phases a 1x1 stride-2 shortcut never reaches (its phase-wise data gradient only writes phase (0, 0))
     for (const char* nm : {"t:S1", "t:S2", "t:S3", "t:S1_b", "t:S2_b", "t:S3_b"})
         if (c->tbufs.count(nm)) SAGEN_HIP_CHECK(hipMemsetAsync(c->p(nm), 0, c->tbufs.at(nm).n * sizeof(float), s));

@@ -450,13 +450,28 @@ def test_uint8_stem_geometry_and_negative_gammas(T, B):
     f32 = (u8 / 255. - 0.5).astype(np.float32)
     net = SptAudioGen(1, encoders=enc, separation='unet_mask')
     net.load_variables(P)
+    net.profile_enable(B, True)
     got = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
+    kernels = {k for k, layer, us, fl in net.profile_report(B)}
     trunk = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    # default (round 5): ONE fp16 plane of u - 128 x TWO fp16 filter planes; 'u8_stem_h2' = 0: the bf16 plane x three bf16 filter planes
+    assert 'stem8pool_kernel<h2>' in kernels, kernels
+    net.set_option(B, 'u8_stem_h2', 0)
+    got3 = net.inference_ops(inp['audio'], T.as_tensor(u8).cuda()).cpu().numpy()
+    kernels3 = {k for k, layer, us, fl in net.profile_report(B)}
+    net.profile_enable(B, False)
+    trunk3 = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()
+    assert 'stem8pool_kernel' in kernels3 and 'stem8pool_kernel<h2>' not in kernels3, kernels3
+    assert not np.array_equal(got, got3) and rel_rms_err(got, got3) < 1e-5 and rel_rms_err(trunk, trunk3) < 1e-5
+    net.set_option(B, 'u8_stem_h2', 1)
     if B <= 5:
         orc = SptAudioGenOracle(encoders=enc)
         ref = orc.inference_ops(inp['audio'], P, video=f32)
         check_out(got, ref)
+        check_out(got3, ref)
         assert rel_rms_err(trunk, orc.ends['video_encoder/conv5_2']) < 1e-4
+        assert rel_rms_err(trunk3, orc.ends['video_encoder/conv5_2']) < 1e-4
+        assert rms(got - ref) <= 1.5 * rms(got3 - ref) + 1e-7, (rms(got - ref), rms(got3 - ref))
     else:                                                           # full size: against the general kernels on the float frames
         ref = net.inference_ops(inp['audio'], f32).cpu().numpy()
         assert rel_rms_err(got, ref) < 1e-5
@@ -539,7 +554,7 @@ def test_fused_stem_pool_with_negative_gammas(T):
 
 
 def test_full_benchmark_batch_of_uint8_frames_against_the_independent_cpu_reference(T):
-    """The headline's exact kernel set - sagen_forward_u8 -> stem8pool_kernel on ONE operand plane - at its real size (32 windows)
+    """The headline's exact kernel set - sagen_forward_u8 -> stem8pool_kernel on ONE fp16 operand plane x two fp16 filter planes - at its real size (32 windows)
     directly against oracle/torch_ref.py in fp64 (it was held against the float-frame kernels only, a two-link chain)."""
     import torch
     from oracle.torch_ref import TorchRef
@@ -558,7 +573,7 @@ def test_full_benchmark_batch_of_uint8_frames_against_the_independent_cpu_refere
     got = net.inference_ops(inp['audio'], u8).cpu().numpy()
     kernels = {k for k, layer, us, fl in net.profile_report(B)}
     net.profile_enable(B, False)
-    assert 'stem8pool_kernel' in kernels, kernels
+    assert 'stem8pool_kernel<h2>' in kernels, kernels
     check_out(got, ref)
     assert net.counter(B, 'fp16x2_saturations') == 0
 
