@@ -243,7 +243,8 @@ int stem16_prep_launch(const float* x, void* planes, float* part, float* a_inv, 
 int stem16pool_launch(const void* planes, const void* wh2, const float* gamma, float* pooled, double* stats, const float* a_inv, const float* w_inv,
                       int B, hipStream_t s);
 constexpr int STEM16_PARTS = 1024;
-int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats, int B, hipStream_t s);      // no pool: the raw output (training step)
+int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats, int B, hipStream_t s);
+int stem8rawpool_launch(const void* plane, const float* wp, const float* gamma, float* y0, float* pooled, double* stats, int B, hipStream_t s);   // raw output AND its 3x3/2 pool (max, or min where gamma < 0) in one kernel      // no pool: the raw output (training step)
 int assemble_wyzx_launch(const float* audio, const float* yzx, float* out, int B, int snd_size,
                          int snd_contx, int snd_dur, hipStream_t s);
 int power_map_launch(const float* ambi, long T, const float* sh, int P, float* rms, hipStream_t s);

@@ -857,7 +857,18 @@ struct Fwd {
         }
         {
             const std::string name = scope + "/conv1/conv";
-            if (fast8) {
+            // ... and, where the pooled tensor goes on as planes, the pool of the raw output in the same kernel (max, or min where gamma < 0:
+            // relu(bn(.)) is monotone per channel, so BN + ReLU of the pooled raw tensor IS maxpool(relu(bn(y0))), bit for bit) - the pool
+            // pass no longer reads the 205 MB raw tensor a second time
+            static const bool no_rawpool = getenv("SAGEN_TRAIN_NO_RAWPOOL") != nullptr;
+            const bool rawpool = fast8 && keep && !no_rawpool && c->bufs.count("rx0" + sfx) != 0;
+            if (rawpool) {
+                H = 112; W = 224;
+                layer = name;
+                timed("stem8pool_kernel<raw+pool>", 2.0 * B * H * W * 64 * 224, [&] {
+                    return stem8rawpool_launch(c->p("t:s8plane" + sfx), c->p("pk:" + name + "/weights"), c->v(name + "/bn/gamma"), c->p("y0" + sfx), c->p("rx0" + sfx),
+                                               bn_acc(li), B, s); });
+            } else if (fast8) {
                 H = 112; W = 224;
                 layer = name;
                 timed("stem8pool_kernel<raw>", 2.0 * B * H * W * 64 * 224, [&] {
@@ -870,7 +881,12 @@ struct Fwd {
                 contract(d);
             }
             const BnRef bn = bn_ref(li, name, (long)B * H * W);
-            if (keep) {                         // the pooled block input also as (retained) planes: stage 2 runs on planes as well
+            if (rawpool) {
+                P3hScale hs0 = h2_scale(h2_xbound(0));
+                hs0.a_inv = pl_a_inv(8);
+                layer = name + "/bn-relu";
+                timed("p3_pack_kernel", 0.0, [&] { return p3_pack_launch(c->p("rx0" + sfx), nullptr, nullptr, bn, nullptr, 1, c->p("t:x0" + sfx), pl_buf("x", 0), B, 56, 112, 64, s, 1, &hs0); });
+            } else if (keep) {                         // the pooled block input also as (retained) planes: stage 2 runs on planes as well
                 P3hScale hs0 = h2_scale(h2_xbound(0));
                 hs0.a_inv = pl_a_inv(8);
                 timed("p3_maxpool_kernel", 0.0, [&] { return p3_maxpool_launch(c->p("y0" + sfx), nullptr, nullptr, bn, c->p("t:x0" + sfx), pl_buf("x", 0), B, H, W, 64, s, 1, &hs0); });

@@ -78,11 +78,14 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
 // MODE 1: float frames, two fp16 planes x two fp16 filter planes (three products)
 // MODE 2: uint8 frames, ONE fp16 plane of u - 128 (|u - 128| <= 128 and -0.5 are exact in fp16 as well) x two fp16 filter planes of
 //         w * 2^kw: TWO products per multiply instead of three - the operand is exact, the filter keeps 22 bits + its residual's sign
-template <bool RAW, int MODE = 0>
+// OUT 0: pooled raw output; 1: the raw output itself (into `pooled`); 2: both - raw into `raw2`, pooled raw into `pooled` (the training
+// step: the backward keeps the raw tensor, and the pool no longer re-reads its 205 MB in a pass of its own)
+template <int OUT, int MODE = 0>
 __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
                                                                   const char* __restrict__ wplanes, const float* __restrict__ gamma,
                                                                   float* __restrict__ pooled, double* __restrict__ stats, int B,
-                                                                  long plane_stride, const float* __restrict__ a_inv, const float* __restrict__ w_inv) {
+                                                                  long plane_stride, const float* __restrict__ a_inv, const float* __restrict__ w_inv,
+                                                                  float* __restrict__ raw2) {
     constexpr bool F16 = MODE != 0;
     constexpr int NPLA = MODE == 1 ? 2 : 1, NPLW = MODE == 0 ? 3 : 2;             // operand planes: activation, filter
     constexpr int W_BYTES = 14 * NPLW * S8_NH * 32;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     const int pch4 = tid & 7;                        // pooling: this thread's 4 channels, max or min per channel
     bool use_min[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) use_min[k] = RAW ? false : gamma[nh * S8_NH + 4 * pch4 + k] < 0.f;
+    for (int k = 0; k < 4; ++k) use_min[k] = OUT == 1 ? false : gamma[nh * S8_NH + 4 * pch4 + k] < 0.f;
     // statistics straight from the accumulators: which of this lane's 16 tile rows are pixels the patch OWNS (16 x 14 of the 17 x 15;
     // the halo row / column belongs to the neighbour) - the same for every patch
     unsigned own = 0;
@@ -222,17 +225,18 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
             ssq = fmaf(vo, vo, ssq);
         }
         __syncthreads();
-        if (RAW) {
+        if (OUT >= 1) {
             // the patch's own pixels, 128 contiguous bytes (this half's 32 channels) per pixel
+            float* const raw = OUT == 2 ? raw2 : pooled;
             for (int it = tid; it < 2 * S8_PH * 2 * S8_PW * 8; it += S8_THREADS) {
                 const int p = it >> 3, q4 = it & 7;
                 const int r = p / (2 * S8_PW), cc = p - r * (2 * S8_PW);
-                *reinterpret_cast<float4*>(pooled + (((long)b * 112 + R0 + r) * 224 + C0 + cc) * 64 + nh * S8_NH + 4 * q4) =
+                *reinterpret_cast<float4*>(raw + (((long)b * 112 + R0 + r) * 224 + C0 + cc) * 64 + nh * S8_NH + 4 * q4) =
                     *reinterpret_cast<const float4*>(ct + (r * S8_RW + cc) * S8_NH + 4 * q4);
             }
-        } else
+        }
         // pool 3x3 / 2 (TF SAME: nothing before, one row / column after -> clipped at the image edge): one item per thread
-        if (tid < S8_PH * S8_PW * 8) {
+        if (OUT != 1 && tid < S8_PH * S8_PW * 8) {
             const int p = tid >> 3;
             const int pr_l = p / S8_PW, pc_l = p - pr_l * S8_PW;
             float4 v[9];
@@ -288,13 +292,13 @@ int stem8pool_launch(const void* plane, const float* wp, const float* gamma, flo
     if (!plane || !wp || !gamma || !pooled || !stats) return fail(SAGEN_ERR_NULL, "stem8pool: null argument");
     static bool attr_set = false;
     if (!attr_set) {
-        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel<false>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
-                       pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(stem8pool_kernel<0>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
+                       pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -305,12 +309,12 @@ int stem8pool_h2_launch(const void* plane, const float* wp, const void* wh2, con
     if (!plane || !wp || !wh2 || !w_inv || !gamma || !pooled || !stats) return fail(SAGEN_ERR_NULL, "stem8pool_h2: null argument");
     static bool attr_set = false;
     if (!attr_set) {
-        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL((stem8pool_kernel<false, 2>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp,
-                       reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, 0L, (const float*)nullptr, w_inv);
+    hipLaunchKernelGGL((stem8pool_kernel<0, 2>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp,
+                       reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, 0L, (const float*)nullptr, w_inv, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -320,13 +324,29 @@ int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats
     if (!plane || !wp || !y0 || !stats) return fail(SAGEN_ERR_NULL, "stem8raw: null argument");
     static bool attr_set = false;
     if (!attr_set) {
-        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel<true>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
-                       (const float*)nullptr, y0, stats, B, 0L, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(stem8pool_kernel<1>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
+                       (const float*)nullptr, y0, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    SAGEN_LAUNCH_CHECK();
+    return SAGEN_OK;
+}
+
+// ... with the pool as well: y0 = the raw stem output, pooled [B,56,112,64] = its 3x3/2 max (min where gamma < 0), one kernel
+int stem8rawpool_launch(const void* plane, const float* wp, const float* gamma, float* y0, float* pooled, double* stats, int B, hipStream_t s) {
+    if (!plane || !wp || !gamma || !y0 || !pooled || !stats) return fail(SAGEN_ERR_NULL, "stem8rawpool: null argument");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        attr_set = true;
+    }
+    const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
+    const int npatch = B * 7 * 16;
+    hipLaunchKernelGGL(stem8pool_kernel<2>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
+                       gamma, pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, y0);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -398,12 +418,12 @@ int stem16pool_launch(const void* planes, const void* wh2, const float* gamma, f
     if (!planes || !wh2 || !gamma || !pooled || !stats || !a_inv || !w_inv) return fail(SAGEN_ERR_NULL, "stem16pool: null argument");
     static bool attr_set = false;
     if (!attr_set) {
-        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
+        SAGEN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stem8pool_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, S8_LDS));
         attr_set = true;
     }
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL((stem8pool_kernel<false, 1>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
-                       (const float*)nullptr, reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, (long)stem8_plane_bytes(B), a_inv, w_inv);
+    hipLaunchKernelGGL((stem8pool_kernel<0, 1>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
+                       (const float*)nullptr, reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, (long)stem8_plane_bytes(B), a_inv, w_inv, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
