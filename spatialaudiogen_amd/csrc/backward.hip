@@ -593,6 +593,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float4* __restri
     if (MODE == 1) channel_partials<2>(sum, C4, part);
 }
 
+// The first pass of maxpool_bn_bwd on the POOLED grid (round 5): every window routes its gradient to its extremum, whose raw value the
+// training forward now keeps (stem8pool_kernel<raw+pool>: `praw` = max, or min where gamma < 0, of the raw stem output over the
+// window; relu(bn(praw)) IS the pooled activation) - so sum dz and sum dz * xhat are sums over the windows: 4 x 51 MB read instead of the
+// 205 MB raw tensor plus its 2x2 gathers.  (An exact float tie inside a window is credited once here and twice by the gather of the second
+// pass - both measure-zero deviations from TF's first-in-scan-order rule, ~1e-6 of the sums.)
+__global__ __launch_bounds__(256) void pool_bn_reduce_kernel(const float4* __restrict__ praw, const BnRef bn, const float4* __restrict__ ga,
+                                                             const float4* __restrict__ gb, long total, int C4, float* __restrict__ part) {
+    const int C = 4 * C4;
+    const int c4 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % C4);
+    float4 sc, sh, mean, invstd;
+    bn_forward_coeffs4(bn, C, c4, sc, sh);
+    bn_moments4(bn, C, c4, mean, invstd);
+    float4 sum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const float4 v = praw[idx];
+        float4 g = ga[idx];
+        if (gb) g = add4(g, gb[idx]);
+        g.x = fmaf(v.x, sc.x, sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(v.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+        g.z = fmaf(v.z, sc.z, sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(v.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+        sum[0] = add4(sum[0], g);
+        sum[1].x = fmaf(g.x, (v.x - mean.x) * invstd.x, sum[1].x); sum[1].y = fmaf(g.y, (v.y - mean.y) * invstd.y, sum[1].y);
+        sum[1].z = fmaf(g.z, (v.z - mean.z) * invstd.z, sum[1].z); sum[1].w = fmaf(g.w, (v.w - mean.w) * invstd.w, sum[1].w);
+    }
+    channel_partials<2>(sum, C4, part);
+}
+
 static int maxpool_bwd_check(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* out, int C) {
     if (!y0 || !bn.acc || !pooled || !ga || !out) return fail(SAGEN_ERR_NULL, "maxpool_bwd: null argument");
     if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bwd: C=%d must be a multiple of 4", C);
@@ -615,7 +641,7 @@ int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, co
 
 // x0 = maxpool(relu(bn0(y0))): gradient at y0 and at gamma / beta from the gradient at x0 (ga + gb), dz0 never materialised
 int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dy0, int B,
-                          int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s) {
+                          int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s, const float* pooled_raw) {
     if (int rc = maxpool_bwd_check(y0, bn, pooled, ga, dy0, C)) return rc;
     if (!acc || !scratch) return fail(SAGEN_ERR_NULL, "maxpool_bn_bwd: null accumulator / scratch");
     if (256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bn_bwd: C=%d must be 4 * a divisor of 256", C);
@@ -625,7 +651,13 @@ int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled,
     const long total = (long)B * H * W * (C / 4);
     // (gather-heavy: more, shorter workgroups than the streaming reductions; rows of 2C floats)
     static const int gmax = getenv("SAGEN_POOLBWD_GRID") ? atoi(getenv("SAGEN_POOLBWD_GRID")) : 2048;
-    const int grid = (int)std::max<long>(1, std::min<long>(cdiv(total, 256 * 4), gmax));
+    int grid = (int)std::max<long>(1, std::min<long>(cdiv(total, 256 * 4), gmax));
+    if (pooled_raw) {                                  // the sums over the pooled grid (the forward kept each window's raw extremum)
+        const long ptotal = (long)B * Ho * Wo * (C / 4);
+        grid = reduce_grid(ptotal, C / 4);
+        hipLaunchKernelGGL(pool_bn_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float4*)pooled_raw, bn, (const float4*)ga, (const float4*)gb, ptotal, C / 4,
+                           scratch);
+    } else
     hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled, (const float4*)ga,
                        (const float4*)gb, (float4*)nullptr, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, scratch, (const double*)nullptr,
                        (float*)nullptr, (float*)nullptr);

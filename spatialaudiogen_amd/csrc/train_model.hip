@@ -542,7 +542,8 @@ struct Bwd : Fwd {
         } else {
             timed("maxpool_bn_bwd_kernels", 0.0, [&] {
                 return maxpool_bn_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, bnb_acc(0), c->p(redws),
-                                             grad(name + "/bn/gamma"), grad(name + "/bn/beta"), s); });
+                                             grad(name + "/bn/gamma"), grad(name + "/bn/beta"), s,
+                                             c->rawpool_last && scope == "video_encoder" ? c->p("rx0" + sfx) : nullptr); });
         }
         // 7x7/2 over the zero-bordered 4-channel frame: the 7 (+1 zero) horizontal taps x 4 channels are 32 contiguous floats
         WgradDesc w = wdesc(c->p("xpad" + sfx), 229, 454, 4, 32, dz0, 112, 224, 64, 64, 7, 1, 2, 2, 0, 0);
