@@ -592,7 +592,8 @@ struct Bwd : Fwd {
         {
             const std::string name = "separation/deconv1";
             const float* ddm = c->p("t:ddmask");
-            relu_bwd("bias:" + name, ddm, nsep, nullptr, 0, nullptr, 0, nullptr, 0, (long)B * 31 * 1024, nsep, name + "/biases");
+            // (only buffer rows 4..26 = mask frames 1..23 carry a gradient: the border rows stay zero)
+            relu_bwd("bias:" + name, ddm, nsep, nullptr, 0, nullptr, 0, nullptr, 0, (long)B * 23 * 1024, nsep, name + "/biases", 23L * 1024, 31L * 1024, 4L * 1024);
             // live grid rows 10..16 of cat1 <-> buffer rows 4*i' + p (virtual rows 40..70)
             // (with fewer than 64 tracks, 64 / nsep neighbouring horizontal taps are folded into the channel index: neighbouring
             // pixels of the gradient are contiguous, [tw][track] is the variable's own order, and the 64-row tile is full)
