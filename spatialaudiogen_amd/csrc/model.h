@@ -116,6 +116,7 @@ struct sagen_ctx {
     int h2_blocks = 0;
     bool use_p3g = true;                   // the block merges of stages 3, 4 also write planes for the NEXT stage's stride-2 conv_1 + shortcut (conv3g.hip); opt-in: SAGEN_P3G=1 / sagen_set_option("plane_gather", 1) - measured no faster than igemm3_kernel
     bool rawpool_last = false;             // the last training forward kept the pooled raw stem output in "rx0" (stem8pool_kernel<raw+pool>)
+    bool train_rawpool = true;             // the training forward's stem writes the raw output AND its pooled extremum (SAGEN_TRAIN_NO_RAWPOOL=1: a pool pass of its own)
     bool train_bands = true;               // the training step's decoder on the live rows only, forward and backward (SAGEN_TRAIN_NO_BANDS=1: full tensors)
     int dec_lo[7] = {0, 0, 0, 0, 0, 0, 0}, dec_hi[7] = {0, 0, 0, 0, 0, 0, 0};      // rows of cat_l the last forward's decoder read (the backward of the same step follows them)
     bool no_scatter = false, no_d1_planes = false, no_lean_trunk = false;      // SAGEN_NO_DECONV_SCATTER / SAGEN_NO_DECONV1_PLANES / SAGEN_NO_LEAN_TRUNK, read when the context is created
@@ -861,8 +862,7 @@ struct Fwd {
             // ... and, where the pooled tensor goes on as planes, the pool of the raw output in the same kernel (max, or min where gamma < 0:
             // relu(bn(.)) is monotone per channel, so BN + ReLU of the pooled raw tensor IS maxpool(relu(bn(y0))), bit for bit) - the pool
             // pass no longer reads the 205 MB raw tensor a second time
-            static const bool no_rawpool = getenv("SAGEN_TRAIN_NO_RAWPOOL") != nullptr;
-            const bool rawpool = fast8 && keep && !no_rawpool && c->bufs.count("rx0" + sfx) != 0;
+            const bool rawpool = fast8 && keep && c->train_rawpool && c->bufs.count("rx0" + sfx) != 0;
             if (scope == "video_encoder") c->rawpool_last = rawpool;
             if (rawpool) {
                 H = 112; W = 224;

@@ -46,6 +46,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
     c->no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
     c->train_bands = getenv("SAGEN_TRAIN_NO_BANDS") == nullptr;
+    c->train_rawpool = getenv("SAGEN_TRAIN_NO_RAWPOOL") == nullptr;
     c->no_d1_planes = getenv("SAGEN_NO_DECONV1_PLANES") != nullptr;
     c->no_lean_trunk = getenv("SAGEN_NO_LEAN_TRUNK") != nullptr;
     if (getenv("SAGEN_NO_DECODER_PLANES") != nullptr) c->dec_planes_min_batch = 1 << 30;
@@ -835,6 +836,8 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
     if (n == "f16_fast_stem") { c->stem16 = value != 0; return SAGEN_OK; }
     if (n == "u8_stem_h2") { c->stem8h = value != 0; return SAGEN_OK; }
+    if (n == "train_bands") { c->train_bands = value != 0; return SAGEN_OK; }
+    if (n == "train_rawpool") { c->train_rawpool = value != 0; return SAGEN_OK; }
     if (n == "fp16x2") { c->use_h2 = value != 0; return SAGEN_OK; }
     if (n == "planes_from_stage") { if (value < 2 || value > 6) return fail(SAGEN_ERR_SHAPE, "planes_from_stage in 2..6"); c->p3_from_stage = value; return SAGEN_OK; }
     if (n == "decoder_planes") { c->dec_planes_min_batch = value ? 1 : (1 << 30); return SAGEN_OK; }

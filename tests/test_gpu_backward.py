@@ -445,6 +445,57 @@ def test_uint8_frames_train_step_matches_the_float_entry_point(T):
     assert errs[worst] < FREE_RUNNING_BAR, (worst, errs[worst])
 
 
+def test_live_row_bands_and_the_fused_stem_pool_leave_the_step_unchanged(T):
+    """Round 5, the training step: (a) the mask decoder runs on the rows that reach the cropped window only, forward (scatter-form
+    deconvs over the band) and backward (banded ReLU / bias pass, weight and data gradients over the band, dead rows zeroed once at
+    bind); (b) the stem kernel emits the raw output and its pooled extremum, BN + ReLU run on the pooled tensor and the stem BN
+    backward sums over the pooled grid.  Against the same context with the options off (the round-4 full-tensor kernels): the kernels
+    really differ, the loss agrees to fp32 rounding, the decoder-side gradients tightly, everything else at the free-running bar
+    (a different summation order in the decoder moves the trunk's inputs by rounding).  (b) alone changes no forward value: tight
+    on every variable."""
+    net, ref, P, inp, target = _setup(T, ['audio', 'video'], 2, 6)
+    from spatialaudiogen_amd.train import Trainer
+    tr = Trainer(net, batch=2)
+    v = T.as_tensor(inp['video']).cuda()
+    u8 = T.round((v.double() + 0.5) * 255.0).clamp(0, 255).to(T.uint8)
+
+    def run(bands, rawpool):
+        tr.ctx.set_option('train_bands', bands)
+        tr.ctx.set_option('train_rawpool', rawpool)
+        tr.profile_enable(True)
+        loss = tr.forward_backward(inp['audio'], u8, None, target, update_moving=False)
+        T.cuda.synchronize()
+        kernels = {k for k, layer, us, fl in tr.profile_report()}
+        tr.profile_enable(False)
+        return float(loss), {k: tr.grad(k).cpu().numpy().copy() for k in tr.opt.layout}, kernels
+
+    full = run(0, 0)
+    pool = run(0, 1)
+    both = run(1, 1)
+    again = run(0, 0)                                       # (the buffers the bands never write were not dirtied by the full-tensor step in between)
+    last = run(1, 1)
+    assert 'stem8pool_kernel<raw+pool>' in pool[2] and 'stem8pool_kernel<raw+pool>' not in full[2], (pool[2], full[2])
+    assert 'deconv_gather_kernel' in both[2] and 'deconv_gather_kernel' not in full[2]
+    same = lambda a, b: abs(a - b) <= 1e-12 * abs(b)        # (the scalar loss is summed with fp64 atomics: its last bits depend on their order)
+    assert same(pool[0], full[0])                           # (b) leaves the forward bit for bit
+    for k in full[1]:
+        e = rel_rms_err(pool[1][k], full[1][k])
+        assert e < 1e-5, ('rawpool', k, e)
+    assert abs(both[0] - full[0]) <= 2e-5 * abs(full[0]), (both[0], full[0])
+    errs = {k: rel_rms_err(both[1][k], full[1][k]) for k in full[1]}
+    dec = max(e for k, e in errs.items() if k.startswith(('separation/deconv', 'localization/')))
+    worst = max(errs, key=errs.get)
+    print('\n[bands vs full tensors] loss %.9g / %.9g, decoder side %.2e, worst %.2e (%s)' % (both[0], full[0], dec, errs[worst], worst))
+    assert dec < 1e-4, dec
+    assert errs[worst] < FREE_RUNNING_BAR, (worst, errs[worst])
+    # run to run: the same step twice gives the same numbers (a full-tensor step in between dirtied the dead rows of the gradient
+    # buffers with REAL zeros only: the bands' step does not depend on it)
+    assert same(again[0], full[0]) and same(last[0], both[0])
+    for k in full[1]:
+        assert np.array_equal(again[1][k], full[1][k]), k
+        assert np.array_equal(last[1][k], both[1][k]), k
+
+
 def test_gradients_on_planes_and_on_fp32_tensors_agree(T):
     """The stride-1 3x3 trunk convs run their data and weight gradients on fp16x2 planes (dy planes from the batch-norm backward,
     retained forward planes: conv3h_kernel / wgrad3h_kernel).  SAGEN_TRAIN_NO_H2W=1 (weight gradients on the fp32 tensors, forward
