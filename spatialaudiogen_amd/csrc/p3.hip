@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ 
 }
 
 // grid whose stride (grid*256 threads) is a multiple of `unit_threads`, so per-thread channel groups are loop-invariant
-static int aligned_grid(long total, int unit_threads) {
-    long g = std::min<long>(cdiv(total, 256), 256L * 8);      // <= 8 blocks per CU: the coefficient table is amortised over several elements per thread
+static int aligned_grid(long total, int unit_threads, int amort = 1) {
+    // <= 8 blocks per CU: the coefficient table is amortised over several elements per thread; `amort` elements per thread at least
+    // where the table is the larger part of a workgroup's work (deep stages: 256 / 512 channels of fp64 finalisation for 256 items)
+    long g = std::min<long>(cdiv(total, 256L * amort), 256L * 8);
     long a = 256, b = unit_threads;
     while (b) { const long t = a % b; a = b; b = t; }
     const long unit = unit_threads / a;                  // smallest g with (g*256) % unit_threads == 0
@@ -233,11 +235,15 @@ int p3_pack_launch(const float* x, const float* scale, const float* shift, const
     if (p3_bytes(B, H, W, C) >= (1UL << 31)) return fail(SAGEN_ERR_UNSUPPORTED, "p3_pack: tensor exceeds 2 GiB buffer addressing");
     const long total = nrows * (W + 1) * (C / 8);
     if (fmt == 1 && p3 && !(h2 && h2->a_inv)) return fail(SAGEN_ERR_NULL, "p3_pack: the fp16x2 format needs a slot for its scale");
+    static const int amort_env = getenv("SAGEN_P3_AMORT") ? atoi(getenv("SAGEN_P3_AMORT")) : 0;
+    // (measured with three batches in flight, same box, tools/ab_p3_amort.sh: 1 / 2 / 4 items per thread = 2 508-2 524 / 2 519-2 529 / 2 536-2 544
+    //  ambisonic-s/s - the pass alone is no faster with fewer workgroups, but it leaves the CUs to the other batches' matrix kernels sooner)
+    const int amort = amort_env > 0 ? amort_env : 4;
     if (fmt == 1)
-        hipLaunchKernelGGL(p3_pack_kernel<true>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+        hipLaunchKernelGGL(p3_pack_kernel<true>, dim3(aligned_grid(total, C / 8, amort)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
                            (char*)p3, nrows, W, C, *h2);
     else
-        hipLaunchKernelGGL(p3_pack_kernel<false>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+        hipLaunchKernelGGL(p3_pack_kernel<false>, dim3(aligned_grid(total, C / 8, amort)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
                            (char*)p3, nrows, W, C, P3hScale());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
