@@ -13,7 +13,10 @@ namespace sagen {
 
 // grid whose stride (grid*256 threads) is a multiple of C4, so a thread always sees the same 4 channels
 static int aligned_grid(long n4, int C4) {
-    long g = std::min<long>(cdiv(n4, 256), 256L * 16);
+    // SAGEN_BWD_AMORT items per thread at least: fewer, longer workgroups leave CUs to the weight gradients on the second stream
+    // (training step on one box, tools/ab_bwd_amort.sh: 1 / 2 / 4 / 8 / 16 / 32 items = 6.09-6.11 / 6.06-6.08 / 6.01 / 5.98-6.01 / 6.07 / 6.28 ms)
+    static const int amort = getenv("SAGEN_BWD_AMORT") ? std::max(1, atoi(getenv("SAGEN_BWD_AMORT"))) : 4;
+    long g = std::min<long>(cdiv(n4, 256L * amort), 256L * 16);
     if ((g * 256) % C4) {
         long a = 256, b = C4;
         while (b) { const long t = a % b; a = b; b = t; }
