@@ -252,7 +252,12 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->expose("localization/coeffs", "coeffs", 0, {B, 3, 3, c->nsep + 1}, c->nsep + 1);
     if (c->freq_mask) c->expose("separation/deconv1", "dmask", 0, {B, 23, 1024, c->nsep}, c->nsep);
     // second stream + fork/join events (host-side objects; no device memory)
-    if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+    // SAGEN_AUX_PRIO=low|high: the second stream below / above the default priority (experiment: the dispatcher then prefers one branch)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // (least, greatest): numerically lower = higher priority
+    const char* aux_prio = getenv("SAGEN_AUX_PRIO");
+    const int prio = aux_prio && aux_prio[0] == 'l' ? prio_lo : (aux_prio && aux_prio[0] == 'h' ? prio_hi : 0);
+    if ((aux_prio ? hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_stft, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess ||
