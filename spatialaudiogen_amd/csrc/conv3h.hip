@@ -35,11 +35,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // KC = 16-channel chunks per barrier step (group): the deep layers (Cin 256 / 512: 48 / 96 groups of only 9*MT*NT MFMAs) are bound by
 // the per-group latency (barrier, DMA round trip, first fragments) - two chunks per group halve the groups.  No slack behind the ring:
 // the fragment reads of the two dropped rows run past the activation image into the filter image of the SAME stage.
-constexpr int conv3h_lds(int BM, int BN, int KC) { return 2 * KC * (BM * 64 + 3 * 2 * BN * 32); }
-constexpr int conv3h_wgs_per_cu(int BM, int BN, int KC) { return 160 * 1024 / conv3h_lds(BM, BN, KC) >= 3 ? 3 : (160 * 1024 / conv3h_lds(BM, BN, KC) >= 2 ? 2 : 1); }
+//
+// AR = depth of the ACTIVATION ring.  AR = 2: one two-stage ring of (activation image, filter images) - group g+1 is issued under
+// group g.  AR = 3 (conv3hr_kernel): the activation images have a ring of their own, three deep, the filter images keep two stages:
+// under group g the workgroup issues the filter images of group g+1 FIRST and then the activation image of group g+2, and the wait
+// in front of group g+1 is the counted vmcnt(activation instructions of one group) - everything older than the youngest activation
+// image has landed, that image has a whole further group to arrive.  The activation images are the HBM / far-L2 reads (the filter is
+// the same 147 KB..4.7 MB for every workgroup and sits in the L2), so the extra depth goes where the latency is, for 16 KB of LDS more
+// per 256x64 workgroup (72 KB: still two per CU) instead of the 28 KB a third full stage would cost (84 KB: one per CU).
+constexpr int conv3h_lds(int BM, int BN, int KC, int AR = 2) { return KC * (AR * BM * 64 + 2 * 3 * 2 * BN * 32); }
+constexpr int conv3h_wgs_per_cu(int BM, int BN, int KC, int AR = 2) {
+    return 160 * 1024 / conv3h_lds(BM, BN, KC, AR) >= 3 ? 3 : (160 * 1024 / conv3h_lds(BM, BN, KC, AR) >= 2 ? 2 : 1);
+}
 
-template <int BM, int BN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_kernel(const IgemmDesc d) {
+template <int BM, int BN, int WM, int WN, int KC, int AR>
+__device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
+    static_assert(AR == 2 || AR == 3, "activation ring of two or three stages");
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
@@ -56,15 +67,38 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
     constexpr int CNT_MAX = KC * SPT;
     static_assert(CNT_MAX <= NMG, "one DMA slot per MFMA slot at most");
     constexpr int NF = 2 * (MT + NT);
-    constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
+    [[maybe_unused]] constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
     static_assert(WM % RPP == 0, "a wave row is a whole number of store passes");
     constexpr int EPI_TILE = WM * BN * 4, EPI_DENSE = BM * 4, EPI_RED = 2 * RPP * BN * 4;
-    constexpr int SMEM_BYTES = 2 * ST_BYTES;
+    constexpr int SMEM_BYTES = KC * (AR * A_BYTES + 2 * B_BYTES);
     static_assert(EPI_TILE + EPI_DENSE + EPI_RED <= SMEM_BYTES, "epilogue staging must fit the ring");
-    static_assert(SMEM_BYTES == conv3h_lds(BM, BN, KC), "occupancy bound uses the same footprint");
+    static_assert(SMEM_BYTES == conv3h_lds(BM, BN, KC, AR), "occupancy bound uses the same footprint");
+    static_assert(AR == 2 || A_INST % 4 == 0, "counted vmcnt: every wave issues the same number of activation instructions");
+    // where stage sa of the activation ring / stage sb of the filter ring start (AR = 2: the interleaved layout [A0 B0 A1 B1])
+    auto a_stage = [&](int sa) { return AR == 2 ? sa * ST_BYTES : sa * (KC * A_BYTES); };
+    auto b_stage = [&](int sb) { return AR == 2 ? sb * ST_BYTES + KC * A_BYTES : AR * KC * A_BYTES + sb * (KC * B_BYTES); };
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // ONE shared object (conv3p.hip)
 
     const int tid = threadIdx.x;
+#ifdef SAGEN_TRACE      // debug builds (tools/trace_conv3h.py): life of every workgroup - entry, K loop entered, K loop left, epilogue done
+    unsigned long long* const trc = d.trace ? (unsigned long long*)d.trace + (size_t)blockIdx.x * 8 : nullptr;
+#define C3H_TRC(k) do { if (trc && tid == 0) trc[k] = __builtin_amdgcn_s_memtime(); } while (0)
+    if (trc && tid == 0) {
+        trc[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave / simd / cu / sh / se
+        trc[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+        trc[6] = __builtin_amdgcn_s_memrealtime();                 // 100 MHz, common to the XCDs
+    }
+    C3H_TRC(0);
+    // ... and the phases of every group of two workgroups (an early and a late one): top, tiles landed, barrier passed, first
+    // fragments in registers, last MFMA issued - [2][64 groups][8] behind the per-workgroup records
+    const int gsel = (int)blockIdx.x == 8 ? 0 : ((int)blockIdx.x == (int)gridDim.x - 64 ? 1 : -1);
+    unsigned long long* const gtr = (d.trace && gsel >= 0) ? (unsigned long long*)d.trace + (size_t)8192 * 8 + (size_t)gsel * 64 * 8 : nullptr;
+    int g_idx = 0;
+#define C3H_GTRC(k) do { if (gtr && tid == 0 && g_idx < 64) gtr[g_idx * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C3H_TRC(k) do { } while (0)
+#define C3H_GTRC(k) do { } while (0)
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -75,6 +109,8 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.xp3, 0, d.xp3_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.wh2, 0, d.wh2_bytes, 0x00020000);
+
+    const float osc = d.h2_a_inv[0] * d.h2_w_inv[0];      // (read here: two dependent-latency loads the epilogue would otherwise wait for)
 
     // block -> tile: XCD x owns M tiles [x*per, (x+1)*per) (vertically neighbouring tiles share input rows in one L2)
     const int xcd = blockIdx.x & 7;
@@ -119,34 +155,51 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
         b_voff[j] = (inst < B_INST && n0 + n < d.N) ? (unsigned)((pl * d.N + n0 + n) * 32 + 16 * (half ^ ((n >> 3) & 1))) : OOB;
     }
 
-    // issue state (SGPRs): the group being issued
-    int q_dh = 0, q_ch = 0, cur_dh = -1;
+    // issue state (SGPRs): the activation group and the filter group being issued (AR = 2: the same group; AR = 3: the activation
+    // tracker runs one group ahead of the filter tracker)
+    int qa_dh = 0, qa_ch = 0, cur_dh = -1, qb_dh = 0, qb_ch = 0;
     unsigned i_asoff = 0, i_bsoff = 0;
-    char* i_stage = smem;
-    auto begin_issue = [&](int stage) {
-        i_stage = smem + stage * ST_BYTES;
-        if (q_dh != cur_dh) {
-            cur_dh = q_dh;
+    char* i_astage = smem;
+    char* i_bstage = smem;
+    auto begin_issue_a = [&](int sa) {
+        i_astage = smem + a_stage(sa);
+        if (qa_dh != cur_dh) {
+            cur_dh = qa_dh;
 #pragma unroll
-            for (int j = 0; j < A_PW; ++j) a_cur[j] = q_dh == 0 ? a_v0[j] : (q_dh == 1 ? a_v1[j] : a_v2[j]);
+            for (int j = 0; j < A_PW; ++j) a_cur[j] = qa_dh == 0 ? a_v0[j] : (qa_dh == 1 ? a_v1[j] : a_v2[j]);
         }
-        i_asoff = (unsigned)q_ch * d.xp3_cstride;
-        i_bsoff = (unsigned)((q_dh * 3) * nchunk + q_ch) * (unsigned)(d.N * 64);
-        q_ch += KC;
-        if (q_ch == nchunk) { q_ch = 0; ++q_dh; }
+        i_asoff = (unsigned)qa_ch * d.xp3_cstride;
+        qa_ch += KC;
+        if (qa_ch == nchunk) { qa_ch = 0; ++qa_dh; }
     };
-    auto issue_one = [&](int sg) {              // sg = compile-time slot index of the group: chunk kc, then A slots first, then B slots
-        const int kc = sg / SPT, s = sg - kc * SPT;
-        if (s < A_PW) {
-            const int inst = wave + 4 * s;
-            if (A_INST % 4 == 0 || inst < A_INST)
-                dma16(x_rsrc, (float*)(i_stage + kc * A_BYTES + inst * 1024), a_cur[s], i_asoff + (unsigned)kc * d.xp3_cstride);
+    auto begin_issue_b = [&](int sb) {
+        i_bstage = smem + b_stage(sb);
+        i_bsoff = (unsigned)((qb_dh * 3) * nchunk + qb_ch) * (unsigned)(d.N * 64);
+        qb_ch += KC;
+        if (qb_ch == nchunk) { qb_ch = 0; ++qb_dh; }
+    };
+    auto issue_a = [&](int kc, int s) {         // activation slot s of chunk kc (compile-time indices)
+        const int inst = wave + 4 * s;
+        if (A_INST % 4 == 0 || inst < A_INST)
+            dma16(x_rsrc, (float*)(i_astage + kc * A_BYTES + inst * 1024), a_cur[s], i_asoff + (unsigned)kc * d.xp3_cstride);
+    };
+    auto issue_b = [&](int kc, int j) {         // filter slot j of chunk kc
+        const int inst = wave + 4 * j;
+        if (4 * (j + 1) <= B_INST || inst < B_INST)
+            dma16(w_rsrc, (float*)(i_bstage + kc * B_BYTES + inst * 1024), b_voff[j], i_bsoff + (unsigned)b_tapoff[j] + (unsigned)(kc * d.N * 64));
+    };
+    // n = position in the group's issue order.  AR = 2: per chunk (last chunk first) its filter slots, then its activation slots;
+    // AR = 3: ALL filter slots, then all activation slots (the counted wait leaves exactly the activation instructions in flight)
+    auto issue_nth = [&](int n) {
+        if (AR == 2) {
+            const int sg = CNT_MAX - 1 - n;
+            const int kc = sg / SPT, s = sg - kc * SPT;
+            if (s < A_PW) issue_a(kc, s); else issue_b(kc, s - A_PW);
+        } else if (n < KC * B_PW) {
+            issue_b(n / B_PW, n % B_PW);
         } else {
-            const int j = s - A_PW;
-            const int inst = wave + 4 * j;
-            if (4 * (j + 1) <= B_INST || inst < B_INST)
-                dma16(w_rsrc, (float*)(i_stage + KC * A_BYTES + kc * B_BYTES + inst * 1024), b_voff[j],
-                      i_bsoff + (unsigned)b_tapoff[j] + (unsigned)(kc * d.N * 64));
+            const int m = n - KC * B_PW;
+            issue_a(m / A_PW, m % A_PW);
         }
     };
 
@@ -168,28 +221,37 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
             const int sl = wm * WM + i * 32 + li + dwi;              // output row r sits at slot r + 1; tap dw reads slot r + dw
             a_foff[dwi][i] = sl * 64 + 16 * (kk ^ ((sl >> 2) & 3));
         }
-    const int b_foff = KC * A_BYTES + (wn * WN + li) * 32 + 16 * (kk ^ ((li >> 3) & 1));
+    const int b_foff = (wn * WN + li) * 32 + 16 * (kk ^ ((li >> 3) & 1));     // (inside a filter stage)
     constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};             // lo*hi, hi*lo, hi*hi
 
-    int stage = 0;
-    begin_issue(0);
+    int sa = 0, sb = 0;                                              // the stages being consumed
+    begin_issue_a(0);
+    begin_issue_b(0);
 #pragma unroll
-    for (int s = CNT_MAX - 1; s >= 0; --s) issue_one(s);            // filter tiles first
+    for (int n = 0; n < CNT_MAX; ++n) issue_nth(n);                  // filter tiles first
+    if (AR == 3) {
+        begin_issue_a(1);                                            // (G >= 3: three vertical taps)
+#pragma unroll
+        for (int n = KC * B_PW; n < CNT_MAX; ++n) issue_nth(n);
+    }
 
-    // one group: its 9*MT*NT MFMAs with the DMA of the next group (ISSUE) spread between them; every MFMA slot is fenced
-    // (conv3p.hip: the source order IS the schedule)
+    // one group: its 9*MT*NT MFMAs with the DMA of the coming group(s) spread between them; every MFMA slot is fenced
+    // (conv3p.hip: the source order IS the schedule).  ISSUE: 0 = nothing, 1 = the filter slots only, 2 = everything
     auto group = [&](auto issue_tag) {
-        constexpr bool ISSUE = decltype(issue_tag)::value;
-        const char* st = smem + stage * ST_BYTES;
+        constexpr int ISSUE = decltype(issue_tag)::value;
+        constexpr int NISSUE = ISSUE == 2 ? CNT_MAX : (ISSUE == 1 ? KC * B_PW : 0);
+        const char* st_a = smem + a_stage(sa);
+        const char* st_b = smem + b_stage(sb);
         f16x8 fq[2][NF];                                             // [buffer][plane * (MT+NT) + (i | MT + j)]
         auto load_frag = [&](int buf, int t, int f) {               // t = kc*3 + dwi: the (chunk, horizontal tap) step inside the group
             const int kc = t / 3, dwi = t - 3 * kc;
             const int pl = f / (MT + NT), r = f - pl * (MT + NT);
-            if (r < MT) fq[buf][f] = *reinterpret_cast<const f16x8*>(st + kc * A_BYTES + (a_foff[dwi][r] ^ (pl * 32)));
-            else fq[buf][f] = *reinterpret_cast<const f16x8*>(st + b_foff + kc * B_BYTES + (dwi * 2 + pl) * (BN * 32) + (r - MT) * 32 * 32);
+            if (r < MT) fq[buf][f] = *reinterpret_cast<const f16x8*>(st_a + kc * A_BYTES + (a_foff[dwi][r] ^ (pl * 32)));
+            else fq[buf][f] = *reinterpret_cast<const f16x8*>(st_b + b_foff + kc * B_BYTES + (dwi * 2 + pl) * (BN * 32) + (r - MT) * 32 * 32);
         };
 #pragma unroll
         for (int f = 0; f < NF; ++f) load_frag(0, 0, f);
+        C3H_GTRC(3);
 #pragma unroll
         for (int t = 0; t < 3 * KC; ++t) {
             const int cb = t & 1;
@@ -210,26 +272,136 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
                                 if (f * NM1 / NF == k) load_frag(cb ^ 1, t + 1, f);
                         }
 #pragma unroll
-                        for (int sg = 0; sg < CNT_MAX; ++sg)
-                            if (ISSUE && idx == sg) issue_one(CNT_MAX - 1 - sg);
+                        for (int n = 0; n < NISSUE; ++n)
+                            if (idx == n) issue_nth(n);
                     }
         }
         __builtin_amdgcn_sched_barrier(0);
-        stage ^= 1;
+        C3H_GTRC(4);
+#ifdef SAGEN_TRACE
+        ++g_idx;
+#endif
+        sa = sa + 1 == AR ? 0 : sa + 1;
+        sb ^= 1;
     };
 
-    for (int it = 0; it + 1 < G; ++it) {
+    C3H_TRC(1);                                                      // prologue done: index setup, first tiles issued
+    if (AR == 2) {
+        for (int it = 0; it + 1 < G; ++it) {
+            C3H_GTRC(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            C3H_GTRC(1);
+            lds_barrier();
+            C3H_GTRC(2);
+            begin_issue_a(sa ^ 1);
+            begin_issue_b(sb ^ 1);
+            group(std::integral_constant<int, 2>{});
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        begin_issue(stage ^ 1);
-        group(std::true_type{});
+        group(std::integral_constant<int, 0>{});
+    } else {
+        // in front of group g the youngest instructions in flight are the KC*A_PW of activation image g+1: everything older - the
+        // filter images and the activation image of group g - has landed once at most those are outstanding
+        for (int it = 0; it + 2 < G; ++it) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * A_PW) : "memory");
+            lds_barrier();                                           // every wave is done with group it-1: its stages are free
+            begin_issue_b(sb ^ 1);                                   // filter images of group it+1
+            begin_issue_a(sa == 0 ? 2 : sa - 1);                     // activation image of group it+2 -> the stage group it-1 read
+            group(std::integral_constant<int, 2>{});
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KC * A_PW) : "memory");
+        lds_barrier();
+        begin_issue_b(sb ^ 1);
+        group(std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        group(std::integral_constant<int, 0>{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    group(std::false_type{});
 
+    C3H_TRC(2);
+#ifndef SAGEN_C3H_LDS_EPILOGUE
+    // ---- epilogue straight from the accumulators: x 2^-(ka + kw), bias / ReLU, batch-norm statistics.  C/D layout of 32x32: col =
+    // lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a store instruction writes two 128-byte row segments.  A workgroup's way
+    // out is bound by the NUMBER of instructions a wave has to issue (tools/trace_conv3h.py: 9.4 k cycles alone, 14 k beside the other
+    // workgroup of the CU, for the 1 500 instructions of the form staged through LDS or of a branchy direct form - with or without
+    // the stores and the atomics), so this form is branch-free: a dropped row (pad pixel, beyond the tile or the tensor) gets the
+    // out-of-range buffer offset and the scale 0, which also keeps it out of the sums - 4 instructions per value, 12 per row.
+    const int colb = n0 + wn * WN + li;                              // column of this lane in N block j = 0
+    const bool plain = d.bias == nullptr && !d.relu_out;             // (the batch-norm convs of the trunk)
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.y, 0, d.y_bytes, 0x00020000);
+    const unsigned ldy4 = (unsigned)d.ldy * 4u;
+    const int plim = min(NP, m0 + BME);
+    float bias_j[NT], cs[NT], cq[NT];
+    unsigned col4[NT];                                               // byte offset of the lane's column, OOB beyond N
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const bool ok = colb + 32 * j < d.N;
+        col4[j] = ok ? (unsigned)(colb + 32 * j) * 4u : OOB;
+        bias_j[j] = (d.bias != nullptr && ok) ? d.bias[colb + 32 * j] : 0.f;
+        cs[j] = 0.f; cq[j] = 0.f;
+    }
+    // FAST (uniform): whole N tile inside N, no bias, no ReLU - the batch-norm convs of the trunk; the other form keeps every case
+    auto epilogue = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int p = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                const unsigned row = __umulhi((unsigned)p, d.p3_magic_wp);   // p / Wp = b*H + h: one pad pixel per preceding row
+                const bool ok = p < plim && (unsigned)p - row * (unsigned)Wp < (unsigned)W;
+                const float sc = ok ? osc : 0.f;
+                const unsigned roff = ok ? ((unsigned)p - row) * ldy4 + (FAST ? (unsigned)(colb * 4) : 0u) : OOB;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float v = acc[i][j][e] * sc;
+                    if (FAST) {
+                        cs[j] += v;
+                        cq[j] = __builtin_fmaf(v, v, cq[j]);
+#ifndef C3H_ABLATE_STORE
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, roff, 128 * j, 0);
+#endif
+                    } else {
+                        const unsigned off = ((roff | col4[j]) & OOB) ? OOB : roff + col4[j];
+                        if (col4[j] & OOB) v = 0.f;
+                        cs[j] += v;
+                        cq[j] = __builtin_fmaf(v, v, cq[j]);
+                        v += bias_j[j];
+                        if (d.relu_out) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off, 0, 0);
+                    }
+                }
+            }
+    };
+    if (plain && n0 + BN <= d.N) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+    if (d.stats != nullptr) {                 // per-channel (sum, sumsq) of the raw output -> fp64 accumulators [2][N]
+        lds_barrier();                        // every wave is done with the last group's fragments: the ring is free
+        float* const red = reinterpret_cast<float*>(smem);                   // [WAVES_M * 2 (lane halves)][2][BN]
+        static_assert(WAVES_M * 2 * 2 * BN * 4 <= SMEM_BYTES, "statistics staging must fit the ring");
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            red[((wm * 2 + kk) * 2 + 0) * BN + wn * WN + j * 32 + li] = cs[j];
+            red[((wm * 2 + kk) * 2 + 1) * BN + wn * WN + j * 32 + li] = cq[j];
+        }
+        lds_barrier();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int which = t / BN, col = t - which * BN;
+            if (n0 + col < d.N) {
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < WAVES_M * 2; ++g) sum += red[(g * 2 + which) * BN + col];
+#ifndef C3H_ABLATE_ATOMICS
+                atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
+#else
+                if (sum == 12345.678f) atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
+#endif
+            }
+        }
+    }
+#else
     // ---- epilogue through the (now idle) ring: x 2^-(ka + kw), 16-byte row-contiguous stores, bias / ReLU, batch-norm statistics ----
-    const float osc = d.h2_a_inv[0] * d.h2_w_inv[0];
     const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
     lds_barrier();                                   // every wave is done with the last group's fragments
     float* const tile = reinterpret_cast<float*>(smem);                              // [WM][BN]
@@ -304,20 +476,48 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC)) void conv3h_ker
             }
         }
     }
+#endif
+    C3H_TRC(3);
+#ifdef SAGEN_TRACE
+    if (trc && tid == 0) trc[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+#undef C3H_TRC
+#undef C3H_GTRC
 }
 
 template <int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC, 2)) void conv3h_kernel(const IgemmDesc d) {
+    conv3h_body<BM, BN, WM, WN, KC, 2>(d);
+}
+// ... with the three-deep activation ring
+template <int BM, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC, 3)) void conv3hr_kernel(const IgemmDesc d) {
+    conv3h_body<BM, BN, WM, WN, KC, 3>(d);
+}
+
+template <int BM, int BN, int WM, int WN, int KC, int AR = 2>
 static int launch_conv3h(const IgemmDesc& d, hipStream_t s) {
     if ((d.Cin / 16) % KC) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: %d channel chunks are not a multiple of %d per group", d.Cin / 16, KC);
     const int per = (cdiv(d.p3_np, BM - 2) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
-    hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
+    if constexpr (AR == 3) hipLaunchKernelGGL((conv3hr_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
 
+#ifdef SAGEN_TRACE
+static void* g_trace_buf = nullptr;
+static int g_trace_nth = -1;
+// arms the trace of the nth conv3h launch from now (0 = the next one); buf: 8 x 8 bytes per workgroup, zeroed by the caller
+extern "C" void sagen_debug_trace_conv3h(void* buf, int nth) { g_trace_buf = buf; g_trace_nth = nth; }
+#endif
+
 int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     IgemmDesc d = d_in;
+#ifdef SAGEN_TRACE
+    if (g_trace_nth >= 0 && g_trace_nth-- == 0) d.trace = g_trace_buf;
+#endif
     if (!d.xp3 || d.p3_np <= 0 || d.xp3_fmt != 1) return fail(SAGEN_ERR_NULL, "conv3h: the fp16x2 activation planes are missing");
     if (!d.wh2 || !d.h2_a_inv || !d.h2_w_inv) return fail(SAGEN_ERR_NULL, "conv3h: the fp16x2 filter planes / scales are missing");
     if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: no split-K");
@@ -325,6 +525,9 @@ int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: too many pixels for 32-bit index arithmetic");
     if ((long)d.p3_np * 64 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: the activation planes exceed 2 GiB buffer addressing (use a smaller batch)");
+    const long y_bytes = ((long)(d.M - 1) * d.ldy + d.N) * 4;
+    if (y_bytes >= (1L << 31)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: the output exceeds 2 GiB buffer addressing (use a smaller batch)");
+    d.y_bytes = (unsigned)y_bytes;
     d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)(d.Win + 1)) + 1u;
     d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hin) + 1u;
     switch (tile) {
@@ -335,6 +538,9 @@ int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         case TILE_P3H_128x64_C2: return launch_conv3h<128, 64, 64, 32, 2>(d, s);
         case TILE_P3H_64x64_C2: return launch_conv3h<64, 64, 32, 32, 2>(d, s);
         case TILE_P3H_64x64_C4: return launch_conv3h<64, 64, 32, 32, 4>(d, s);
+        case TILE_P3HR_256x64: return launch_conv3h<256, 64, 64, 64, 1, 3>(d, s);
+        case TILE_P3HR_128x64: return launch_conv3h<128, 64, 64, 32, 1, 3>(d, s);
+        case TILE_P3HR_64x64_C2: return launch_conv3h<64, 64, 32, 32, 2, 3>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: bad tile id %d", (int)tile);
     }
 }

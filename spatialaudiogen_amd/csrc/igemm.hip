@@ -333,6 +333,8 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {64, 64, 64, "conv3h_kernel<64,64,32,32,4>", true, true, false, true, false, true},
     {64, 128, 16, "conv3g_kernel<64,128,32,64,2,true,1>", true, false, false, true, true, true}, {64, 128, 16, "conv3g_kernel<64,128,32,64,4,true,1>", true, false, false, true, true, true},
     {128, 128, 16, "conv3g_kernel<128,128,64,64,2,true,1>", true, false, false, true, true, true}, {128, 256, 16, "conv3g_kernel<128,256,64,128,2,true,1>", true, false, false, true, true, true},
+    {256, 64, 16, "conv3hr_kernel<256,64,64,64,1>", true, true, false, true, false, true}, {128, 64, 16, "conv3hr_kernel<128,64,64,32,1>", true, true, false, true, false, true},
+    {64, 64, 32, "conv3hr_kernel<64,64,32,32,2>", true, true, false, true, false, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {

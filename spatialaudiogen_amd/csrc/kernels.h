@@ -69,6 +69,7 @@ struct IgemmDesc {
     int splitk = 1;
     // filled by igemm_launch
     unsigned x_bytes = 0, w_bytes = 0;
+    unsigned y_bytes = 0;             // conv3h_kernel: extent of y for its buffer stores (set by conv3h_dispatch)
     int no_bounds = 0;
     int uniform_taps = 0;
     // conv3p_kernel (conv3p.hip): the activation as pre-split bf16 planes [Cin/16][p3_np][3][16], p3_np = B*Hin*(Win+1)
@@ -128,6 +129,8 @@ enum IgemmTile {
     TILE_P3H_128x64_C2, TILE_P3H_64x64_C2, TILE_P3H_64x64_C4,
     // conv3g_kernel on fp16x2 planes with the fused decoder tail as its epilogue (deconv1 at inference: IgemmDesc::mm_out), 2 / 4 K tiles per group
     TILE_P3GH_MM_64x128_K2, TILE_P3GH_MM_64x128_K4, TILE_P3GH_MM_128x128_K2, TILE_P3GH_MM_128x256_K2,
+    // conv3hr_kernel: conv3h_kernel with a three-deep ring of activation images beside the two filter stages (conv3h.hip)
+    TILE_P3HR_256x64, TILE_P3HR_128x64, TILE_P3HR_64x64_C2,
     TILE_AUTO
 };
 

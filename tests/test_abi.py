@@ -105,4 +105,4 @@ def test_tile_table_is_exposed_and_consistent():
     assert L.sagen_tile_name(-1) is None and L.sagen_tile_name(n) is None
     assert names == SptAudioGen.tile_names()
     fams = {nm.split('<')[0] for nm in names}
-    assert fams == {'igemm_kernel', 'igemm3_kernel', 'igemm3dw_kernel', 'igemm3s2_kernel', 'conv3p_kernel', 'conv3pp_kernel', 'conv3g_kernel', 'conv3h_kernel'}
+    assert fams == {'igemm_kernel', 'igemm3_kernel', 'igemm3dw_kernel', 'igemm3s2_kernel', 'conv3p_kernel', 'conv3pp_kernel', 'conv3g_kernel', 'conv3h_kernel', 'conv3hr_kernel'}

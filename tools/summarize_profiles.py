@@ -63,7 +63,7 @@ json.dump(traffic, open(os.path.join(dst, tag + '_traffic.json'), 'w'), indent=1
 label = {}
 wsum = collections.defaultdict(lambda: [0.0, 0.0])
 for k, v in traffic.items():
-    if k.startswith(('igemm_kernel<', 'igemm3s2_kernel<', 'conv3p_kernel<', 'conv3h_kernel<', 'conv3g_kernel<')) or k.startswith(('stem8pool_kernel', 'p3_pack_kernel')):
+    if k.startswith(('igemm_kernel<', 'igemm3s2_kernel<', 'conv3p_kernel<', 'conv3h_kernel<', 'conv3hr_kernel<', 'conv3g_kernel<')) or k.startswith(('stem8pool_kernel', 'p3_pack_kernel')):
         label[k.replace(' ', '')] = round(v['hbm_bytes_fetch_x2'])
     elif k.startswith('igemm3_kernel<') or k.startswith('igemm3dw_kernel<'):
         # the runtime labels the bf16x3 kernels without their last template argument (batch-norm prologue flag):
