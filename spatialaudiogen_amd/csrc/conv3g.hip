@@ -256,6 +256,79 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
         igemm_epilogue_maskmix<BM, BN, WM, WN, SMEM_BYTES / 4>(d, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
         return;
     }
+#ifndef SAGEN_C3G_LDS_EPILOGUE
+    // ---- epilogue straight from the accumulators (conv3h.hip: a workgroup's way out is bound by the number of instructions its waves
+    // issue - the form staged through LDS took 400 - 1 000 of them): branch-free, a row beyond M gets the out-of-range buffer offset
+    // and the scale 0 (which keeps it out of the sums); C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    {
+        const int colb = n0 + wn * WN + li;                          // column of this lane in N block j = 0
+        const bool plain = d.bias == nullptr && !d.relu_out;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.y, 0, d.y_bytes, 0x00020000);
+        const unsigned ldy4 = (unsigned)d.ldy * 4u;
+        const int mrow = m0 + wm * WM + 4 * kk;                      // first output row of this lane
+        const unsigned rbase = (unsigned)mrow * ldy4;
+        float bias_j[NT], cs[NT], cq[NT];
+        unsigned col4[NT];                                           // byte offset of the lane's column, OOB beyond N
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bool ok = colb + 32 * j < d.N;
+            col4[j] = ok ? (unsigned)(colb + 32 * j) * 4u : OOB;
+            bias_j[j] = (d.bias != nullptr && ok) ? d.bias[colb + 32 * j] : 0.f;
+            cs[j] = 0.f; cq[j] = 0.f;
+        }
+        auto epilogue = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;         // whole N tile inside N, no bias, no ReLU
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = i * 32 + (e & 3) + 8 * (e >> 2);  // (compile-time row offset)
+                    const bool ok = mrow + ro < d.M;
+                    const float sc = ok ? osc : 0.f;
+                    const unsigned roff = ok ? rbase + (unsigned)ro * ldy4 + (FAST ? (unsigned)(colb * 4) : 0u) : OOB;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        float v = acc[i][j][e] * sc;
+                        if (FAST) {
+                            cs[j] += v;
+                            cq[j] = __builtin_fmaf(v, v, cq[j]);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, roff, 128 * j, 0);
+                        } else {
+                            const unsigned off = ((roff | col4[j]) & OOB) ? OOB : roff + col4[j];
+                            if (col4[j] & OOB) v = 0.f;
+                            cs[j] += v;
+                            cq[j] = __builtin_fmaf(v, v, cq[j]);
+                            v += bias_j[j];
+                            if (d.relu_out) v = fmaxf(v, 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off, 0, 0);
+                        }
+                    }
+                }
+        };
+        if (plain && n0 + BN <= d.N) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        if (d.stats != nullptr) {                 // per-channel (sum, sumsq) of the raw output -> fp64 accumulators [2][N]
+            lds_barrier();                        // every wave is done with the last group's fragments: the ring is free
+            float* const red = reinterpret_cast<float*>(smem);               // [WAVES_M * 2 (lane halves)][2][BN]
+            static_assert(WAVES_M * 2 * 2 * BN * 4 <= SMEM_BYTES, "statistics staging must fit the ring");
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                red[((wm * 2 + kk) * 2 + 0) * BN + wn * WN + j * 32 + li] = cs[j];
+                red[((wm * 2 + kk) * 2 + 1) * BN + wn * WN + j * 32 + li] = cq[j];
+            }
+            lds_barrier();
+            for (int t = tid; t < 2 * BN; t += 256) {
+                const int which = t / BN, col = t - which * BN;
+                if (n0 + col < d.N) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < WAVES_M * 2; ++g) sum += red[(g * 2 + which) * BN + col];
+                    atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
+                }
+            }
+        }
+    }
+#else
     // ---- epilogue through the (now idle) ring (conv3p.hip): 16-byte row-contiguous stores, bias / ReLU,
     //      batch-norm statistics of the raw output ----
     const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
@@ -320,6 +393,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
             }
         }
     }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int KS, bool H2, int EPI = 0>
@@ -363,6 +437,11 @@ int conv3g_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
     const bool h2 = mm || tile == TILE_P3GH_128x64_K3 || tile == TILE_P3GH_64x64_K4 || tile == TILE_P3GH_128x128_K2 || tile == TILE_P3GH_64x128_K3;
     if (h2 != (d.xp3_fmt == 1)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the planes' format does not match the tile");
     if (h2 && (!d.wh2 || !d.h2_a_inv || !d.h2_w_inv)) return fail(SAGEN_ERR_NULL, "conv3g: the fp16x2 filter planes / scales are missing");
+    if (!mm) {
+        const long y_bytes = ((long)(d.M - 1) * d.ldy + d.N) * 4;       // extent of the dense output for the epilogue's buffer stores
+        if (y_bytes >= (1L << 31)) return fail(SAGEN_ERR_UNSUPPORTED, "conv3g: the output exceeds 2 GiB buffer addressing (use a smaller batch)");
+        d.y_bytes = (unsigned)y_bytes;
+    }
     d.p3_magic_wp = (unsigned)((1UL << 32) / (unsigned)d.Wg) + 1u;      // (reused fields: here the divisors are the OUTPUT grid's Wg, Hg)
     d.p3_magic_h = (unsigned)((1UL << 32) / (unsigned)d.Hg) + 1u;
     switch (tile) {
