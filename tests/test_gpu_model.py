@@ -258,7 +258,7 @@ def test_fp16x2_trunk_planes_hold_over_the_range_of_batch_norm_parameters(T, cas
     net.inference_ops(inp['audio'], inp['video'])
     kernels = {k for k, layer, us, fl in net.profile_report(B)}
     net.profile_enable(B, False)
-    assert any(k.startswith(('conv3h_kernel', 'conv3hr_kernel')) for k in kernels), kernels
+    assert any(k.startswith('conv3h') for k in kernels), kernels
     net.set_option(B, 'fp16x2', 0)
     other = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
     trunk3 = net.intermediate(B, 'video_encoder/conv5_2').cpu().numpy()

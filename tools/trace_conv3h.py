@@ -37,6 +37,7 @@ for nth in [int(x) for x in sys.argv[1:]] or [0, 5]:
     net.inference_ops(a, v)
     torch.cuda.synchronize()
     raw = buf.cpu().numpy()
+    if os.environ.get('DUMP'): np.save(os.path.join(os.environ['DUMP'], 'trace_launch%d.npy' % nth), raw)
     gt = raw[NWG * 8:].reshape(2, 64, 8)
     t = raw[:NWG * 8].reshape(NWG, 8)
     live = t[:, 3] != 0
