@@ -356,6 +356,10 @@ struct Fwd {
             // flight (7.27 -> 7.23 ms per step on one box), or when asked for (SAGEN_P3PP=1)
             static const bool p3pp = getenv("SAGEN_P3PP") != nullptr;
             if (!p3pp && !c->train_mode && (tile == TILE_P3PP_PAIR || tile == TILE_P3PP_SPLITK)) continue;
+            // conv3hr_kernel (three-deep activation ring) measured equal to conv3h_kernel on every layer: left out of
+            // the tuner so that equal candidates do not split a layer family over two kernel names from run to run (SAGEN_P3HR=1 adds it)
+            static const bool p3hr = getenv("SAGEN_P3HR") != nullptr;
+            if (!p3hr && (tile == TILE_P3HR_256x64 || tile == TILE_P3HR_128x64 || tile == TILE_P3HR_64x64_C2)) continue;
             const int nk = d.Kpad / igemm_tile_bk(tile);
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;
