@@ -50,11 +50,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
     constexpr int NMG = KS * NM1;
     static_assert(CNT <= NMG, "one DMA slot per MFMA slot at most");
     constexpr int NF = NPL * (MT + NT);
-    constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
-    static_assert(WM % RPP == 0, "a wave row is a whole number of store passes");
-    constexpr int EPI_TILE = WM * BN * 4, EPI_RED = 2 * RPP * BN * 4;
     constexpr int SMEM_BYTES = 2 * ST_BYTES;
-    static_assert(EPI_TILE + EPI_RED <= SMEM_BYTES, "epilogue staging must fit the ring");
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // ONE shared object (a second one makes hipcc drain vmcnt before every ds_read)
 
     const int tid = threadIdx.x;
@@ -256,7 +252,6 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
         igemm_epilogue_maskmix<BM, BN, WM, WN, SMEM_BYTES / 4>(d, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
         return;
     }
-#ifndef SAGEN_C3G_LDS_EPILOGUE
     // ---- epilogue straight from the accumulators (conv3h.hip: a workgroup's way out is bound by the number of instructions its waves
     // issue - the form staged through LDS took 400 - 1 000 of them): branch-free, a row beyond M gets the out-of-range buffer offset
     // and the scale 0 (which keeps it out of the sums); C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -328,72 +323,6 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
             }
         }
     }
-#else
-    // ---- epilogue through the (now idle) ring (conv3p.hip): 16-byte row-contiguous stores, bias / ReLU,
-    //      batch-norm statistics of the raw output ----
-    const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
-    char* const epi = smem;
-    float* const tile = reinterpret_cast<float*>(epi);                       // [WM][BN]
-    float* const red = reinterpret_cast<float*>(epi + EPI_TILE);             // [2][RPP][BN]
-    const int c4 = tid % TPR, rg = tid / TPR;
-    const int n = n0 + 4 * c4;
-    const bool vec_ok = n + 3 < d.N && ldy_ok;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias) {
-        bias.x = n < d.N ? d.bias[n] : 0.f; bias.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
-        bias.z = n + 2 < d.N ? d.bias[n + 2] : 0.f; bias.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
-    }
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int part = 0; part < WAVES_M; ++part) {
-        if (wm == part) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)      // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-                        tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = H2 ? acc[i][j][e] * osc : acc[i][j][e];
-        }
-        lds_barrier();
-        float4 tv[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) tv[k] = *reinterpret_cast<const float4*>(tile + (rg + k * RPP) * BN + 4 * c4);
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int m = m0 + part * WM + rg + k * RPP;
-            if (m >= d.M) continue;
-            float4 v = tv[k];
-            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
-            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            if (d.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            float* dst = d.y + (long)m * d.ldy + n;
-            if (vec_ok) *reinterpret_cast<float4*>(dst) = v;
-            else {
-                if (n < d.N) dst[0] = v.x;
-                if (n + 1 < d.N) dst[1] = v.y;
-                if (n + 2 < d.N) dst[2] = v.z;
-                if (n + 3 < d.N) dst[3] = v.w;
-            }
-        }
-        if (part + 1 < WAVES_M) lds_barrier();
-    }
-    if (d.stats != nullptr) {
-        *reinterpret_cast<float4*>(red + (0 * RPP + rg) * BN + 4 * c4) = cs;
-        *reinterpret_cast<float4*>(red + (1 * RPP + rg) * BN + 4 * c4) = cq;
-        lds_barrier();
-        for (int t = tid; t < 2 * BN; t += 256) {
-            const int which = t / BN, col = t - which * BN;
-            if (n0 + col < d.N) {
-                float sum = 0.f;
-#pragma unroll
-                for (int g = 0; g < RPP; ++g) sum += red[(which * RPP + g) * BN + col];
-                atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
-            }
-        }
-    }
-#endif
 }
 
 template <int BM, int BN, int WM, int WN, int KS, bool H2, int EPI = 0>

@@ -67,11 +67,7 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
     constexpr int CNT_MAX = KC * SPT;
     static_assert(CNT_MAX <= NMG, "one DMA slot per MFMA slot at most");
     constexpr int NF = 2 * (MT + NT);
-    [[maybe_unused]] constexpr int TPR = BN / 4, RPP = 256 / TPR, NPASS = WM / RPP;
-    static_assert(WM % RPP == 0, "a wave row is a whole number of store passes");
-    constexpr int EPI_TILE = WM * BN * 4, EPI_DENSE = BM * 4, EPI_RED = 2 * RPP * BN * 4;
     constexpr int SMEM_BYTES = KC * (AR * A_BYTES + 2 * B_BYTES);
-    static_assert(EPI_TILE + EPI_DENSE + EPI_RED <= SMEM_BYTES, "epilogue staging must fit the ring");
     static_assert(SMEM_BYTES == conv3h_lds(BM, BN, KC, AR), "occupancy bound uses the same footprint");
     static_assert(AR == 2 || A_INST % 4 == 0, "counted vmcnt: every wave issues the same number of activation instructions");
     // where stage sa of the activation ring / stage sb of the filter ring start (AR = 2: the interleaved layout [A0 B0 A1 B1])
@@ -320,7 +316,6 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
     }
 
     C3H_TRC(2);
-#ifndef SAGEN_C3H_LDS_EPILOGUE
     // ---- epilogue straight from the accumulators: x 2^-(ka + kw), bias / ReLU, batch-norm statistics.  C/D layout of 32x32: col =
     // lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a store instruction writes two 128-byte row segments.  A workgroup's way
     // out is bound by the NUMBER of instructions a wave has to issue (tools/trace_conv3h.py: 9.4 k cycles alone, 14 k beside the other
@@ -371,9 +366,7 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
                         if (FAST) {
                             cs[j] += v;
                             cq[j] = __builtin_fmaf(v, v, cq[j]);
-#ifndef C3H_ABLATE_STORE
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, roff, 128 * j, 0);
-#endif
                         } else {
                             const unsigned off = ((roff | col4[j]) & OOB) ? OOB : roff + col4[j];
                             if (col4[j] & OOB) v = 0.f;
@@ -404,91 +397,10 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
                 float sum = 0.f;
 #pragma unroll
                 for (int g = 0; g < WAVES_M * 2; ++g) sum += red[(g * 2 + which) * BN + col];
-#ifndef C3H_ABLATE_ATOMICS
-                atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
-#else
-                if (sum == 12345.678f) atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
-#endif
-            }
-        }
-    }
-#else
-    // ---- epilogue through the (now idle) ring: x 2^-(ka + kw), 16-byte row-contiguous stores, bias / ReLU, batch-norm statistics ----
-    const bool ldy_ok = (d.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(d.y) & 15) == 0);
-    lds_barrier();                                   // every wave is done with the last group's fragments
-    float* const tile = reinterpret_cast<float*>(smem);                              // [WM][BN]
-    int* const s_dense = reinterpret_cast<int*>(smem + EPI_TILE);                    // [BM] dense pixel index or -1
-    float* const red = reinterpret_cast<float*>(smem + EPI_TILE + EPI_DENSE);        // [2][RPP][BN]
-    for (int r = tid; r < BM; r += 256) {
-        const int p = m0 + r;
-        int dense = -1;
-        if (r < BME && p < NP) {
-            const int row = (int)__umulhi((unsigned)p, d.p3_magic_wp);   // p / Wp = b*H + h: one pad pixel per preceding row
-            if (p - row * Wp < W) dense = p - row;
-        }
-        s_dense[r] = dense;
-    }
-    const int c4 = tid % TPR, rg = tid / TPR;
-    const int n = n0 + 4 * c4;
-    const bool vec_ok = n + 3 < d.N && ldy_ok;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d.bias) {
-        bias.x = n < d.N ? d.bias[n] : 0.f; bias.y = n + 1 < d.N ? d.bias[n + 1] : 0.f;
-        bias.z = n + 2 < d.N ? d.bias[n + 2] : 0.f; bias.w = n + 3 < d.N ? d.bias[n + 3] : 0.f;
-    }
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int part = 0; part < WAVES_M; ++part) {
-        if (part > 0) lds_barrier();                  // the staging rows are rewritten by the next wave row
-        if (wm == part) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)      // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-                        tile[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk) * BN + wn * WN + j * 32 + li] = acc[i][j][e] * osc;
-        }
-        lds_barrier();
-        int dn[NPASS];
-        float4 tv[NPASS];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) dn[k] = s_dense[part * WM + rg + k * RPP];
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) tv[k] = *reinterpret_cast<const float4*>(tile + (rg + k * RPP) * BN + 4 * c4);
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            if (dn[k] < 0) continue;
-            float4 v = tv[k];
-            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
-            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            if (d.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            float* dst = d.y + (long)dn[k] * d.ldy + n;
-            if (vec_ok) *reinterpret_cast<float4*>(dst) = v;
-            else {
-                if (n < d.N) dst[0] = v.x;
-                if (n + 1 < d.N) dst[1] = v.y;
-                if (n + 2 < d.N) dst[2] = v.z;
-                if (n + 3 < d.N) dst[3] = v.w;
-            }
-        }
-    }
-    if (d.stats != nullptr) {                 // per-channel (sum, sumsq) of the raw output -> fp64 accumulators [2][N]
-        *reinterpret_cast<float4*>(red + (0 * RPP + rg) * BN + 4 * c4) = cs;
-        *reinterpret_cast<float4*>(red + (1 * RPP + rg) * BN + 4 * c4) = cq;
-        lds_barrier();
-        for (int t = tid; t < 2 * BN; t += 256) {
-            const int which = t / BN, col = t - which * BN;
-            if (n0 + col < d.N) {
-                float sum = 0.f;
-#pragma unroll
-                for (int g = 0; g < RPP; ++g) sum += red[(which * RPP + g) * BN + col];
                 atomicAdd(&d.stats[(long)which * d.N + n0 + col], (double)sum);
             }
         }
     }
-#endif
     C3H_TRC(3);
 #ifdef SAGEN_TRACE
     if (trc && tid == 0) trc[7] = __builtin_amdgcn_s_memrealtime();
