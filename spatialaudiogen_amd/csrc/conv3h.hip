@@ -363,6 +363,9 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         float v = acc[i][j][e] * sc;
+                        // the tile's last two rows were contracted from bytes BEHIND the activation image (the filter image, or - three-
+                        // deep ring - an image still in flight): whatever bit pattern that was, it must not reach the sums as 0 x NaN
+                        if (i == MT - 1 && e >= 14 && (rraw & OOB)) v = 0.f;
                         if (FAST) {
                             cs[j] += v;
                             cq[j] = __builtin_fmaf(v, v, cq[j]);
