@@ -222,6 +222,61 @@ def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
 
 
+_POISON_SRC = r"""
+#include <hip/hip_runtime.h>
+// every workgroup fills the whole LDS of its CU with fp16 NaN bit patterns and lingers until all CUs have one
+__global__ __launch_bounds__(256, 1) void poison_kernel(unsigned* sink) {
+    __shared__ unsigned lds[160 * 1024 / 4];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) lds[i] = 0x7fff7fffu;
+    __syncthreads();
+    unsigned acc = 0;
+    for (int k = 0; k < 64; ++k) { acc += lds[(threadIdx.x * 97 + k * 1031) % (160 * 1024 / 4)]; __builtin_amdgcn_s_sleep(64); }
+    if (acc == 12345u) sink[0] = acc;
+}
+extern "C" int poison_lds(void* sink) {
+    hipLaunchKernelGGL(poison_kernel, dim3(2048), dim3(256), 0, 0, (unsigned*)sink);
+    return (int)hipDeviceSynchronize();
+}
+"""
+
+
+@pytest.mark.parametrize('tile_name', ['conv3hr_kernel<256,64,64,64,1>', 'conv3h_kernel<64,64,32,32,4>'])
+def test_rows_a_conv3h_tile_drops_cannot_reach_the_statistics(T, tile_name, tmp_path):
+    """The last two rows of a conv3h tile are contracted from whatever lies BEHIND the activation image in LDS (the filter image;
+    with the three-deep ring an image that may still be in flight, i.e. bytes a previous kernel left).  The epilogue drops them by
+    the out-of-range store offset and must keep them out of the batch-norm sums whatever their bit pattern: fill every CU's LDS
+    with fp16 NaNs (a kernel built here with hipcc), then run the forward with the trunk pinned to the tile.  (The window in which a
+    dropped row can meet foreign bytes is narrow - the image behind has usually landed - so this run is a guard on the property, not a
+    proof of it: the select in the epilogue is.)"""
+    import ctypes, shutil, subprocess
+    from spatialaudiogen_amd.model import SptAudioGen
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src, lib = tmp_path / 'poison.hip', tmp_path / 'libpoison.so'
+    src.write_text(_POISON_SRC)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O2', '-fPIC', '-shared', str(src), '-o', str(lib)])
+    poison = ctypes.CDLL(str(lib)).poison_lds
+    poison.argtypes = [ctypes.c_void_p]
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=6, mode='test')
+    inp = synth_inputs(2, enc, seed=31)
+    ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.inference_ops(inp['audio'], inp['video'])
+    tile = SptAudioGen.tile_names().index(tile_name)
+    for name in variable_specs(enc):
+        if name.endswith('/weights') and name.startswith('video_encoder'):
+            net.plan_set(2, name[:-len('/weights')], tile, 1)
+    import torch
+    sink = torch.zeros(4, dtype=torch.int32, device='cuda')
+    for _ in range(3):
+        torch.cuda.synchronize()
+        assert poison(ctypes.c_void_p(sink.data_ptr())) == 0
+        out = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+        assert np.isfinite(out).all()
+        check_out(out, ref)
+
+
 @pytest.mark.parametrize('case', ['tiny', 'huge', 'mixed', 'offset'])
 def test_fp16x2_trunk_planes_hold_over_the_range_of_batch_norm_parameters(T, case):
     """conv3h_kernel evaluates the trunk's 3x3 convs on TWO fp16 planes per operand (three products per multiply).  fp16 has no
