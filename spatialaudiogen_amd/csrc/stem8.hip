@@ -30,6 +30,10 @@ constexpr int S8_PH = 8, S8_PW = 7;            // pooled rows / cols per patch
 constexpr int S8_RH = 2 * S8_PH + 1;           // raw rows per patch (17)
 constexpr int S8_RW = 2 * S8_PW + 1;           // raw cols per patch (15)
 constexpr int S8_M = S8_RH * S8_RW;            // 255
+// where raw pixel m of a patch sits in the staged raw tile (128 B per pixel): the pool reads pixels two apart (256 B = all 64 banks
+// once round) from eight lanes each, so a 16-lane ds_read_b128 group met the same 32 banks twice - every second pixel PAIR swaps its
+// two members and the group covers all 64 banks (rocprofv3: 7.0e6 bank-conflict cycles per launch = a third of the kernel's LDS cycles)
+__device__ __forceinline__ int s8_slot(int m) { return m ^ ((m >> 1) & 1); }
 constexpr int S8_UH = 229, S8_UW = 456;        // plane geometry: 2 + 224 + 3 rows, 2 + 448 + 6 pixels per row (row pitch 3648 B = 16 * 228)
 constexpr int S8_NH = 32;                      // output channels per workgroup: the two halves of the 64 run as separate workgroups
 constexpr int S8_W_BYTES = 14 * 3 * S8_NH * 32;   // this half's filter planes [K/16][plane][n][16] bf16 (43 KB; the fp16x2 variant: two planes, 29 KB)
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float v = fmaf(acc[0][e] + acc[1][e], osc, cbl);
-            ct[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * S8_NH + li] = v;
+            ct[s8_slot(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * S8_NH + li] = v;
             const float vo = ((own >> e) & 1u) ? v : 0.f;
             ssum += vo;
             ssq = fmaf(vo, vo, ssq);
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
                 const int p = it >> 3, q4 = it & 7;
                 const int r = p / (2 * S8_PW), cc = p - r * (2 * S8_PW);
                 *reinterpret_cast<float4*>(raw + (((long)b * 112 + R0 + r) * 224 + C0 + cc) * 64 + nh * S8_NH + 4 * q4) =
-                    *reinterpret_cast<const float4*>(ct + (r * S8_RW + cc) * S8_NH + 4 * q4);
+                    *reinterpret_cast<const float4*>(ct + s8_slot(r * S8_RW + cc) * S8_NH + 4 * q4);
             }
         }
         // pool 3x3 / 2 (TF SAME: nothing before, one row / column after -> clipped at the image edge): one item per thread
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
                     // (rows / columns past the image edge are clamped to the window's first row / column: max / min is unchanged by a duplicate)
                     const int rr = (R0 + 2 * pr_l + dr >= 112) ? 2 * pr_l : 2 * pr_l + dr;
                     const int cc = (C0 + 2 * pc_l + dc >= 224) ? 2 * pc_l : 2 * pc_l + dc;
-                    v[dr * 3 + dc] = *reinterpret_cast<const float4*>(ct + (rr * S8_RW + cc) * S8_NH + 4 * pch4);
+                    v[dr * 3 + dc] = *reinterpret_cast<const float4*>(ct + s8_slot(rr * S8_RW + cc) * S8_NH + 4 * pch4);
                 }
             float4 ext = v[0];
 #pragma unroll
