@@ -520,43 +520,44 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float* __restrict__ y, int ldy, int rep, float* __restrict__ amax_out) {
     const int NV = N / V;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)M * NV) {
-        if (amax_out != nullptr) igemm_publish_amax(amax_out, 0.f);     // (wave-wide: every lane takes part)
-        return;
-    }
-    const int m = (int)(idx / NV), n = (int)(idx - (long)m * NV) * V;
+    // no early return: the lanes past the end of a partial last wave keep v = 0, skip their loads / stores and meet the others at ONE
+    // converged igemm_publish_amax (its DPP / permlane reduction must not run under a partial EXEC mask: ADVICE r05)
+    const bool ok = idx < (long)M * NV;
+    const int m = ok ? (int)(idx / NV) : 0, n = ok ? (int)(idx - (long)m * NV) * V : 0;
     float v[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) v[i] = 0.f;
-    const long MN = (long)M * N;
-    const float* p = ws + (long)m * N + n;
-    int zz = 0;
-    if (V == 4)
-        for (; zz + 4 <= splitk; zz += 4, p += 4 * MN) {          // four partials in flight
-            const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + MN);
-            const float4 t2 = *reinterpret_cast<const float4*>(p + 2 * MN), t3 = *reinterpret_cast<const float4*>(p + 3 * MN);
-            v[0] += (t0.x + t1.x) + (t2.x + t3.x); v[1 % V] += (t0.y + t1.y) + (t2.y + t3.y);
-            v[2 % V] += (t0.z + t1.z) + (t2.z + t3.z); v[3 % V] += (t0.w + t1.w) + (t2.w + t3.w);
+    if (ok) {
+        const long MN = (long)M * N;
+        const float* p = ws + (long)m * N + n;
+        int zz = 0;
+        if (V == 4)
+            for (; zz + 4 <= splitk; zz += 4, p += 4 * MN) {          // four partials in flight
+                const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + MN);
+                const float4 t2 = *reinterpret_cast<const float4*>(p + 2 * MN), t3 = *reinterpret_cast<const float4*>(p + 3 * MN);
+                v[0] += (t0.x + t1.x) + (t2.x + t3.x); v[1 % V] += (t0.y + t1.y) + (t2.y + t3.y);
+                v[2 % V] += (t0.z + t1.z) + (t2.z + t3.z); v[3 % V] += (t0.w + t1.w) + (t2.w + t3.w);
+            }
+        for (; zz < splitk; ++zz, p += MN) {
+            if (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                v[0] += t.x; v[1 % V] += t.y; v[2 % V] += t.z; v[3 % V] += t.w;
+            } else {
+                v[0] += p[0];
+            }
         }
-    for (; zz < splitk; ++zz, p += MN) {
-        if (V == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            v[0] += t.x; v[1 % V] += t.y; v[2 % V] += t.z; v[3 % V] += t.w;
-        } else {
-            v[0] += p[0];
-        }
-    }
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-        if (bias) v[i] += bias[n + i];
-        if (relu) v[i] = fmaxf(v[i], 0.f);
+        for (int i = 0; i < V; ++i) {
+            if (bias) v[i] += bias[n + i];
+            if (relu) v[i] = fmaxf(v[i], 0.f);
+        }
+        for (int r = 0; r < rep; ++r) {
+            float* o = y + ((long)m * rep + r) * ldy + n;
+            if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+            else o[0] = v[0];
+        }
     }
-    for (int r = 0; r < rep; ++r) {
-        float* o = y + ((long)m * rep + r) * ldy + n;
-        if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
-        else o[0] = v[0];
-    }
-    if (amax_out != nullptr) {
+    if (amax_out != nullptr) {                                        // block-uniform condition: every lane of every wave arrives
         float a = 0.f;
 #pragma unroll
         for (int i = 0; i < V; ++i) a = fmaxf(a, fabsf(v[i]));

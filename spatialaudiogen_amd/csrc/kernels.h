@@ -263,7 +263,14 @@ int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B,
 size_t p3_bytes(int B, int H, int W, int C);
 // y = [relu](x*scale + shift [+ residual]) -> fp32 NHWC `y` (or null) and / or planes `p3` (or null)
 // fmt 0: three bf16 planes (conv3p / conv3g); fmt 1: two fp16 planes of v * 2^ka (conv3h.hip) - ka from the statistics in `h2`
-constexpr int H2_RIG_OFF = 240;         // the rigorous (Samuelson) bound of a tracked tensor lives this many floats behind its statistical bound
+// h2s (256 floats) layout: [0], [1] trunk plane 2^-ka; [2..5] tracked block-input bounds; [6] scratch; [7] saturation counter;
+// [H2S_FILTER_FIRST .. H2S_FIXED_FIRST) 2^-kw per fp16x2 filter; then the hard-wired a_inv slots; [2 + H2_RIG_OFF ..] rigorous bounds
+constexpr int H2S_FILTER_FIRST = 8;
+constexpr int H2S_FIXED_FIRST = 232;    // first slot that is NOT a filter scale: filter slots must stay below (model.hip checks)
+constexpr int H2S_A_INV_X = 232;        // [232..235] lean trunk: 2^-ka of the block-input planes, two alternating slots x (video, flow)
+constexpr int H2S_A_INV_B = 236;        // [236..237] lean trunk: 2^-ka of the conv_2 input planes (video, flow)
+constexpr int H2S_S16_A_INV = 238;      // [238..239] float-frame stem: 2^-ka of the frame planes (video, flow)
+constexpr int H2_RIG_OFF = 240;           // the rigorous (Samuelson) bound of a tracked tensor lives this many floats behind its statistical bound
 struct P3hScale {
     float* a_inv = nullptr;             // out: 2^-ka
     const float* res_bound = nullptr;   // in: bound of the residual tensor (identity shortcut), or null; [H2_RIG_OFF] behind it: its rigorous bound

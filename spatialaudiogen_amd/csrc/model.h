@@ -542,8 +542,8 @@ struct Fwd {
     float* h2_a_inv() { return c->p("h2s") + (sfx.empty() ? 0 : 1); }        // 2^-ka of the planes currently in this trunk's plane buffer
     // lean trunk (round 5, resnet()): the block input / output planes live in buffer "p3" with two alternating scale slots (a merge reads
     // its residual under the old scale while it publishes the new one), the conv_2 input planes in "p3b" with their own
-    float* h2_a_inv_x(int parity) { return c->p("h2s") + 232 + 2 * (parity & 1) + (sfx.empty() ? 0 : 1); }
-    float* h2_a_inv_b() { return c->p("h2s") + 236 + (sfx.empty() ? 0 : 1); }
+    float* h2_a_inv_x(int parity) { return c->p("h2s") + H2S_A_INV_X + 2 * (parity & 1) + (sfx.empty() ? 0 : 1); }
+    float* h2_a_inv_b() { return c->p("h2s") + H2S_A_INV_B + (sfx.empty() ? 0 : 1); }
     // statistical bound of the current block input / output (conv3h.hip, p3.hip: P3hScale), two slots used alternately so that a merge
     // reads its input's bound from one and publishes its output's bound into the other
     float* h2_xbound(int parity) { return c->p("h2s") + 2 + 2 * (parity & 1) + (sfx.empty() ? 0 : 1); }
@@ -619,7 +619,7 @@ struct Fwd {
         // copy of the pooled tensor.  The planes carry the value conv_1 saw (22 significant bits + the residual's sign).
         const bool no_lean = c->no_lean_trunk;
         const bool lean = !no_lean && h2() && pool_planes && c->use_p3g && c->bufs.count("p3b" + sfx) != 0 && !c->train_mode;
-        float* const s16_a_inv = c->p("h2s") + 238 + (sfx.empty() ? 0 : 1);        // 2^-ka of the frame planes
+        float* const s16_a_inv = c->p("h2s") + H2S_S16_A_INV + (sfx.empty() ? 0 : 1);        // 2^-ka of the frame planes
         if (fast16)
             timed("stem16_amax_kernel+stem16_prep_kernel", 0.0, [&] { return stem16_prep_launch(img, c->p("xpad" + sfx), c->p("s16:part" + sfx), s16_a_inv, B, s,
                                                                                                c->p("bnacc" + sfx), (long)c->bufs.at("bnacc" + sfx).n); });

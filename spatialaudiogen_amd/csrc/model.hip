@@ -163,9 +163,11 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         }
     }
     {   // 2^-kw slots of the fp16x2 filter planes, h2s[8 ..]
-        int slot = 8;
+        int slot = H2S_FILTER_FIRST;
         for (auto& kv : c->h2_slot) kv.second = slot++;
-        if (slot > 2 + H2_RIG_OFF) return fail(SAGEN_ERR_UNSUPPORTED, "too many fp16x2 layers for the scale table");
+        static_assert(H2S_A_INV_X + 4 <= H2S_A_INV_B && H2S_A_INV_B + 2 <= H2S_S16_A_INV && H2S_S16_A_INV + 2 <= H2_RIG_OFF &&
+                      2 + H2_RIG_OFF + 4 <= 256, "h2s: the fixed slots overlap");
+        if (slot > H2S_FIXED_FIRST) return fail(SAGEN_ERR_UNSUPPORTED, "too many fp16x2 layers for the scale table");
     }
     c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
     c->alloc("h2:amax", c->h2_slot.size() + h2_pack_blocks + 64);      // per-job maxima + per-workgroup partials

@@ -230,11 +230,13 @@ class SptAudioGen(object):
         y = self.inference_ops(audio, video, flow, out=out)
         B = y.shape[0]
         ctx = self.context_for(B)
-        if not hasattr(self, '_sat_seen'):
-            self._sat_seen, self.saturation_events = {}, []
+        if not hasattr(self, 'saturation_events'):
+            self.saturation_events = []
+        # the last-seen value lives ON the context: the native counter is the context's, and load_variables() replaces the contexts
+        # (a count kept per batch size on this object would go stale against a fresh context's zero: ADVICE r05)
         now = ctx.counter('fp16x2_saturations')
-        clamped = now - self._sat_seen.get(B, 0)
-        self._sat_seen[B] = now
+        clamped = now - getattr(ctx, 'sat_seen', 0)
+        ctx.sat_seen = now
         if clamped <= 0:
             return y
         if on_saturation == 'raise':

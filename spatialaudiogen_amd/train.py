@@ -583,14 +583,10 @@ def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_
     history = []
     t_last, n_last = time.time(), init_step
     step = init_step
-    # tf.train.Saver(max_to_keep=1) across --resume: the previous run's periodic bundle is the one to drop at the next periodic save
+    # tf.train.Saver(max_to_keep=1), train.py:176: the Saver only ever deletes bundles IT saved in this session (saver.restore does
+    # not register the restored one), so nothing this run did not write is touched - hand-kept milestones, another experiment's
+    # bundles and the bundle --resume restored all stay (the directory is never globbed).
     last_periodic = None
-    stale = []
-    if rank == 0 and os.path.isdir(model_dir):
-        import re
-        found = [(int(m.group(1)), os.path.join(model_dir, m.group(0)[:-len('.index')]))
-                 for m in (re.match(r'model\.ckpt-(\d+)\.index$', f) for f in os.listdir(model_dir)) if m]
-        stale = [pfx for _, pfx in sorted(found)]
     flag = None
     sat_seen = tr.ctx.counter('fp16x2_saturations') if hasattr(tr, 'ctx') else 0
     try:
@@ -628,10 +624,9 @@ def train_loop(tr, batches, model_dir, n_iters, init_step=0, log_every=20, ckpt_
             if step % ckpt_every == 0 and step != 0 and rank == 0:
                 prefix = tr.save(model_dir, global_step=tr.opt.step)
                 from .checkpoint import remove_checkpoint
-                for old in stale + ([last_periodic] if last_periodic else []):     # tf.train.Saver(max_to_keep=1), train.py:176
-                    if old != prefix:
-                        remove_checkpoint(old)
-                stale, last_periodic = [], prefix
+                if last_periodic and last_periodic != prefix:               # max_to_keep=1 over this run's own periodic saves
+                    remove_checkpoint(last_periodic)
+                last_periodic = prefix
                 log('=' * 60 + '\nCheckpoint saved\n' + '=' * 60)
     finally:
         if torch.cuda.is_available():

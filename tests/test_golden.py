@@ -56,11 +56,58 @@ def test_hip_path_reproduces_golden(name):
     assert err <= 1e-4 and err <= 1e-3 * rms(ref), (name, err, rms(ref))
 
 
+def tf1_pin_problems(tf1, cases=None):
+    """Why a tf1_v1.npz cannot serve as the pin of the CURRENT case table ([] = it can): a case of tools/make_golden.py missing from
+    it, or a case whose '<case>/fingerprint' (tools/tf1_pin_inputs.py: checksums of the weights and inputs the TF1 run was fed)
+    differs from the one the current seeds / initialisers give."""
+    import tf1_pin_inputs as K
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    bad = []
+    for name, (enc, B, ws, ins) in sorted((cases or G.CASES).items()):
+        if name + '/ambix' not in tf1 or name + '/fingerprint' not in tf1:
+            bad.append('%s: no output / no fingerprint in the file' % name)
+            continue
+        want = K.fingerprint(init_weights(variable_specs(enc), seed=ws, mode='test'), synth_inputs(B, enc, seed=ins))
+        got = np.asarray(tf1[name + '/fingerprint'], np.float64)
+        if got.shape != want.shape or not np.allclose(got, want, rtol=1e-9, atol=1e-9):
+            bad.append('%s: computed from other weights / inputs than the current case table gives' % name)
+    return bad
+
+
+def test_a_tf1_pin_that_is_present_must_not_be_stale():
+    """tests/golden/tf1_v1.npz absent = parity UNPINNED (the tests below skip and say so).  PRESENT but made from another case table
+    (seeds, initialisers, batch sizes changed since tools/tf1_pin_inputs.py wrote its inputs) = FAIL, never a silent skip or a
+    comparison against outputs of other inputs."""
+    if TF1 is None:
+        pytest.skip(UNPINNED)
+    bad = tf1_pin_problems(TF1)
+    assert not bad, 'tests/golden/tf1_v1.npz is STALE against tools/tf1_pin_inputs.py: %s - rerun the pin kit' % '; '.join(bad)
+
+
+def test_the_staleness_check_tells_a_current_pin_from_a_stale_one():
+    """The check itself, on synthetic files (audio-only case: small): a pin whose fingerprint matches passes, one made with another
+    weight seed, one without a fingerprint and one lacking the case are all reported."""
+    import tf1_pin_inputs as K
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
+    name = 'a_b2_s0'
+    enc, B, ws, ins = G.CASES[name]
+    cases = {name: G.CASES[name]}
+    amb = np.zeros((B, 4800, 3), np.float32)
+    good = {name + '/ambix': amb, name + '/fingerprint': K.fingerprint(init_weights(variable_specs(enc), seed=ws, mode='test'), synth_inputs(B, enc, seed=ins))}
+    assert tf1_pin_problems(good, cases) == []
+    other = dict(good)
+    other[name + '/fingerprint'] = K.fingerprint(init_weights(variable_specs(enc), seed=ws + 7, mode='test'), synth_inputs(B, enc, seed=ins))
+    assert len(tf1_pin_problems(other, cases)) == 1 and 'other weights' in tf1_pin_problems(other, cases)[0]
+    assert len(tf1_pin_problems({name + '/ambix': amb}, cases)) == 1
+    assert len(tf1_pin_problems({}, cases)) == 1
+
+
 @pytest.mark.parametrize('name', sorted(G.CASES))
 def test_oracle_matches_what_tf1_computed(name):
     """The pin: the numpy oracle against the outputs of the reference's own graph (BASELINE.json: <= 1e-4 RMS vs TF1)."""
     if TF1 is None:
         pytest.skip(UNPINNED)
+    assert not tf1_pin_problems(TF1, {name: G.CASES[name]}), 'stale tf1_v1.npz'
     out = G.run_case(name)
     ref = TF1[name + '/ambix'].astype(np.float64)
     err = rms(out[name + '/ambix'].astype(np.float64) - ref)
@@ -78,6 +125,7 @@ def test_oracle_matches_what_tf1_computed(name):
 def test_hip_path_matches_what_tf1_computed(name):
     if TF1 is None:
         pytest.skip(UNPINNED)
+    assert not tf1_pin_problems(TF1, {name: G.CASES[name]}), 'stale tf1_v1.npz'
     import torch
     from spatialaudiogen_amd.model import SptAudioGen
     from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
@@ -111,3 +159,4 @@ def test_pin_kit_inputs_carry_every_variable_under_its_checkpoint_name():
         assert tuple(d['a_b2_s0/var/' + k].shape) == tuple(shape) and d['a_b2_s0/var/' + k].dtype == np.float32
     assert d['a_b2_s0/in/audio'].shape == (2, 52799, 1) and str(d['a_b2_s0/encoders']) == 'audio'
     assert sum(1 for k in d if k.startswith('a_b2_s0/var/')) == len(specs)
+    assert d['a_b2_s0/fingerprint'].shape == (5,) and d['a_b2_s0/fingerprint'][0] == len(specs)

@@ -127,17 +127,21 @@ def test_train_loop_keeps_one_periodic_checkpoint(tmp_path):
     assert int(load_checkpoint(latest_checkpoint(d))['step']) == 9
 
 
-def test_resume_prunes_the_previous_runs_periodic_checkpoints(tmp_path):
-    """max_to_keep=1 across --resume: the periodic bundles a previous process left behind go at the first periodic save of this one."""
+def test_resume_never_deletes_bundles_this_run_did_not_write(tmp_path):
+    """tf.train.Saver(max_to_keep=1) only deletes bundles it saved in the current session (saver.restore registers nothing): bundles
+    a previous process, another experiment or the user left in model_dir - including the one --resume restored - survive; this
+    run's own periodic saves still keep one."""
     from spatialaudiogen_amd.checkpoint import save_checkpoint
     d = str(tmp_path)
-    for n in (3, 5):                                                 # left by an earlier run (two: e.g. one that died mid-prune)
+    for n in (3, 5):                                                 # left by an earlier run / kept by hand
         save_checkpoint(os.path.join(d, 'model.ckpt-%d' % n), {'step': np.asarray(n, np.int32), 'w': np.zeros(6, np.float32)})
+    save_checkpoint(os.path.join(d, 'milestone.ckpt-5'), {'step': np.asarray(5, np.int32), 'w': np.zeros(6, np.float32)})
     tr = _FakeTrainer()
     tr.opt.step = 5
-    T.train_loop(tr, _endless(), d, n_iters=9, init_step=5, log_every=2, ckpt_every=2, log=lambda *_: None)
+    T.train_loop(tr, _endless(), d, n_iters=11, init_step=5, log_every=2, ckpt_every=2, log=lambda *_: None)
     files = sorted(f for f in os.listdir(d) if f.endswith('.index'))
-    assert files == ['model.ckpt-9.index', 'model.ckpt.index'], files
+    # this run saved after steps 6, 8, 10 (opt.step 7, 9, 11): only its last periodic bundle is left of those
+    assert files == ['milestone.ckpt-5.index', 'model.ckpt-11.index', 'model.ckpt-3.index', 'model.ckpt-5.index', 'model.ckpt.index'], files
 
 
 class _FakeCtx(object):

@@ -1,7 +1,9 @@
 #!/bin/bash
 # 1 / 2 / 4 / 8-GPU sweep of bench.py on ONE node (one rank per GPU over RCCL) and a table of the lines.
 #   tools/scale_sweep.sh [config=av] [steps=30] [warmup=5]          (configs: av a avf eval train)
-# Needs as many GPUs as the largest N it runs (it stops at what `rocm-smi` / torch sees).  Output: gpurun_out/scale_<config>.jsonl
+# Needs as many GPUs as the largest N it runs (it stops at what `rocm-smi` / torch sees).  Output: gpurun_out/scale_<config>.jsonl (the
+# bench lines) and gpurun_out/SCALE_<config>.json - ONE JSON object in the shape of the driver's SCALE record: metric / unit / config
+# and per N {n_gpus, value, ms_per_step, ranks_seen, backend, efficiency_vs_n1} - also printed as the last line of stdout.
 set -u
 cd "$(dirname "$0")/.."
 CFG=${1:-av}; STEPS=${2:-30}; WARM=${3:-5}
@@ -36,4 +38,12 @@ for r in rows:
     if x:
         print('       gradient exchange: step %.2f ms, comm stream waiting for gradients %.2f ms, in all-reduce %.2f ms, last all-reduce done at %.2f ms'
               % (x['step_ms'], x['waiting_for_gradients_ms'], x['in_all_reduce_ms'], x['last_all_reduce_done_ms']))
+scale = {'metric': rows[0]['metric'], 'unit': rows[0]['unit'], 'scaling': rows[0].get('scaling'), 'config': rows[0].get('config'),
+         'steps': rows[0]['steps'], 'warmup': rows[0]['warmup'],
+         'points': [{'n_gpus': r['n_gpus'], 'value': r['value'], 'ms_per_step': r['ms_per_step'],
+                     'ranks_seen': (r.get('ranks') or {}).get('ranks_seen'), 'backend': (r.get('ranks') or {}).get('backend'),
+                     'efficiency_vs_n1': r['value'] / (base * r['n_gpus'])} for r in rows]}
+out = sys.argv[1].replace('scale_', 'SCALE_').replace('.jsonl', '.json')
+json.dump(scale, open(out, 'w'), indent=1)
+print(json.dumps(scale))
 PY

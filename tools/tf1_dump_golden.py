@@ -76,6 +76,8 @@ def run_case(name, data, ref_dir):
                 fetch['chk/' + key] = net.ends[key]
         got = sess.run(fetch, feed_dict=feeds)
     out[name + '/ambix'] = np.asarray(got['ambix'], np.float32)
+    if name + '/fingerprint' in data:                                      # ties the outputs to the weights / inputs they came from
+        out[name + '/fingerprint'] = np.asarray(data[name + '/fingerprint'], np.float64)
     for k, v in got.items():
         if k.startswith('chk/'):
             out['%s/%s' % (name, k)] = checksum(v)

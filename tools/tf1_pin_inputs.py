@@ -16,6 +16,19 @@ import make_golden as G
 from spatialaudiogen_amd.weights import variable_specs, init_weights, synth_inputs
 
 
+def fingerprint(P, inp):
+    """What ties an output file to the EXACT weights and inputs it was computed from: float64 [number of variables, sum over the
+    variables of sum(v), of sum(v^2), then sum / sum of squares of every input present].  tools/tf1_dump_golden.py copies it through
+    ('<case>/fingerprint'); tests/test_golden.py recomputes it from the current case table and FAILS on a mismatch (a stale pin)."""
+    f = [float(len(P)), sum(float(np.asarray(v, np.float64).sum()) for v in P.values()),
+         sum(float((np.asarray(v, np.float64) ** 2).sum()) for v in P.values())]
+    for k in ('audio', 'video', 'flow'):
+        if k in inp:
+            x = np.asarray(inp[k], np.float32).astype(np.float64)
+            f += [float(x.sum()), float((x ** 2).sum())]
+    return np.array(f, np.float64)
+
+
 def build():
     data = {}
     for name, (enc, B, ws, ins) in G.CASES.items():
@@ -26,6 +39,7 @@ def build():
         for k, v in inp.items():
             data['%s/in/%s' % (name, k)] = np.asarray(v, np.float32)
         data['%s/encoders' % name] = np.array(','.join(enc))
+        data['%s/fingerprint' % name] = fingerprint(P, inp)
     return data
 
 
