@@ -100,7 +100,12 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int W = d.Win, H = d.Hin, Wp = W + 1, NP = d.p3_np;
     const int nchunk = d.Cin >> 4;
-    const int G = 3 * nchunk / KC;                         // (nchunk % KC == 0: conv3h_dispatch)
+    // dh-split (round 6; d.splitk == 3, grid.y = filter row): workgroup (tile, dh) contracts ONE vertical tap - a third of the K loop,
+    // three times the workgroups - and writes a raw partial tile [dh][M][N]; splitk_reduce_stats_kernel sums the three and takes the
+    // batch-norm statistics.  The grid runs all dh = 0 workgroups first: the third of the filter they stream stays in the XCD's L2.
+    const bool dhs = d.splitk == 3;
+    const int dh_z = dhs ? (int)blockIdx.y : 0;
+    const int G = (dhs ? 1 : 3) * nchunk / KC;             // (nchunk % KC == 0: conv3h_dispatch)
     const int nM = (NP + BME - 1) / BME, nN = (d.N + BN - 1) / BN;
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.xp3, 0, d.xp3_bytes, 0x00020000);
@@ -153,7 +158,7 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
 
     // issue state (SGPRs): the activation group and the filter group being issued (AR = 2: the same group; AR = 3: the activation
     // tracker runs one group ahead of the filter tracker)
-    int qa_dh = 0, qa_ch = 0, cur_dh = -1, qb_dh = 0, qb_ch = 0;
+    int qa_dh = dh_z, qa_ch = 0, cur_dh = -1, qb_dh = dh_z, qb_ch = 0;
     unsigned i_asoff = 0, i_bsoff = 0;
     char* i_astage = smem;
     char* i_bstage = smem;
@@ -324,7 +329,8 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
     // out-of-range buffer offset and the scale 0, which also keeps it out of the sums - 4 instructions per value, 12 per row.
     const int colb = n0 + wn * WN + li;                              // column of this lane in N block j = 0
     const bool plain = d.bias == nullptr && !d.relu_out;             // (the batch-norm convs of the trunk)
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.y, 0, d.y_bytes, 0x00020000);
+    // (dh-split: conv3h_dispatch pointed y at the partials [3][M][N] with ldy = N; partial dh_z starts y_bytes further on)
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)d.y + (size_t)dh_z * d.y_bytes), 0, d.y_bytes, 0x00020000);
     const unsigned ldy4 = (unsigned)d.ldy * 4u;
     const int plim = min(NP, m0 + BME);
     float bias_j[NT], cs[NT], cq[NT];
@@ -427,8 +433,10 @@ static int launch_conv3h(const IgemmDesc& d, hipStream_t s) {
     if ((d.Cin / 16) % KC) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: %d channel chunks are not a multiple of %d per group", d.Cin / 16, KC);
     const int per = (cdiv(d.p3_np, BM - 2) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
-    if constexpr (AR == 3) hipLaunchKernelGGL((conv3hr_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
+    if constexpr (AR == 3) {
+        if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3hr: no dh-split (the three-deep ring needs three groups)");
+        hipLaunchKernelGGL((conv3hr_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
+    } else hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN, KC>), dim3(grid, d.splitk), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -447,7 +455,12 @@ int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
 #endif
     if (!d.xp3 || d.p3_np <= 0 || d.xp3_fmt != 1) return fail(SAGEN_ERR_NULL, "conv3h: the fp16x2 activation planes are missing");
     if (!d.wh2 || !d.h2_a_inv || !d.h2_w_inv) return fail(SAGEN_ERR_NULL, "conv3h: the fp16x2 filter planes / scales are missing");
-    if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: no split-K");
+    if (d.splitk != 1 && d.splitk != 3) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: split-K only as the dh-split (3), got %d", d.splitk);
+    if (d.splitk == 3) {             // partials [dh][M][N] (dense rows): the reducer applies bias / ReLU / statistics
+        if (!d.splitk_ws || d.bias || d.relu_out || d.stats) return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: the dh-split writes raw partials (no bias / ReLU / statistics)");
+        d.y = d.splitk_ws;
+        d.ldy = d.N;
+    }
     if ((long)(d.p3_np + 512) * (d.Win + 1) >= (1L << 32) || ((long)(d.p3_np + 512) / (d.Win + 1) + 1) * d.Hin >= (1L << 32))
         return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: too many pixels for 32-bit index arithmetic");
     if ((long)d.p3_np * 64 >= (1L << 31) || (long)d.xp3_cstride * (d.Cin / 16) >= (1L << 31) || d.xp3_bytes == 0)

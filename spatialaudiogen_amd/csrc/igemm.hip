@@ -351,6 +351,10 @@ static bool dw3_ok(const IgemmDesc& d) {
 }
 bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].split; }
 bool igemm_tile_p3(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].p3; }
+// conv3h_kernel tiles can split K by the filter row (dh-split, split-K = 3 exactly); the three-deep-ring variant cannot
+bool igemm_tile_dh_split(IgemmTile t) {
+    return t >= 0 && t < TILE_AUTO && kTiles[t].p3 && kTiles[t].h && !kTiles[t].g && t != TILE_P3HR_256x64 && t != TILE_P3HR_128x64 && t != TILE_P3HR_64x64_C2;
+}
 bool igemm_p3_eligible(const IgemmDesc& d) { return dw3_ok(d) && d.w_split && d.dsh * d.dsw == 1 && d.Cin <= MAX_BN_C; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }
 static int tile_bn(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bn : 0; }
@@ -377,7 +381,7 @@ bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
             return false;
     }
     if (kTiles[t].dw3 && !dw3_ok(d)) return false;
-    if (kTiles[t].p3 && (d.xp3 == nullptr || d.splitk != 1)) return false;
+    if (kTiles[t].p3 && (d.xp3 == nullptr || (d.splitk != 1 && !(d.splitk == 3 && igemm_tile_dh_split(t))))) return false;
     if (kTiles[t].p3 && (kTiles[t].h ? (d.xp3_fmt != 1 || d.wh2 == nullptr) : d.xp3_fmt != 0)) return false;   // the planes' format decides the family
     if (!kTiles[t].p3 && d.xp3 != nullptr && d.x == nullptr) return false;      // only the planes were provided
     if (kTiles[t].g) return conv3g_ok(d);                                        // gathered operand tiles: any stride / tap set on the plane rows

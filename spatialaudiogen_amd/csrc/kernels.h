@@ -161,6 +161,7 @@ bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel 
 constexpr int SK_TICKETS = 8192;                      // tiles an in-launch split-K combine can track (IgemmDesc::sk_ticket)
 inline bool igemm_tile_fused_splitk(IgemmTile) { return true; }     // every kernel that writes split-K partials does it through igemm_epilogue
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
+bool igemm_tile_dh_split(IgemmTile t);                // ... except conv3h_kernel's dh-split: split-K = 3 exactly, one filter row per workgroup
 bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]),  r in [0,rep); with `stats` also the

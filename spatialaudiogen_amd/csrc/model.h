@@ -106,6 +106,7 @@ struct sagen_ctx {
     bool train_h2 = true;                  // the training step's forward also runs the trunk's stride-1 3x3 convs on the fp16x2 planes (SAGEN_TRAIN_NO_H2=1: bf16x3)
     bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
     bool train_h2d = true;                 // ... and its backward runs the stride-1 3x3 data gradients on fp16x2 planes of dy, written by the batch-norm backward (SAGEN_TRAIN_NO_H2D=1: bf16x3 on fp32 dy)
+    bool no_dh_split = false;              // SAGEN_NO_DH_SPLIT=1: the tuner does not consider conv3h_kernel's dh-split (one filter row per workgroup, round 6)
     bool sk_fused = false;                 // SAGEN_SK_FUSED=1: split-K partials are combined inside the contraction (last-arriver, igemm_epilogue) instead of by a reducer launch - bit-identical, measured no faster
     bool train_h2w = true;                 // ... and the weight gradients of those layers run on the planes too (wgrad3h.hip): the forward retains its activation planes (SAGEN_TRAIN_NO_H2W=1: bf16x3 on the fp32 tensors)
     std::map<std::string, int> h2d_slot;   // per data-gradient filter: index of its 2^-kw in the "t:h2d" table
@@ -364,8 +365,12 @@ struct Fwd {
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;
             for (int sk : SKS) {
-                if (sk > 1 && (!allow_split || !dense || igemm_tile_p3(tile))) break;
-                if (sk > 1 && (nk / sk < 4 || (size_t)sk * d.M * d.N > ws_capacity())) break;
+                if (sk > 1 && (!allow_split || !dense)) break;
+                if (sk > 1 && igemm_tile_p3(tile)) {                     // plane-fed kernels: only conv3h_kernel's dh-split (3)
+                    if (!igemm_tile_dh_split(tile) || sk > 3 || c->no_dh_split) break;
+                    if (sk != 3) continue;
+                }
+                if (sk > 1 && ((nk / sk < 4 && !igemm_tile_p3(tile)) || (size_t)sk * d.M * d.N > ws_capacity())) break;
                 if (sk == 1 && (rep > 1 || custom_reduce) && (size_t)d.M * d.N > ws_capacity()) continue;
                 const long blocks = (long)cdiv(d.M, bm) * cdiv(d.N, bn) * sk;
                 if (sk > 1 && blocks > 8192) break;                     // more parallelism than the chip can use
@@ -412,7 +417,8 @@ struct Fwd {
         } else if (it != c->plan.end()) {
             ch = it->second;
             if (!igemm_tile_ok(d, (IgemmTile)ch.tile)) ch = heuristic(d, rep, allow_split);
-            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || igemm_tile_p3((IgemmTile)ch.tile) || d.Kpad / igemm_tile_bk((IgemmTile)ch.tile) / ch.splitk < 1)) ch.splitk = 1;
+            const bool dh3 = ch.splitk == 3 && igemm_tile_dh_split((IgemmTile)ch.tile);
+            if (ch.splitk > 1 && (!allow_split || !dense_out(d) || (igemm_tile_p3((IgemmTile)ch.tile) && !dh3) || d.Kpad / igemm_tile_bk((IgemmTile)ch.tile) / ch.splitk < 1)) ch.splitk = 1;
         } else {
             ch = heuristic(d, rep, allow_split);
         }

@@ -44,6 +44,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     c->train_h2d = getenv("SAGEN_TRAIN_NO_H2D") == nullptr;
     c->train_h2w = getenv("SAGEN_TRAIN_NO_H2W") == nullptr;
     c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
+    c->no_dh_split = getenv("SAGEN_NO_DH_SPLIT") != nullptr;
     c->no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
     c->train_bands = getenv("SAGEN_TRAIN_NO_BANDS") == nullptr;
     c->train_rawpool = getenv("SAGEN_TRAIN_NO_RAWPOOL") == nullptr;

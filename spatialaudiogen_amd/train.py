@@ -665,6 +665,10 @@ def parse_arguments(argv=None):
     ap.add_argument('--freq_mask_units', default=SEP_FREQ_MASK_FCUNITS_DEF, nargs='*', type=int)
     ap.add_argument('--loc_units', default=LOC_FCUNITS_DEF, nargs='+', type=int)
     ap.add_argument('--gpu', type=int, default=0)
+    ap.add_argument('--pretrained', default=None, metavar='resnet18.npy',
+                    help="ImageNet initialisation of the ResNet18 trunks: the reference's pyutils/tflib/models/image/resnet18.npy (a pickled "
+                         '{variable name without scope: array}; resnet.py:238-249, run at train.py:182-184).  Assigned after the initialisers, '
+                         'before a --resume restore (which then overwrites it, as in the reference)')
     ap.add_argument('--synthetic', action='store_true', help='synthetic inputs / targets instead of a dataset folder')
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args(argv)
@@ -704,6 +708,11 @@ def main(argv=None):
                                                sep_fft_window=args.fft_window))
     # initialisers of the reference (core.py:13,34; fc3 ~ N(0, 0.001^2), model.py:255); the same replica on every rank
     P = init_weights(net.variable_specs(), seed=args.seed, mode='bench', fc3_std=0.001)
+    if args.pretrained:                  # sess.run(rest_ops), train.py:182-184: both trunks start from the ImageNet ResNet18
+        from .weights import load_pretrained_resnet18
+        names = load_pretrained_resnet18(P, args.pretrained, specs=net.variable_specs())
+        if rank == 0:
+            print('Initialised %d trunk variables from %s' % (len(names), args.pretrained))
     tr = Trainer(net, batch=args.batch_size, lr=args.lr, lr_iters=args.lr_iters, lr_decay=args.lr_decay, variables=P)
     init_step = tr.restore(args.model_dir) if args.resume else 0
     if args.synthetic:

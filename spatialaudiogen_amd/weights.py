@@ -95,6 +95,34 @@ def variable_specs(encoders, separation=FREQ_MASK, num_sep_tracks=32, loc_units=
     return s
 
 
+def load_pretrained_resnet18(variables, pretrained, specs=None):
+    """ResNet18.restore_pretrained (resnet.py:238-249), run by train.py:182-184 right after the initialisers and BEFORE an optional
+    --resume restore: every MODEL variable under `video_encoder/` and `flow_encoder/` (conv weights and the four batch-norm vectors of
+    every layer, model.py:198-199 -> cnn.restore_pretrained(inp_shape[-1], scope)) is assigned `pretrained[<name without the scope>]`.
+
+    `pretrained`: the dict of `resnet18.npy` (np.load(...).all() in the reference: one pickled {name: array}) or a path to such a
+    file.  As in the reference a variable of the trunk that the blob lacks is a KeyError, and an array of another shape an error
+    (tf.assign would refuse it) - nothing is assigned in that case.  Both trunks receive the SAME ImageNet values (the flow trunk too:
+    its input has three channels as well).  Returns the names assigned, in order; `variables` is updated in place."""
+    if isinstance(pretrained, str):
+        blob = np.load(pretrained, allow_pickle=True, encoding='latin1')       # (a Python 2 pickle)
+        pretrained = blob.item() if hasattr(blob, 'item') and getattr(blob, 'dtype', None) == object else dict(blob)
+    staged = OrderedDict()
+    for name in (specs if specs is not None else variables):
+        for scope in ('video_encoder', 'flow_encoder'):
+            if name.startswith(scope + '/'):
+                key = name[len(scope) + 1:]
+                if key not in pretrained:
+                    raise KeyError('resnet18 blob has no %r (needed by %s)' % (key, name))
+                v = np.asarray(pretrained[key], np.float32)
+                want = tuple(specs[name]) if specs is not None else tuple(np.shape(variables[name]))
+                if tuple(v.shape) != want:
+                    raise ValueError('resnet18 blob: %r has shape %s, %s needs %s' % (key, tuple(v.shape), name, want))
+                staged[name] = np.ascontiguousarray(v)
+    variables.update(staged)
+    return list(staged)
+
+
 def count_params(specs):
     return int(sum(int(np.prod(v)) for v in specs.values()))
 

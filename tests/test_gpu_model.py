@@ -222,6 +222,43 @@ def test_forced_plans_cover_every_tile_and_splitk_path(T, tile, splitk):
     check_out(net.inference_ops(inp['audio'], inp['video']).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('tile_name', ['conv3h_kernel<128,64,64,32,1>', 'conv3h_kernel<128,128,64,64,1>', 'conv3h_kernel<64,64,32,32,1>',
+                                       'conv3h_kernel<256,64,64,64,1>', 'conv3h_kernel<128,64,64,32,2>', 'conv3h_kernel<64,64,32,32,2>',
+                                       'conv3h_kernel<64,64,32,32,4>'])
+@pytest.mark.parametrize('B', [2, 5])
+def test_dh_split_of_every_conv3h_tile(T, tile_name, B):
+    """Round 6: conv3h_kernel with one workgroup per (tile, FILTER ROW) - split-K = 3 over the vertical taps, raw partials [3][M][N],
+    summed (+ batch-norm statistics) by splitk_reduce_stats_kernel.  Every conv3h tile forced onto every stride-1 3x3 trunk conv with the
+    split: the launches really are split (the profile shows the reducer behind the conv), and the output holds the oracle's bar and
+    agrees with the unsplit run of the same tile."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio', 'video']
+    P = init_weights(variable_specs(enc), seed=8, mode='test')
+    inp = synth_inputs(B, enc, seed=47)
+    ref = SptAudioGenOracle(encoders=enc).inference_ops(inp['audio'], P, video=inp['video'])
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    net.inference_ops(inp['audio'], inp['video'])
+    tid = SptAudioGen.tile_names().index(tile_name)
+    trunk = [n[:-len('/weights')] for n in variable_specs(enc) if n.endswith('/weights') and '_encoder/conv' in n and '/conv1/' not in n
+             and 'shortcut' not in n and not n.endswith(('3_1/conv_1/weights', '4_1/conv_1/weights', '5_1/conv_1/weights'))]
+    assert len(trunk) == 13
+    outs = {}
+    for sk in (1, 3):
+        for name in trunk:
+            net.plan_set(B, name, tid, sk)
+        net.profile_enable(B, True)
+        outs[sk] = net.inference_ops(inp['audio'], inp['video']).cpu().numpy()
+        rows = net.profile_report(B)
+        net.profile_enable(B, False)
+        for name in trunk:
+            kernels = [k for k, layer, _, _ in rows if layer == name]
+            assert tile_name in kernels, (name, kernels)
+            assert ('splitk_reduce_kernel' in kernels) == (sk == 3), (name, sk, kernels)
+    check_out(outs[3], ref)
+    assert rms(outs[3] - outs[1]) <= 2e-5 * max(rms(outs[1]), 1e-9) + 1e-7, rms(outs[3] - outs[1])
+
+
 _POISON_SRC = r"""
 #include <hip/hip_runtime.h>
 // every workgroup fills the whole LDS of its CU with fp16 NaN bit patterns and lingers until all CUs have one

@@ -227,3 +227,54 @@ def test_nan_on_one_rank_stops_every_rank_in_the_same_step(tmp_path):
     for rank, err, steps in res:
         assert err and 'NaN' in err, (rank, err)
         assert steps == 5                                            # the NaN appears in step 4, a logged step: both stop after it
+
+
+def _fake_resnet18_blob(rng, drop=None, reshape=None):
+    from spatialaudiogen_amd.weights import resnet18_specs
+    blob = {}
+    for name, shape in resnet18_specs('S').items():
+        key = name[2:]
+        if key == drop:
+            continue
+        blob[key] = rng.standard_normal(shape if key != reshape else tuple(shape) + (1,)).astype(np.float32)
+    return blob
+
+
+def test_pretrained_resnet18_initialises_both_trunks_by_name(tmp_path):
+    """--pretrained (resnet.py:238-249 at train.py:182-184) on a synthetic blob: every model variable of BOTH trunks (weights, shortcuts
+    and the four batch-norm vectors per layer) takes `blob[name without scope]`; nothing else moves; the file form is the reference's
+    (one pickled dict in a .npy); a missing key is a KeyError and a wrong shape an error, with nothing assigned."""
+    from spatialaudiogen_amd.weights import variable_specs, init_weights, load_pretrained_resnet18, resnet18_specs
+    enc = ['audio', 'flow', 'video']
+    specs = variable_specs(enc)
+    P0 = init_weights(specs, seed=3, mode='bench')
+    blob = _fake_resnet18_blob(np.random.default_rng(0))
+    fn = str(tmp_path / 'resnet18.npy')
+    np.save(fn, np.array(blob, dtype=object), allow_pickle=True)
+    P = dict((k, np.array(v)) for k, v in P0.items())
+    names = load_pretrained_resnet18(P, fn, specs=specs)
+    assert len(names) == 2 * len(resnet18_specs('S')) and len(names) == sum(1 for k in specs if k.split('/')[0] in ('video_encoder', 'flow_encoder'))
+    for k in specs:
+        scope = k.split('/')[0]
+        if scope in ('video_encoder', 'flow_encoder'):
+            assert np.array_equal(P[k], blob[k[len(scope) + 1:]]), k
+        else:
+            assert np.array_equal(P[k], P0[k]), k
+    assert np.array_equal(P['video_encoder/conv3_1/shortcut/weights'], P['flow_encoder/conv3_1/shortcut/weights'])
+    assert np.array_equal(P['video_encoder/conv5_2/conv_2/bn/moving_variance'], blob['conv5_2/conv_2/bn/moving_variance'])
+    # audio + video only: the flow trunk is not in the graph, nothing of it is touched or required
+    specs_av = variable_specs(['audio', 'video'])
+    Pav = init_weights(specs_av, seed=3, mode='bench')
+    assert len(load_pretrained_resnet18(Pav, blob, specs=specs_av)) == len(resnet18_specs('S'))
+    for bad, err in ((_fake_resnet18_blob(np.random.default_rng(1), drop='conv4_2/conv_1/bn/gamma'), KeyError),
+                     (_fake_resnet18_blob(np.random.default_rng(1), reshape='conv2_1/conv_1/weights'), ValueError)):
+        Q = dict((k, np.array(v)) for k, v in P0.items())
+        with pytest.raises(err):
+            load_pretrained_resnet18(Q, bad, specs=specs)
+        assert all(np.array_equal(Q[k], P0[k]) for k in specs)
+
+
+def test_train_cli_accepts_pretrained():
+    a = T.parse_arguments(['db', 'model', '--pretrained', '/x/resnet18.npy', '--synthetic'])
+    assert a.pretrained == '/x/resnet18.npy'
+    assert T.parse_arguments(['db', 'model']).pretrained is None
