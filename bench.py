@@ -65,6 +65,10 @@ SUSTAINED_NOTE = ('achieved / 290 TFLOP/s = the fp32-equivalent rate a pure v_mf
                   'normally distributed operands (1.66-1.81 PFLOP/s bf16: profiles/r03_mfma_sustained.txt); `frac` above is against the data-sheet peak')
 
 
+DEFAULT_GROUP = 1
+DEFAULT_IN_FLIGHT = 3
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -73,7 +77,7 @@ def parse():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='av')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the one-in-flight and H2D-inclusive legs (they run after the timed region)')
-    ap.add_argument('--in-flight', type=int, default=3,
+    ap.add_argument('--in-flight', type=int, default=DEFAULT_IN_FLIGHT,
                     help='batches in flight per GPU: steps rotate over this many native contexts, each on its own stream, the streams '
                          'probed to really run concurrently (DESIGN.md 6.1); 1 = strictly one forward at a time (round 4: three, measured '
                          '2 210 against 2 083-2 131 ambisonic-s/s with two on one box - the fp16x2 kernels leave LDS and registers for a third '
@@ -84,6 +88,11 @@ def parse():
     ap.add_argument('--no-autotune', action='store_true', help='use shape heuristics instead of the timed per-layer plan')
     ap.add_argument('--plan-file', default=None, help='replay this saved launch plan if it exists, else autotune and save it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg')
+    ap.add_argument('--group', type=int, default=DEFAULT_GROUP,
+                    help='batches per grouped launch (include/sagen.h: sagen_forward_grouped): each native context carries this many INDEPENDENT batches '
+                         'of the configuration per forward call, one launch per layer - every batch keeps its own batch-norm statistics and its '
+                         'output is bit-identical to a forward of that batch alone (tests/test_gpu_grouped.py); a step is still ONE batch: K steps = '
+                         'K / group calls (+ one smaller call for a remainder).  1 = one batch per call (rounds 1-5)')
     ap.add_argument('--no-repeats', action='store_true', help='skip the four extra timed regions behind the headline (headline_repeats)')
     ap.add_argument('--no-pmc', action='store_true',
                     help='do not measure roofline.traffic in this run (two short child processes of this script under rocprofv3 --pmc, when '
@@ -328,7 +337,7 @@ def main_train(args, cfg):
         'fp16x2_families_us_per_step': round(sum(a[1] for k, a in agg.items() if k.startswith(('conv3h', 'wgrad3h')) or (k.startswith('conv3g') and k.rstrip('>').endswith('true'))) / nprof, 1),
         'bf16x3_families_us_per_step': round(sum(a[1] for k, a in agg.items() if k.startswith(('igemm3', 'conv3p', 'wgrad3_', 'wgrad3r')) or (k.startswith('conv3g') and not k.rstrip('>').endswith('true'))) / nprof, 1),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
+        'launches_per_step': round(n_l / nprof / G, 2), 'batches_per_launch': G, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
         'share_of_step_time': round(us_l / total_us, 3),
         'phases_us_per_step': {k: round(v[0] / nprof, 1) for k, v in sorted(by_phase.items())},
         'phases_tflops': {k: round(v[1] / (v[0] * 1e-6) / 1e12, 1) for k, v in sorted(by_phase.items()) if v[1] > 0},
@@ -339,7 +348,7 @@ def main_train(args, cfg):
                        'achieved_over_fp32_mfma_peak': round(step_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
                        'gflop_per_window_launched': round(total_fl / nprof / BATCH / 1e9, 2),
                        'gflop_per_window_forward_needed_only': cfg['gflop'],
-                       'kernel_time_us_per_step': round(total_us / nprof, 1)},
+                       'kernel_time_us_per_step': round(total_us / nprof / G, 1)},
     }
     result = {
         'metric': 'ambisonic seconds trained/sec (0.1 s windows, 224x448 video; one Adam step per batch)',
@@ -408,7 +417,7 @@ def pmc_traffic_in_run(args, net, batch, dom):
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(tmp, ctr)
             cmd = [prof, '--pmc', ctr, '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
-                   '--config', args.config, '--in-flight', '1', '--plan-file', plan_fn, '--no-cpu-baseline', '--no-other-configs'] + \
+                   '--config', args.config, '--in-flight', '1', '--group', str(args.group), '--plan-file', plan_fn, '--no-cpu-baseline', '--no-other-configs'] + \
                   (['--float-frames'] if args.float_frames else [])
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=240)
             fs = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
@@ -471,7 +480,9 @@ def main():
     # eval: a pool of distinct synthetic windows stands in for the 9216 windows of the clip set (window w of the global order
     # uses pool entry w % pool); the other configurations: each rank owns one batch of its own windows
     # (the other configurations cycle over three distinct batches of this rank's own windows: no step re-reads the inputs of the one before)
-    NPOOL = 4 if is_eval else 3
+    G = 1 if is_eval else max(1, args.group)            # batches per grouped call (eval keeps one: its metrics run per batch)
+    CALLB = G * BATCH                                   # windows per forward call
+    NPOOL = 4 if is_eval else (3 if G == 1 else 2 * G)  # resident batches (G > 1: two distinct input sets per call, alternated)
     POOL = NPOOL * BATCH
     inp = synth_inputs(POOL, ENCODERS, seed=1234 + (0 if is_eval else rank))
     # Steps are independent batches, so NF of them are kept in flight: step i runs on native context i % NF and stream
@@ -479,7 +490,7 @@ def main():
     # one batch; the kernels of neighbouring steps fill each other's launch tails.  Outputs are bit-identical to
     # strictly sequential execution (tests/test_gpu_streams.py, tools/two_in_flight.py).
     NF = max(1, args.in_flight)
-    nets = [SptAudioGen(1, encoders=ENCODERS, separation='unet_mask') for _ in range(NF)]
+    nets = [SptAudioGen(1, encoders=ENCODERS, separation='unet_mask', groups=G) for _ in range(NF)]
     for n in nets:
         n.load_variables(P)
     net = nets[0]
@@ -498,11 +509,11 @@ def main():
         dev_in['video'] = u8
         frames_note = 'uint8 as decoded (x / 255 - 0.5 applied on the device), sagen_forward_u8'
 
-    def batch_inputs(b):                # device views of the windows of (global) batch b
-        lo = (b * BATCH) % POOL
-        return [dev_in[k][lo:lo + BATCH] for k in names_in]
+    def batch_inputs(b):                # device views of the windows of (global) batch b - of call b's G batches when grouped
+        lo = (b * CALLB) % POOL
+        return [dev_in[k][lo:lo + CALLB] for k in names_in]
 
-    outs = [torch.empty(BATCH, 4800, 3, device='cuda') for _ in range(NF)]
+    outs = [torch.empty(CALLB, 4800, 3, device='cuda') for _ in range(NF)]
     metric = torch.zeros(14, dtype=torch.float64, device='cuda')
     eval_sums = [torch.zeros(12, dtype=torch.float64, device='cuda') for _ in range(NF)]
     counter = [0]
@@ -514,7 +525,8 @@ def main():
         my_batches = list(range(lo_b, hi_b))
         steps = min(args.steps, len(my_batches)) if args.steps > 0 else len(my_batches)
     else:
-        my_batches, steps = list(range(NPOOL)), args.steps
+        my_batches, steps = list(range(NPOOL // G)), args.steps
+    n_calls, rem = steps // G, steps % G                # K steps (batches) = n_calls grouped calls + one call of the `rem` left over
 
     # (built ONCE: a torch.tensor(list, device='cuda') inside the step is a blocking pageable-host copy behind the forward just
     #  enqueued on the same stream - it made the launching thread wait for every forward and took the batches out of flight)
@@ -593,28 +605,48 @@ def main():
         n.inference_ops(*a0)
         for layer, tile, sk, _ in plan:
             n.plan_set(BATCH, layer, names.index(tile) if tile in names else 0, sk)
+    tail = None
+    if rem:                             # K % G batches left over: one call of a context with that many groups, in the timed region
+        tail = SptAudioGen(1, encoders=ENCODERS, separation='unet_mask', groups=rem)
+        tail.load_variables(P)
+        tail_in = [t[:rem * BATCH] for t in a0]
+        tail_out = torch.empty(rem * BATCH, 4800, 3, device='cuda')
+        tail.inference_ops(*tail_in, out=tail_out)
+        for layer, tile, sk, _ in plan:
+            tail.plan_set(BATCH, layer, names.index(tile) if tile in names else 0, sk)
+        tail.inference_ops(*tail_in, out=tail_out)
+
+    def region():                       # K steps: n_calls grouped calls rotating over the contexts in flight, then the remainder
+        for _ in range(n_calls):
+            step()
+        if tail is not None:
+            with torch.cuda.stream(streams[0] if NF > 1 else torch.cuda.current_stream()):
+                tail.inference_ops(*tail_in, out=tail_out)
     torch.cuda.synchronize()
     if args.pmc_child:                  # under rocprofv3 --pmc: a few forwards of the replayed plan on ONE context, nothing else
         for _ in range(3):
             net.inference_ops(*a0, out=outs[0])
         torch.cuda.synchronize()
         return
-    for _ in range(args.warmup):
+    for _ in range((args.warmup + G - 1) // G):
         step()
     reduce_metric()                     # also loads the torch kernels it uses before the timed region
     for e in eval_sums:
         e.zero_()
     counter[0] = 0
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_calls)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(n_calls):
         st = streams[counter[0] % NF] if NF > 1 else torch.cuda.current_stream()
         ev[i][0].record(st)
         step()
         ev[i][1].record(st)
+    if tail is not None:
+        with torch.cuda.stream(streams[0] if NF > 1 else torch.cuda.current_stream()):
+            tail.inference_ops(*tail_in, out=tail_out)
     reduce_metric()
     torch.cuda.synchronize()
     barrier()
@@ -649,8 +681,7 @@ def main():
         for _ in range(4):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(steps):
-                step()
+            region()
             reduce_metric()
             torch.cuda.synchronize()
             reps.append(0.1 * BATCH * steps / (time.perf_counter() - t1))
@@ -666,13 +697,13 @@ def main():
         for _ in range(ks):
             net.inference_ops(*a, out=outs[0])          # context 0 on the current stream, nothing else in flight
         torch.cuda.synchronize()
-        extra['one_in_flight'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
-                                  'note': 'strictly sequential forwards on one context (this rank x n_gpus), %d steps' % ks}
+        extra['one_in_flight'] = {'value': round(0.1 * CALLB * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
+                                  'note': 'strictly sequential forward calls on one context (this rank x n_gpus), %d calls of %d batch(es)' % (ks, G)}
         if float_video is not None and not args.float_frames:
             def float_inputs(b):        # the SAME three resident batches the headline cycles, frames as float32
-                lo = (b * BATCH) % POOL
-                return [float_video[lo:lo + BATCH] if k == 'video' else dev_in[k][lo:lo + BATCH] for k in names_in]
-            kf = steps                  # as long as the headline's region
+                lo = (b * CALLB) % POOL
+                return [float_video[lo:lo + CALLB] if k == 'video' else dev_in[k][lo:lo + CALLB] for k in names_in]
+            kf = max(n_calls, 1)        # as long as the headline's region
             for j in range(NF):
                 nets[j].inference_ops(*float_inputs(my_batches[j % len(my_batches)]), out=outs[j])
             torch.cuda.synchronize()
@@ -683,7 +714,7 @@ def main():
                 with ctx:
                     nets[j].inference_ops(*float_inputs(my_batches[i % len(my_batches)]), out=outs[j])
             torch.cuda.synchronize()
-            extra['float_frames'] = {'value': round(0.1 * BATCH * world * kf / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
+            extra['float_frames'] = {'value': round(0.1 * CALLB * world * kf / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
                                      'note': 'the same forward on float32 frames (the float entry point sagen_forward: the stem runs stem8pool_kernel<MODE 1> on '
                                              'two fp16 planes of x * 2^ka, ka from the exact maximum of the batch - three products per multiply where the uint8 '
                                              'stem needs two, plus the amax / prep passes over 45 MB instead of 16 MB of frames); the same %d resident batches '
@@ -725,7 +756,7 @@ def main():
         t1 = time.perf_counter()
         h2d_loop(ks)
         torch.cuda.synchronize()
-        extra['h2d_inclusive'] = {'value': round(0.1 * BATCH * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
+        extra['h2d_inclusive'] = {'value': round(0.1 * CALLB * world * ks / (time.perf_counter() - t1), 2), 'unit': 'ambisonic-s/s',
                                   'note': 'inputs start in pinned host memory (video frames as uint8, normalised on the device): %.1f MB copied per batch on a copy stream into '
                                           'the second of two device buffer sets while the previous batch of the context runs; %d batches in flight, %d steps' % (mb, NF, ks)}
 
@@ -739,7 +770,7 @@ def main():
         net.inference_ops(*a0, out=outs[0])              # context 0 alone on the current stream: unoverlapped launch times
         for k, layer, us, fl in net.profile_report(BATCH):
             a = agg.setdefault(k, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += us; a[2] += fl
+            a[0] += 1; a[1] += us; a[2] += fl * G          # (the runtime reports the work of ONE group; a grouped launch carries G)
     net.profile_enable(BATCH, False)
     total_us = sum(a[1] for a in agg.values())
     dom = max((k for k in agg if agg[k][2] > 0), key=lambda k: agg[k][1])        # the dominant CONTRACTION (the path is matrix-bound)
@@ -809,7 +840,11 @@ def main():
                    'weights': 'random init (Xavier / BN identity), same replica on every rank',
                    'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics',
                    'video_frames': frames_note if 'video' in dev_in else None,
-                   'batches_in_flight': NF},
+                   'batches_in_flight': NF * G, 'contexts_in_flight': NF, 'batches_per_grouped_launch': G,
+                   'grouped_launch': None if G == 1 else
+                   ('every forward call carries %d INDEPENDENT batches of %d windows as one launch per layer (sagen_forward_grouped: the group is a grid '
+                    'dimension; own batch-norm statistics / plane scales per batch, outputs bit-identical to one call per batch - '
+                    'tests/test_gpu_grouped.py); a step is one batch: %d steps = %d calls%s' % (G, BATCH, steps, n_calls, ' + one call of %d' % rem if rem else ''))},
         'ranks': ranks,
         'step_latency_ms_event': {'median': round(float(np.median(step_ms)), 4), 'p10': round(step_ms[len(step_ms) // 10], 4),
                           'p90': round(step_ms[(9 * len(step_ms)) // 10], 4)},

@@ -111,6 +111,21 @@ int    sagen_forward(sagen_ctx* ctx, const float* audio, const float* video, con
  * would have produced.  Host -> device traffic per window: 301 KB instead of 1.2 MB. */
 int    sagen_forward_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video_u8, const float* flow,
                         float* ambi_yzx, void* stream);
+/* Grouped launch (round 6).  The reference runs ONE sess.run per batch (deploy.py:141, eval.py:145) and its batch-norm couples the
+ * windows OF a batch (model.py:197, resnet.py:123: is_training=True), so a batch is the unit of work.  A grouped context runs
+ * `groups` INDEPENDENT batches of cfg->batch windows as ONE launch per layer (the group is a grid dimension of every kernel): each
+ * batch keeps its own batch-norm statistics, plane scales and maxima, and its output is bit-identical to what sagen_forward[_u8] of
+ * an ungrouped context gives for that batch alone - the semantics per batch are untouched, the fixed cost of a launch is paid once
+ * per `groups` batches.  sagen_create_grouped: as sagen_create; sagen_workspace_bytes then covers `groups` copies of the per-batch
+ * region (the packed filters are shared).  sagen_forward_grouped[_u8]: audio [groups*B, snd_size], video / flow [groups*B,224,448,3],
+ * ambi_yzx [groups*B, snd_dur, 3] - the batches back to back; `groups` must be the context's.  FREQ_MASK separation and the default
+ * arithmetic only (sagen_set_option values that leave it are refused at the next forward); sagen_forward[_u8] on a grouped context
+ * (groups > 1) is an error, as is the training step.  sagen_get_intermediate returns group 0's tensors. */
+int    sagen_create_grouped(sagen_ctx** out, const sagen_config* cfg, int groups);
+int    sagen_forward_grouped(sagen_ctx* ctx, int groups, const float* audio, const float* video, const float* flow,
+                             float* ambi_yzx, void* stream);
+int    sagen_forward_grouped_u8(sagen_ctx* ctx, int groups, const float* audio, const uint8_t* video_u8, const float* flow,
+                                float* ambi_yzx, void* stream);
 /* deploy.py:143-152: out[b, n, :] = [mono[b, snd_contx/2 + n], ambi_yzx[b, n, 0..2]] -> [B,snd_dur,4] WYZX */
 int    sagen_assemble_wyzx(const float* audio, const float* ambi_yzx, float* out_wyzx,
                            int batch, int snd_size, int snd_contx, int snd_dur, void* stream);

@@ -42,6 +42,9 @@ SIGNATURES = {
     'sagen_bind_weights': (C.c_int, [_P, C.POINTER(SagenTensor), _I, _P, _SZ, _P]),
     'sagen_forward': (C.c_int, [_P, _P, _P, _P, _P, _P]),
     'sagen_forward_u8': (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    'sagen_create_grouped': (C.c_int, [C.POINTER(_P), C.POINTER(SagenConfig), _I]),
+    'sagen_forward_grouped': (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
+    'sagen_forward_grouped_u8': (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     'sagen_assemble_wyzx': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'sagen_get_intermediate': (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64)]),

@@ -6,7 +6,8 @@
 #include <algorithm>
 
 struct sagen_ctx;
-int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg);
+int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups = 1);
+int sagen_groups_impl(const sagen_ctx* c);
 int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* workspace, size_t workspace_bytes, hipStream_t s);
 int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, const float* flow, float* out, hipStream_t s);
 int sagen_forward_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video_u8, const float* flow, float* out, hipStream_t s);
@@ -40,6 +41,11 @@ namespace sagen {
 char* err_buf() {
     static thread_local char buf[512] = {0};
     return buf;
+}
+
+GroupInfo& cur_group() {
+    static thread_local GroupInfo gi;
+    return gi;
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -93,11 +99,26 @@ int sagen_bind_weights(sagen_ctx* ctx, const sagen_tensor* tensors, int n, void*
                        void* stream) {
     return guarded([&] { return sagen_bind_impl(ctx, tensors, n, workspace, workspace_bytes, (hipStream_t)stream); });
 }
+int sagen_create_grouped(sagen_ctx** out, const sagen_config* cfg, int groups) {
+    return guarded([&] { return sagen_create_impl(out, cfg, groups); });
+}
+static int check_groups(const sagen_ctx* ctx, int groups, const char* fn) {
+    if (!ctx) return fail(SAGEN_ERR_NULL, "%s: null ctx", fn);
+    if (sagen_groups_impl(ctx) != groups)
+        return fail(SAGEN_ERR_SHAPE, "%s: %d group(s) asked of a context created for %d (sagen_create_grouped)", fn, groups, sagen_groups_impl(ctx));
+    return SAGEN_OK;
+}
 int sagen_forward(sagen_ctx* ctx, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {
-    return guarded([&] { return sagen_forward_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
+    return guarded([&] { const int rc = check_groups(ctx, 1, "sagen_forward"); return rc ? rc : sagen_forward_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
 }
 int sagen_forward_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video_u8, const float* flow, float* ambi_yzx, void* stream) {
-    return guarded([&] { return sagen_forward_u8_impl(ctx, audio, video_u8, flow, ambi_yzx, (hipStream_t)stream); });
+    return guarded([&] { const int rc = check_groups(ctx, 1, "sagen_forward_u8"); return rc ? rc : sagen_forward_u8_impl(ctx, audio, video_u8, flow, ambi_yzx, (hipStream_t)stream); });
+}
+int sagen_forward_grouped(sagen_ctx* ctx, int groups, const float* audio, const float* video, const float* flow, float* ambi_yzx, void* stream) {
+    return guarded([&] { const int rc = check_groups(ctx, groups, "sagen_forward_grouped"); return rc ? rc : sagen_forward_impl(ctx, audio, video, flow, ambi_yzx, (hipStream_t)stream); });
+}
+int sagen_forward_grouped_u8(sagen_ctx* ctx, int groups, const float* audio, const uint8_t* video_u8, const float* flow, float* ambi_yzx, void* stream) {
+    return guarded([&] { const int rc = check_groups(ctx, groups, "sagen_forward_grouped_u8"); return rc ? rc : sagen_forward_u8_impl(ctx, audio, video_u8, flow, ambi_yzx, (hipStream_t)stream); });
 }
 int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                            int64_t* pixel_stride) {

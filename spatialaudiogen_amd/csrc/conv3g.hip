@@ -32,7 +32,9 @@ constexpr int conv3g_wgs_per_cu(int BM, int BN, int KS, bool H2) {
 // EPI 0: dense NHWC rows (+ bias / ReLU / batch-norm statistics); EPI 1: the fused decoder tail of deconv1 (igemm_epilogue_maskmix:
 // sigmoid + track-weighted sums per mask bin, IgemmDesc::mm_*) on the depth-to-space tile
 template <int BM, int BN, int WM, int WN, int KS, bool H2, int EPI = 0>
-__global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g_kernel(const IgemmDesc d) {
+__global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g_kernel(const IgemmDesc d_in) {
+    IgemmDesc d = d_in;
+    if (d.grp.G > 1) igemm_relocate(d, (int)blockIdx.z);              // grouped launch (common.h)
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
@@ -329,7 +331,7 @@ template <int BM, int BN, int WM, int WN, int KS, bool H2, int EPI = 0>
 static int launch_conv3g(const IgemmDesc& d, hipStream_t s) {
     const int per = (cdiv(d.M, BM) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
-    hipLaunchKernelGGL((conv3g_kernel<BM, BN, WM, WN, KS, H2, EPI>), dim3(grid), dim3(256), 0, s, d);
+    hipLaunchKernelGGL((conv3g_kernel<BM, BN, WM, WN, KS, H2, EPI>), dim3(grid, 1, d.grp.G), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -91,6 +91,7 @@ static int channel_aligned_grid(long n4, int C4) {
 
 int bn_apply_relu_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, const float* residual,
                          float* y, long n_pixels, int C, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "bn_apply_relu: C=%d must be a multiple of 4", C);
     const long n4 = n_pixels * (C / 4);
     const int grid = channel_aligned_grid(n4, C / 4);
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float4* __restr
 
 int maxpool3x3s2_launch(const float* x, const float* scale, const float* shift, const BnRef& bn, float* y, int B, int H,
                         int W, int C, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     if (C % 4) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool: C=%d must be a multiple of 4", C);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(256) void pad_u8_nhwc3to4_kernel(const unsigned cha
 }
 
 int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     const int Hp = H + pt + pb, Wp = W + pl + pr;
     const long total = (long)B * Hp * Wp;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
@@ -199,6 +202,7 @@ int pad_u8_nhwc3to4_launch(const unsigned char* x, float* y, int B, int H, int W
 }
 
 int pad_nhwc3to4_launch(const float* x, float* y, int B, int H, int W, int pt, int pb, int pl, int pr, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     const int Hp = H + pt + pb, Wp = W + pl + pr;
     const long total = (long)B * Hp * Wp;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(256) void nosep_mix_kernel(const float* __restrict_
 
 int nosep_mix_launch(const float* audio, const float* coeffs, float* out, int B, int snd_size, int snd_contx,
                      int snd_dur, int num_out, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     const long total = (long)B * snd_dur * num_out;
     hipLaunchKernelGGL(nosep_mix_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, audio, coeffs, out, B, snd_size,
                        snd_contx / 2, snd_dur, num_out);

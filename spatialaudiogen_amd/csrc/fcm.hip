@@ -149,6 +149,7 @@ int fcm_pick_slices(int K, long weights) {
 }
 
 int fcm_launch(const FcmDesc& d, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     if (d.M <= 0 || d.M > FCM_MAX_M || d.njobs < 1 || d.njobs > FCM_MAX_JOBS || d.nseg < 1 || d.nseg > FCM_MAX_SEG || d.nslices < 1)
         return fail(SAGEN_ERR_SHAPE, "fcm: M=%d jobs=%d segments=%d slices=%d", d.M, d.njobs, d.nseg, d.nslices);
     if (d.K % (8 * d.nslices)) return fail(SAGEN_ERR_UNSUPPORTED, "fcm: K=%d must be a multiple of 8 x %d slices", d.K, d.nslices);

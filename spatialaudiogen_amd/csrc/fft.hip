@@ -85,9 +85,14 @@ __device__ __forceinline__ float2* fft1024(float2* a, float2* b, int tid) {
 // -----------------------------------------------------------------------------------------
 // STFT: grid (ceil(nframes/2), B). hop 256, window 1024, periodic Hann.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ audio, int n_samples, int f0, int f1,
-                                                   float* __restrict__ mag, int c0, int c1, float2* __restrict__ spec,
-                                                   float* __restrict__ zero_ptr, int zero_n) {
+__global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ audio_, int n_samples, int f0, int f1,
+                                                   float* __restrict__ mag_, int c0, int c1, float2* __restrict__ spec_,
+                                                   float* __restrict__ zero_ptr_, int zero_n, const GroupInfo gi) {
+    // grouped launch (common.h): the caller's audio holds the groups back to back (gridDim.y windows each); outputs per group
+    const float* __restrict__ audio = audio_ + (size_t)blockIdx.z * ((size_t)gridDim.y * n_samples);
+    float* __restrict__ mag = SAGEN_GRP(mag_);
+    float2* __restrict__ spec = SAGEN_GRP(spec_);
+    float* __restrict__ zero_ptr = SAGEN_GRP(zero_ptr_);
     __shared__ float2 bufA[1024], bufB[1024];
     const int tid = threadIdx.x;
     // (the forward's first kernel on this stream also clears a small buffer for it - the maxima words of the decoder's concat
@@ -135,8 +140,9 @@ int stft_launch(const float* audio, int B, int n_samples, int f0, int f1, float*
     if (spec && (c0 < f0 || c1 > f1 || c1 <= c0)) return fail(SAGEN_ERR_SHAPE, "stft: spec frames must lie in [f0,f1)");
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
-    hipLaunchKernelGGL(stft_kernel, dim3(cdiv(f1 - f0, 2), B), dim3(256), 0, s, audio, n_samples, f0, f1, mag, c0, c1,
-                       (float2*)spec, zero_ptr, zero_ptr ? zero_n : 0);
+    const GroupInfo gi = cur_group();
+    hipLaunchKernelGGL(stft_kernel, dim3(cdiv(f1 - f0, 2), B, gi.G), dim3(256), 0, s, audio, n_samples, f0, f1, mag, c0, c1,
+                       (float2*)spec, zero_ptr, zero_ptr ? zero_n : 0, gi);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -151,9 +157,14 @@ constexpr int MASK_F_LO = 1, MASK_F_HI = 24, MASK_NF = MASK_F_HI - MASK_F_LO;   
 constexpr int OUT_SHIFT = 1216;   // 768 + 448
 
 template <int NTR>
-__global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ dmask, long dmask_bstride, int dmask_f0,
-                                                         const float2* __restrict__ spec, const float* __restrict__ coeffs,
-                                                         float* __restrict__ frames, const float* __restrict__ ebuf) {
+__global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ dmask_, long dmask_bstride, int dmask_f0,
+                                                         const float2* __restrict__ spec_, const float* __restrict__ coeffs_,
+                                                         float* __restrict__ frames_, const float* __restrict__ ebuf_, const GroupInfo gi) {
+    const float* __restrict__ dmask = SAGEN_GRP(dmask_);              // grouped launch (common.h): group = blockIdx.z
+    const float2* __restrict__ spec = SAGEN_GRP(spec_);
+    const float* __restrict__ coeffs = SAGEN_GRP(coeffs_);
+    float* __restrict__ frames = SAGEN_GRP(frames_);
+    const float* __restrict__ ebuf = SAGEN_GRP(ebuf_);
     __shared__ __attribute__((aligned(16))) float2 fftbuf[2048];      // FFT ping-pong; before that: staging of the mask rows
     float2* const bufA = fftbuf;
     float2* const bufB = fftbuf + 1024;
@@ -273,8 +284,11 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 }
 
 // overlap-add of the 4 covering frames (average, no synthesis window: myutils.py:205) + bias
-__global__ __launch_bounds__(256) void ola_mix_kernel(const float* __restrict__ frames, const float* __restrict__ coeffs,
-                                                      int ntr, float* __restrict__ out, int B) {
+__global__ __launch_bounds__(256) void ola_mix_kernel(const float* __restrict__ frames_, const float* __restrict__ coeffs_,
+                                                      int ntr, float* __restrict__ out_, int B, const GroupInfo gi) {
+    const float* __restrict__ frames = SAGEN_GRP(frames_);
+    const float* __restrict__ coeffs = SAGEN_GRP(coeffs_);
+    float* __restrict__ out = out_ + (size_t)blockIdx.z * ((size_t)B * 4800 * 3);      // the caller's output: the groups back to back
     const long total = (long)B * 4800 * 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int o = (int)(i % 3);
@@ -297,19 +311,20 @@ int mask_istft_mix_launch(const float* dmask, long dmask_bstride, int dmask_f0, 
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     if (dmask_f0 > MASK_F_LO) return fail(SAGEN_ERR_SHAPE, "mask_istft: dmask must start at frame <= %d", MASK_F_LO);
-    dim3 grid(MASK_NF, B);
+    const GroupInfo gi = cur_group();
+    dim3 grid(MASK_NF, B, gi.G);
     if (ntracks == 32)
-        hipLaunchKernelGGL(mask_istft_kernel<32>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf);
+        hipLaunchKernelGGL(mask_istft_kernel<32>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf, gi);
     else if (ntracks == 64)
-        hipLaunchKernelGGL(mask_istft_kernel<64>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf);
+        hipLaunchKernelGGL(mask_istft_kernel<64>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf, gi);
     else if (ntracks == 16)
-        hipLaunchKernelGGL(mask_istft_kernel<16>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf);
+        hipLaunchKernelGGL(mask_istft_kernel<16>, grid, dim3(256), 0, s, dmask, dmask_bstride, dmask_f0, (const float2*)spec, coeffs, scratch, ebuf, gi);
     else
         return fail(SAGEN_ERR_UNSUPPORTED, "mask_istft: num_sep_tracks=%d (supported: 16, 32, 64)", ntracks);
     SAGEN_LAUNCH_CHECK();
     const long total = (long)B * 4800 * 3;
-    hipLaunchKernelGGL(ola_mix_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096L)), dim3(256), 0, s, scratch, coeffs,
-                       ntracks, out, B);
+    hipLaunchKernelGGL(ola_mix_kernel, dim3((int)std::min<long>(cdiv(total, 256), 4096L), 1, gi.G), dim3(256), 0, s, scratch, coeffs,
+                       ntracks, out, B, gi);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -33,8 +33,15 @@ namespace sagen {
 // (row tables, DMA helpers and the epilogue live in igemm_common.h)
 
 template <int BM, int BN, int WM, int WN, int STG, int BK>
-__global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK == 32 ? 2 : 3) : (BK == 32 ? 3 : 4)))) void igemm_kernel(const IgemmDesc d) {
+__global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK == 32 ? 2 : 3) : (BK == 32 ? 3 : 4)))) void igemm_kernel(const IgemmDesc d_in) {
     static_assert(BK == 16 || BK == 32, "K tile of 16 or 32");
+    IgemmDesc d = d_in;
+    int z = blockIdx.z;
+    if (d.grp.G > 1) {                      // grouped launch: blockIdx.z = group * splitk + z (common.h)
+        const int g = d.splitk == 1 ? z : z / d.splitk;
+        z -= g * d.splitk;
+        igemm_relocate(d, g);
+    }
     constexpr int CPR = BK / 4;            // 16-B chunks per LDS row
     constexpr int RPI = 64 / CPR;          // rows covered by one DMA instruction (64 lanes x 16 B)
     constexpr int RPBR = 64 / BK;          // rows per 256-B LDS bank row: the swizzle key is (row / RPBR) % CPR
@@ -73,7 +80,6 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK 
     }
     const int m0 = tile_m * BM;
     const int n0 = blockIdx.y * BN;
-    const int z = blockIdx.z;
     const bool uni = d.uniform_taps != 0;
 
     igemm_setup<BM>(d, m0, tid, uni, s_row, s_tapb, s_bn);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 4096 ? 2 : (WM * WN >= 2048 ? (BK 
 
 template <int BM, int BN, int WM, int WN, int STG, int BK>
 static int launch_cfg(const IgemmDesc& d, hipStream_t s) {
-    dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
+    dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk * d.grp.G);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, STG, BK>), grid, dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
@@ -366,8 +372,17 @@ const char* igemm_tile_name(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kT
 static bool uniform_taps_for(const IgemmDesc& d, int bk) {
     return (d.ntaps > 1 ? (d.Cin % bk == 0) : true) && (d.K % bk == 0);
 }
+// kernels that take the group index of a grouped launch from their grid (common.h): igemm_kernel, igemm3_kernel, conv3h_kernel, conv3g_kernel
+bool igemm_tile_grouped(IgemmTile t) {
+    if (t < 0 || t >= TILE_AUTO) return false;
+    const TileCfg& k = kTiles[t];
+    if (k.s2 || (k.dw3 && !k.p3)) return false;                       // igemm3s2_kernel, igemm3dw_kernel
+    if (k.p3 && !k.h && !k.g) return false;                            // conv3p_kernel / conv3pp_kernel
+    return t != TILE_P3HR_256x64 && t != TILE_P3HR_128x64 && t != TILE_P3HR_64x64_C2;
+}
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     if (t < 0 || t >= TILE_AUTO) return false;
+    if (cur_group().G > 1 && !igemm_tile_grouped(t)) return false;
     const int bk = kTiles[t].bk;
     if (d.Kpad % bk) return false;
     if (kTiles[t].split && !d.w_split) return false;
@@ -478,6 +493,8 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         if (!inside && d.ntaps > 64) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: padded conv with %d taps (max 64)", d.ntaps);
     }
     if (tile == TILE_AUTO) tile = igemm_pick_tile(d);
+    d.grp = cur_group();
+    if (d.grp.G > 1 && !igemm_tile_grouped(tile)) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %s has no grouped launch", igemm_tile_name(tile));
     if (!igemm_tile_ok(d, tile)) return fail(SAGEN_ERR_UNSUPPORTED, "igemm: %s cannot run this problem (Kpad=%d Cin=%d)", igemm_tile_name(tile), d.Kpad, d.Cin);
     // wave-uniform tap per K tile: every K tile lies inside one tap (and there is no ragged K tail)
     d.uniform_taps = uniform_taps_for(d, kTiles[tile].bk) ? 1 : 0;
@@ -519,9 +536,12 @@ int igemm_launch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
 // out[(m*rep + r)*ldy + n] = act(sum_z ws[z][m][n] + bias[n]).  One thread per 4 columns (N % 4 == 0) or per
 // column; fully parallel over M x N.
 template <int V>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N,
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws_, int splitk, int M, int N,
                                                             const float* __restrict__ bias, int relu,
-                                                            float* __restrict__ y, int ldy, int rep, float* __restrict__ amax_out) {
+                                                            float* __restrict__ y_, int ldy, int rep, float* __restrict__ amax_out_, const GroupInfo gi) {
+    const float* __restrict__ ws = SAGEN_GRP(ws_);
+    float* __restrict__ y = SAGEN_GRP(y_);
+    float* __restrict__ amax_out = SAGEN_GRP(amax_out_);
     const int NV = N / V;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     // no early return: the lanes past the end of a partial last wave keep v = 0, skip their loads / stores and meet the others at ONE
@@ -572,9 +592,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // The same for FEW outputs and MANY partials (weight gradients of small layers: 28 KB of gradient from 256 pixel ranges took 27 us
 // with one thread walking all 256 partials of its four columns): eight threads per column group, each summing every eighth partial
 // (four loads in flight), combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void splitk_reduce_sliced_kernel(const float* __restrict__ ws, int splitk, int M, int N,
+__global__ __launch_bounds__(256) void splitk_reduce_sliced_kernel(const float* __restrict__ ws_, int splitk, int M, int N,
                                                                    const float* __restrict__ bias, int relu,
-                                                                   float* __restrict__ y, int ldy, int rep, float* __restrict__ amax_out) {
+                                                                   float* __restrict__ y_, int ldy, int rep, float* __restrict__ amax_out_, const GroupInfo gi) {
+    const float* __restrict__ ws = SAGEN_GRP(ws_);
+    float* __restrict__ y = SAGEN_GRP(y_);
+    float* __restrict__ amax_out = SAGEN_GRP(amax_out_);
     __shared__ float4 red[8][32];
     const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int NV = N / 4;
@@ -613,9 +636,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_sliced_kernel(const float* 
 // Same sum, plus the per-channel (sum, sumsq) of the raw sums over each block of SPLITK_RB rows
 // (training-mode batch-norm statistics of a split-K conv).  Thread t owns 4 columns n = 4*(t % CN4) and rows
 // (t / CN4) + i*(256 / CN4) of its row block; grid (row blocks, column blocks of 4*CN4).
-__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ ws, int splitk, int M, int N,
-                                                                  float* __restrict__ y, int ldy, double* __restrict__ stats,
-                                                                  int CN4, int RB) {
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ ws_, int splitk, int M, int N,
+                                                                  float* __restrict__ y_, int ldy, double* __restrict__ stats_,
+                                                                  int CN4, int RB, const GroupInfo gi) {
+    const float* __restrict__ ws = SAGEN_GRP(ws_);
+    float* __restrict__ y = SAGEN_GRP(y_);
+    double* __restrict__ stats = SAGEN_GRP(stats_);
     __shared__ float4 red[2][256];
     const int tid = threadIdx.x;
     const int cl = tid % CN4, rl = tid / CN4, RL = 256 / CN4;
@@ -663,6 +689,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 
 int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float* bias, int relu,
                          float* y, int ldy, int rep, double* stats, hipStream_t s, float* amax_out) {
+    const GroupInfo gi = cur_group();
     if (stats) {
         if (amax_out) return fail(SAGEN_ERR_UNSUPPORTED, "split-K reduce: statistics and amax_out together");
         if (N % 4 || ldy % 4 || rep != 1 || bias || relu)
@@ -672,18 +699,18 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
         const int ncb = cdiv(N, CN4 * 4);
         int RB = SPLITK_RB;
         while (RB < 128 && (long)cdiv(M, 2 * RB) * ncb >= 512) RB *= 2;
-        dim3 grid(cdiv(M, RB), ncb);
-        hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, s, ws, splitk, M, N, y, ldy, stats, CN4, RB);
+        dim3 grid(cdiv(M, RB), ncb, gi.G);
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, grid, dim3(256), 0, s, ws, splitk, M, N, y, ldy, stats, CN4, RB, gi);
     } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0) && splitk >= 16 &&
                (long)M * (N / 4) <= 65536) {
-        hipLaunchKernelGGL(splitk_reduce_sliced_kernel, dim3(cdiv((long)M * (N / 4), 32)), dim3(256), 0, s, ws, splitk, M, N, bias,
-                           relu, y, ldy, rep, amax_out);
+        hipLaunchKernelGGL(splitk_reduce_sliced_kernel, dim3(cdiv((long)M * (N / 4), 32), 1, gi.G), dim3(256), 0, s, ws, splitk, M, N, bias,
+                           relu, y, ldy, rep, amax_out, gi);
     } else if (N % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0)) {
-        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv((long)M * (N / 4), 256)), dim3(256), 0, s, ws, splitk, M, N, bias,
-                           relu, y, ldy, rep, amax_out);
+        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(cdiv((long)M * (N / 4), 256), 1, gi.G), dim3(256), 0, s, ws, splitk, M, N, bias,
+                           relu, y, ldy, rep, amax_out, gi);
     } else {
-        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv((long)M * N, 256)), dim3(256), 0, s, ws, splitk, M, N, bias, relu,
-                           y, ldy, rep, amax_out);
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(cdiv((long)M * N, 256), 1, gi.G), dim3(256), 0, s, ws, splitk, M, N, bias, relu,
+                           y, ldy, rep, amax_out, gi);
     }
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
@@ -702,7 +729,10 @@ int splitk_reduce_launch(const float* ws, int splitk, int M, int N, const float*
 // and every load is issued before the first add - with run-time loops each thread walked its 5..15 taps one memory round trip at
 // a time (12 us for the 9 MB of deconv5's partials)
 template <int PT, int QT>
-__global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restrict__ ws, int splitk, const DeconvGather g) {
+__global__ __launch_bounds__(256) void deconv_gather_kernel(const float* __restrict__ ws_, int splitk, const DeconvGather g_, const GroupInfo gi) {
+    const float* __restrict__ ws = SAGEN_GRP(ws_);
+    DeconvGather g = g_;
+    g.y = SAGEN_GRP(g.y); g.amax_out = SAGEN_GRP(g.amax_out);
     const int Hout = g.Hin * g.sh + g.kh - g.sh, Wout = g.Win * g.sw + g.kw - g.sw, C4 = g.Cout >> 2;
     const int rows = g.y1 - g.y0;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -761,10 +791,11 @@ int deconv_gather_launch(const float* ws, int splitk, const DeconvGather& g, hip
         return fail(SAGEN_ERR_SHAPE, "deconv_gather: rows [%d, %d) of %d / input band [%d, +%d) of %d", g.y0, g.y1, Hout, g.in_row0, g.R, g.Hin);
     const long total = (long)g.B * (g.y1 - g.y0) * (g.Win * g.sw + g.kw - g.sw) * (g.Cout / 4);
     const int pt = cdiv(g.kh, g.sh), qt = cdiv(g.kw, g.sw);
-    const dim3 grid(cdiv(total, 256));
-    if (pt <= 2 && qt <= 2) hipLaunchKernelGGL((deconv_gather_kernel<2, 2>), grid, dim3(256), 0, s, ws, splitk, g);
-    else if (pt <= 2 && qt <= 3) hipLaunchKernelGGL((deconv_gather_kernel<2, 3>), grid, dim3(256), 0, s, ws, splitk, g);
-    else if (pt <= 3 && qt <= 5) hipLaunchKernelGGL((deconv_gather_kernel<3, 5>), grid, dim3(256), 0, s, ws, splitk, g);
+    const GroupInfo gi = cur_group();
+    const dim3 grid(cdiv(total, 256), 1, gi.G);
+    if (pt <= 2 && qt <= 2) hipLaunchKernelGGL((deconv_gather_kernel<2, 2>), grid, dim3(256), 0, s, ws, splitk, g, gi);
+    else if (pt <= 2 && qt <= 3) hipLaunchKernelGGL((deconv_gather_kernel<2, 3>), grid, dim3(256), 0, s, ws, splitk, g, gi);
+    else if (pt <= 3 && qt <= 5) hipLaunchKernelGGL((deconv_gather_kernel<3, 5>), grid, dim3(256), 0, s, ws, splitk, g, gi);
     else return fail(SAGEN_ERR_UNSUPPORTED, "deconv_gather: %d x %d taps per output pixel", pt, qt);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;

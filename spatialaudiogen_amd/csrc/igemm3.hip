@@ -36,7 +36,7 @@ namespace sagen {
 // KS = K tiles of 16 per barrier step (small tiles amortise the barrier and the loop overhead over 2 tiles);
 // PRO = the producer's batch-norm + ReLU is applied to the activations on the way in.
 template <int BM, int BN, int WM, int WN, int KS, bool PRO>
-__device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
+__device__ __forceinline__ void igemm3_body(const IgemmDesc& d, const int z) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN, WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
@@ -68,7 +68,6 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
     }
     const int m0 = tile_m * BM;
     const int n0 = blockIdx.y * BN;
-    const int z = blockIdx.z;
     const bool uni = d.uniform_taps != 0;
 
     igemm_setup<BM>(d, m0, tid, uni, s_row, s_tapb, s_bn);
@@ -337,13 +336,20 @@ __device__ __forceinline__ void igemm3_body(const IgemmDesc& d) {
 }
 
 template <int BM, int BN, int WM, int WN, int KS, bool PRO>
-__global__ __launch_bounds__(256, 2) void igemm3_kernel(const IgemmDesc d) {
-    igemm3_body<BM, BN, WM, WN, KS, PRO>(d);
+__global__ __launch_bounds__(256, 2) void igemm3_kernel(const IgemmDesc d_in) {
+    IgemmDesc d = d_in;
+    int z = blockIdx.z;
+    if (d.grp.G > 1) {                      // grouped launch: blockIdx.z = group * splitk + z (common.h)
+        const int g = d.splitk == 1 ? z : z / d.splitk;
+        z -= g * d.splitk;
+        igemm_relocate(d, g);
+    }
+    igemm3_body<BM, BN, WM, WN, KS, PRO>(d, z);
 }
 
 template <int BM, int BN, int WM, int WN, int KS>
 static int launch_cfg3(const IgemmDesc& d, hipStream_t s) {
-    dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
+    dim3 grid(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk * d.grp.G);
     if (d.in_scale != nullptr || d.bn_in.acc != nullptr)
         hipLaunchKernelGGL((igemm3_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(256), 0, s, d);
     else

@@ -93,7 +93,23 @@ struct IgemmDesc {
     // debug builds (-DSAGEN_TRACE): phase timeline of workgroup `trace_block`
     void* trace = nullptr;
     int trace_block = 0;
+    // grouped launch (common.h: GroupInfo): filled by igemm_launch from cur_group(); the kernels relocate their per-group pointers
+    GroupInfo grp;
 };
+// every pointer of the descriptor that may live in the per-group region of the workspace, moved to group g's copy (filters, the
+// caller's variables and null pointers lie outside the region and stay)
+__device__ __forceinline__ void igemm_relocate(IgemmDesc& d, int g) {
+    const GroupInfo gi = d.grp;
+    d.x = grp_ptr(d.x, gi, g); d.y = grp_ptr(d.y, gi, g);
+    d.in_scale = grp_ptr(d.in_scale, gi, g); d.in_shift = grp_ptr(d.in_shift, gi, g);
+    d.bn_in.acc = grp_ptr(d.bn_in.acc, gi, g);
+    d.stats = grp_ptr(d.stats, gi, g); d.amax_out = grp_ptr(d.amax_out, gi, g);
+    d.splitk_ws = grp_ptr(d.splitk_ws, gi, g); d.sk_ticket = grp_ptr(d.sk_ticket, gi, g);
+    d.xp3 = grp_ptr(d.xp3, gi, g);
+    d.h2_a_inv = grp_ptr(d.h2_a_inv, gi, g); d.h2_w_inv = grp_ptr(d.h2_w_inv, gi, g);
+    d.mm_coeffs = grp_ptr(d.mm_coeffs, gi, g); d.mm_out = grp_ptr(d.mm_out, gi, g);
+}
+// grid.z of an IgemmDesc launch: groups x split-K for igemm_kernel / igemm3_kernel (blockIdx.z = g * splitk + z), groups for the others
 
 // tile configurations (BM x BN, 4 waves)
 // The first six are the shape-heuristic set; the rest exist for the autotuner (2-stage LDS ring = less LDS,
@@ -161,6 +177,7 @@ bool conv3g_ok(const IgemmDesc& d);                   // geometry conv3g_kernel 
 constexpr int SK_TICKETS = 8192;                      // tiles an in-launch split-K combine can track (IgemmDesc::sk_ticket)
 inline bool igemm_tile_fused_splitk(IgemmTile) { return true; }     // every kernel that writes split-K partials does it through igemm_epilogue
 bool igemm_tile_p3(IgemmTile t);                      // conv3p_kernel tile (pre-split activation planes, no split-K)?
+bool igemm_tile_grouped(IgemmTile t);                 // does the tile's kernel support the grouped launch (common.h: GroupInfo)?
 bool igemm_tile_dh_split(IgemmTile t);                // ... except conv3h_kernel's dh-split: split-K = 3 exactly, one filter row per workgroup
 bool igemm_p3_eligible(const IgemmDesc& d);           // dense 3x3 stride-1 SAME conv that conv3p_kernel can run (given planes)
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t);   // can this instantiation run the problem?              // instantiation name as rocprofv3 prints it

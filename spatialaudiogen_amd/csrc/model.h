@@ -87,6 +87,21 @@ struct sagen_ctx {
     std::vector<const float*> var_ptr;
     bool bound = false;
 
+    // grouped launch (common.h: GroupInfo; sagen_create_grouped): G independent batches per forward.  The workspace is
+    // [shared: packed filters, job tables][per-batch region of group 0][... of group 1] ...: `grp_off` floats of shared buffers, then
+    // G copies of `grp_floats` floats; bufs / p() describe group 0, group g's copy of a per-batch buffer lies g * grp_floats further on
+    int G = 1;
+    size_t grp_off = 0, grp_floats = 0;
+    GroupInfo group_info() const {
+        GroupInfo gi;
+        if (G > 1 && ws) {
+            gi.lo = reinterpret_cast<const char*>(ws + grp_off);
+            gi.span = (unsigned long long)grp_floats * sizeof(float);
+            gi.stride = gi.span;
+            gi.G = G;
+        }
+        return gi;
+    }
     // workspace
     size_t ws_floats = 0;
     float* ws = nullptr;
@@ -278,6 +293,14 @@ struct Fwd {
                (d.M <= d.Hg * d.Wg || d.y_bstride == (long)d.Hg * d.Wg * d.ldy);
     }
     size_t ws_capacity() const { return c->bufs.at(wsname).n; }
+    // clear a per-batch buffer in EVERY group's copy (grouped contexts; one fill per group)
+    hipError_t memset_groups(void* p, size_t bytes) {
+        for (int g = 0; g < c->G; ++g) {
+            const hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(p) + (size_t)g * c->grp_floats * sizeof(float), 0, bytes, s);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
 
     // launches the contraction with an explicit choice; returns the number of BN partial rows written (0 if none)
     int run_choice(const IgemmDesc& d, int rep, IgemmTile tile, int sk) {
@@ -412,7 +435,7 @@ struct Fwd {
             ch = tune(d, rep, allow_split);
             c->profiling = was_prof;
             c->plan[layer] = ch;
-            if (d.stats && !rc && hipMemsetAsync(d.stats, 0, (size_t)2 * d.N * sizeof(double), s) != hipSuccess)
+            if (d.stats && !rc && memset_groups(d.stats, (size_t)2 * d.N * sizeof(double)) != hipSuccess)
                 rc = fail(SAGEN_ERR_HIP, "autotune: memset failed");         // candidates polluted the accumulators
         } else if (it != c->plan.end()) {
             ch = it->second;
@@ -608,11 +631,13 @@ struct Fwd {
         const int B = c->B;
         int li = 0;
         // uint8 frames: the centred bf16 plane u - 128 IS the exact operand (x = (u' + 0.5) / 255): one plane, three products (stem8.hip)
-        const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !c->tuning && !c->fp32_only && !c->train_mode;
+        // (a grouped context has no other stem: its autotune pass runs the fused kernels too - they take no tile from the plan)
+        const bool tune_general = c->tuning && c->G == 1;
+        const bool fast8 = c->video_u8 && scope == "video_encoder" && c->stem8 && !tune_general && !c->fp32_only && !c->train_mode;
         // ... with the filter as two fp16 planes where they exist: two products per multiply instead of three (stem8.hip, MODE 2)
         const bool fast8h = fast8 && c->stem8h && h2() && c->h2_slot.count(scope + "/conv1/conv") != 0;
         // float frames (the flow encoder; video handed over as float32): the same kernel on two fp16 planes of the frame (stem8.hip, F16)
-        const bool fast16 = !fast8 && !(c->video_u8 && scope == "video_encoder") && c->stem16 && !c->tuning && !c->fp32_only && !c->train_mode && h2() &&
+        const bool fast16 = !fast8 && !(c->video_u8 && scope == "video_encoder") && c->stem16 && !tune_general && !c->fp32_only && !c->train_mode && h2() &&
                             c->use_p3 && c->p3_from_stage <= 2 && c->bufs.count("s16:part" + sfx) != 0 && c->h2_slot.count(scope + "/conv1/conv") != 0;
         // the batch-norm accumulators start at zero: cleared by the trunk's first kernel where that is stem8_prep / stem16_amax, else by a fill
         if (!fast8 && !fast16 && !rc && hipMemsetAsync(c->p("bnacc" + sfx), 0, c->bufs.at("bnacc" + sfx).n * sizeof(float), s) != hipSuccess)

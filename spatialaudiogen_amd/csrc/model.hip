@@ -6,8 +6,13 @@
 // ------------------------------------------------------------------------------------------------
 // create / destroy
 // ------------------------------------------------------------------------------------------------
-int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
+void sagen_destroy_impl(sagen_ctx* c);
+int sagen_groups_impl(const sagen_ctx* c) { return c->G; }
+int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups) {
     if (!out || !cfg) return fail(SAGEN_ERR_NULL, "sagen_create: null argument");
+    if (groups < 1 || groups > 16) return fail(SAGEN_ERR_SHAPE, "sagen_create_grouped: groups=%d (1..16)", groups);
+    if (groups > 1 && cfg->separation != SAGEN_SEP_FREQ_MASK)
+        return fail(SAGEN_ERR_UNSUPPORTED, "sagen_create_grouped: the grouped launch covers the FREQ_MASK path only");
     if (cfg->batch <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_create: batch=%d", cfg->batch);
     if (!(cfg->encoders & SAGEN_ENC_AUDIO))
         return fail(SAGEN_ERR_UNSUPPORTED, "the audio encoder is mandatory (reference model.py:207)");
@@ -29,6 +34,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         if (cfg->loc_units[i] <= 0 || cfg->loc_units[i] % 4) return fail(SAGEN_ERR_UNSUPPORTED, "loc_units[%d]=%d must be a positive multiple of 4", i, cfg->loc_units[i]);
 
     sagen_ctx* c = new sagen_ctx();
+    c->G = groups;
 
     c->fp32_only = getenv("SAGEN_FP32_ONLY") != nullptr;
     c->use_p3 = !c->fp32_only && getenv("SAGEN_NO_P3") == nullptr;
@@ -172,8 +178,10 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
     }
     c->alloc("h2:jobs", (c->h2_slot.size() + 1) * sizeof(H2Job) / sizeof(float) + 64);
     c->alloc("h2:amax", c->h2_slot.size() + h2_pack_blocks + 64);      // per-job maxima + per-workgroup partials
-    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [7] saturation counter, [8..] 2^-kw per layer, [2 + H2_RIG_OFF ..] the rigorous bounds behind [2..5] (p3.hip)
     c->alloc("pk:jobs", (c->vars.size() + 1) * sizeof(PackJob) / sizeof(float) + 64);      // device copy of the pack-job table
+    // ---- everything from here on is PER BATCH: a grouped context (sagen_create_grouped) holds this region once per group ----
+    c->grp_off = c->ws_floats;
+    c->alloc("h2s", 256);                  // fp16x2 scales: [0], [1] = 2^-ka of the planes in the video / flow trunk's plane buffer, [2..5] block-input bounds, [6] scratch, [7] saturation counter, [8..] 2^-kw per layer, [2 + H2_RIG_OFF ..] the rigorous bounds behind [2..5] (p3.hip)
     // activations
     c->alloc("mag", (size_t)B * 127 * 1024);
     c->alloc("spec", (size_t)B * 28 * 513 * 2);
@@ -268,6 +276,12 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg) {
         (void)hipGetLastError();
         c->aux = nullptr;      // no device / no stream: forward falls back to a single stream (and fails at launch)
     }
+    c->grp_floats = c->ws_floats - c->grp_off;          // (a multiple of 64 floats: every buffer is rounded up to 256 bytes)
+    c->ws_floats = c->grp_off + (size_t)c->G * c->grp_floats;
+    if (c->G > 1 && (c->use_fcm || c->sk_fused || c->fp32_only || !c->use_h2 || !c->use_p3 || !c->use_p3g || c->p3_from_stage > 2 || c->no_lean_trunk)) {
+        sagen_destroy_impl(c);
+        return fail(SAGEN_ERR_UNSUPPORTED, "sagen_create_grouped: the grouped launch runs the default kernels only (an environment switch selected others)");
+    }
     *out = c;
     return SAGEN_OK;
 }
@@ -303,13 +317,20 @@ int sagen_bind_impl(sagen_ctx* c, const sagen_tensor* tensors, int n, void* work
     c->var_ptr = ptr;
     c->pack_jobs.clear();                 // (the table holds the variables' addresses)
     c->h2_jobs.clear();
-    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("h2s"), 0, 256 * sizeof(float), s));       // fp16x2 scales, bounds, saturation counter
-    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("splitk:tk"), 0, SK_TICKETS * sizeof(int), s));
-    SAGEN_HIP_CHECK(hipMemsetAsync(c->p("splitk_aux:tk"), 0, SK_TICKETS * sizeof(int), s));
+    for (int g = 0; g < c->G; ++g) {
+        const size_t go = (size_t)g * c->grp_floats;
+        SAGEN_HIP_CHECK(hipMemsetAsync(c->p("h2s") + go, 0, 256 * sizeof(float), s));       // fp16x2 scales, bounds, saturation counter
+        SAGEN_HIP_CHECK(hipMemsetAsync(c->p("splitk:tk") + go, 0, SK_TICKETS * sizeof(int), s));
+        SAGEN_HIP_CHECK(hipMemsetAsync(c->p("splitk_aux:tk") + go, 0, SK_TICKETS * sizeof(int), s));
+    }
     int rc = fft_tables_ensure(s);
     if (rc) return rc;
     rc = sagen_repack_impl(c, s);
     if (rc) return rc;
+    // the filters' 2^-kw (written by the fp16x2 pack into group 0's scale table) are the same for every group
+    for (int g = 1; g < c->G; ++g)
+        SAGEN_HIP_CHECK(hipMemcpyAsync(c->p("h2s") + (size_t)g * c->grp_floats + H2S_FILTER_FIRST, c->p("h2s") + H2S_FILTER_FIRST,
+                                       (H2S_FIXED_FIRST - H2S_FILTER_FIRST) * sizeof(float), hipMemcpyDeviceToDevice, s));
     c->bound = true;
     return SAGEN_OK;
 }
@@ -446,6 +467,19 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     const int B = c->B;
     c->events_used = 0;
     c->prof.clear();
+    // grouped context: every launch of this call carries the group dimension (common.h); the launchers read it from cur_group()
+    struct GroupScope {
+        GroupInfo saved;
+        explicit GroupScope(const GroupInfo& gi) : saved(cur_group()) { cur_group() = gi; }
+        ~GroupScope() { cur_group() = saved; }
+    } group_scope(c->group_info());
+    if (c->G > 1) {
+        if (c->train_mode) return fail(SAGEN_ERR_UNSUPPORTED, "the training step has no grouped launch");
+        if (!c->freq_mask || c->fp32_only || !c->use_h2 || !c->use_p3 || !c->use_p3g || c->p3_from_stage > 2 || c->no_lean_trunk || c->use_fcm || c->sk_fused ||
+            (c->has_video && !c->video_u8 && !c->stem16) || (c->has_video && c->video_u8 && !c->stem8) || (c->has_flow && !c->stem16))
+            return fail(SAGEN_ERR_UNSUPPORTED, "grouped forward: an option moved the path off the kernels that take a group dimension "
+                        "(fp16x2 / planes_from_stage / plane_gather / u8_fast_stem / f16_fast_stem must keep their defaults)");
+    }
 
     // Two launch streams: `f` (the caller's) carries the video trunk and everything after the bottleneck; `g`
     // (context-owned) carries the independent audio chain and, with three encoders, the flow trunk.  They fork at
@@ -829,7 +863,7 @@ int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen) {
     memcpy(buf, out.c_str(), out.size() + 1);
     return (int)c->prof.size();
 }
-size_t sagen_workspace_bytes_impl(const sagen_ctx* c) { return c->ws_floats * sizeof(float); }
+size_t sagen_workspace_bytes_impl(const sagen_ctx* c) { return c->ws_floats * sizeof(float); }      // (all groups' copies included)
 int sagen_num_variables_impl(const sagen_ctx* c) { return (int)c->vars.size(); }
 int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32_t* ndim, int64_t shape[4]) {
     if (i < 0 || i >= (int)c->vars.size()) return fail(SAGEN_ERR_SHAPE, "variable index %d out of range", i);
@@ -856,10 +890,13 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
 int sagen_counter_impl(sagen_ctx* c, const char* name, uint64_t* value, hipStream_t s) {
     if (!c->ws) return fail(SAGEN_ERR_WORKSPACE, "no workspace bound");
     if (std::string(name) != "fp16x2_saturations") return fail(SAGEN_ERR_UNSUPPORTED, "sagen_counter: unknown counter %s", name);
-    unsigned v = 0;
-    SAGEN_HIP_CHECK(hipMemcpyAsync(&v, c->p("h2s") + 7, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    unsigned v[16] = {0};                    // one counter per group
+    for (int g = 0; g < c->G; ++g)
+        SAGEN_HIP_CHECK(hipMemcpyAsync(&v[g], c->p("h2s") + (size_t)g * c->grp_floats + 7, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     SAGEN_HIP_CHECK(hipStreamSynchronize(s));
-    *value = v;
+    uint64_t tot = 0;
+    for (int g = 0; g < c->G; ++g) tot += v[g];
+    *value = tot;
     return SAGEN_OK;
 }
 

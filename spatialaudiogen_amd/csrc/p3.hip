@@ -148,10 +148,23 @@ __device__ __forceinline__ float p3_tables(const float* scale, const float* shif
 }
 
 template <bool H2>
-__global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, const BnRef bn,
-                                                      const float* __restrict__ res, int relu, float* __restrict__ y,
-                                                      char* p3, long nrows, int W, int C, const P3hScale h2) {       // (p3 may alias h2.res_planes)
+__global__ __launch_bounds__(256) void p3_pack_kernel(const float* __restrict__ x_, const float* __restrict__ scale_,
+                                                      const float* __restrict__ shift_, const BnRef bn_,
+                                                      const float* __restrict__ res_, int relu, float* __restrict__ y_,
+                                                      char* p3_, long nrows, int W, int C, const P3hScale h2_, const GroupInfo gi) {       // (p3 may alias h2.res_planes)
+    // grouped launch (common.h): this workgroup's group = blockIdx.z, its tensors / accumulators / scales in that group's region
+    const float* __restrict__ x = SAGEN_GRP(x_);
+    const float* __restrict__ scale = SAGEN_GRP(scale_);
+    const float* __restrict__ shift = SAGEN_GRP(shift_);
+    const float* __restrict__ res = SAGEN_GRP(res_);
+    float* __restrict__ y = SAGEN_GRP(y_);
+    char* p3 = SAGEN_GRP(p3_);
+    BnRef bn = bn_;
+    bn.acc = SAGEN_GRP(bn.acc);
+    P3hScale h2 = h2_;
+    h2.a_inv = SAGEN_GRP(h2.a_inv); h2.res_bound = SAGEN_GRP(h2.res_bound); h2.res_acc = SAGEN_GRP(h2.res_acc);
+    h2.bound_out = SAGEN_GRP(h2.bound_out); h2.sat_count = SAGEN_GRP(h2.sat_count); h2.relu_bits = SAGEN_GRP(h2.relu_bits);
+    h2.res_planes = SAGEN_GRP(h2.res_planes); h2.res_a_inv = SAGEN_GRP(h2.res_a_inv);
     const int C8 = C >> 3;
     const long total = nrows * (W + 1) * C8;             // padded pixels x channel octets (the grid stride is a multiple of C8)
     const long cstride = nrows * (W + 1) * (H2 ? 64 : 96);
@@ -239,21 +252,28 @@ int p3_pack_launch(const float* x, const float* scale, const float* shift, const
     // (measured with three batches in flight, same box, tools/ab_p3_amort.sh: 1 / 2 / 4 items per thread = 2 508-2 524 / 2 519-2 529 / 2 536-2 544
     //  ambisonic-s/s - the pass alone is no faster with fewer workgroups, but it leaves the CUs to the other batches' matrix kernels sooner)
     const int amort = amort_env > 0 ? amort_env : 4;
+    const GroupInfo gi = cur_group();
     if (fmt == 1)
-        hipLaunchKernelGGL(p3_pack_kernel<true>, dim3(aligned_grid(total, C / 8, amort)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
-                           (char*)p3, nrows, W, C, *h2);
+        hipLaunchKernelGGL(p3_pack_kernel<true>, dim3(aligned_grid(total, C / 8, amort), 1, gi.G), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+                           (char*)p3, nrows, W, C, *h2, gi);
     else
-        hipLaunchKernelGGL(p3_pack_kernel<false>, dim3(aligned_grid(total, C / 8, amort)), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
-                           (char*)p3, nrows, W, C, P3hScale());
+        hipLaunchKernelGGL(p3_pack_kernel<false>, dim3(aligned_grid(total, C / 8, amort), 1, gi.G), dim3(256), 0, s, x, scale, shift, bn, residual, relu, y,
+                           (char*)p3, nrows, W, C, P3hScale(), gi);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
 
 // ---- a band of rows of a plain fp32 tensor as fp16x2 planes, scaled by its producers' EXACT maximum (the decoder's concat buffers:
 //      no batch-norm bounds them, so the contractions that wrote the two halves publish max |y| from their epilogues) ----
-__global__ __launch_bounds__(256) void h2_pack_rows_kernel(const float* __restrict__ x, long x_bstride, long x_rstride, int ldx, int row0, int B, int R,
-                                                           int W, int C, const float* __restrict__ amax0, const float* __restrict__ amax1,
-                                                           char* __restrict__ planes, float* __restrict__ a_inv, unsigned* __restrict__ sat_count) {
+__global__ __launch_bounds__(256) void h2_pack_rows_kernel(const float* __restrict__ x_, long x_bstride, long x_rstride, int ldx, int row0, int B, int R,
+                                                           int W, int C, const float* __restrict__ amax0_, const float* __restrict__ amax1_,
+                                                           char* __restrict__ planes_, float* __restrict__ a_inv_, unsigned* __restrict__ sat_count_, const GroupInfo gi) {
+    const float* __restrict__ x = SAGEN_GRP(x_);
+    const float* __restrict__ amax0 = SAGEN_GRP(amax0_);
+    const float* __restrict__ amax1 = SAGEN_GRP(amax1_);
+    char* __restrict__ planes = SAGEN_GRP(planes_);
+    float* __restrict__ a_inv = SAGEN_GRP(a_inv_);
+    unsigned* __restrict__ sat_count = SAGEN_GRP(sat_count_);
     const int C8 = C >> 3;
     const long NP = (long)B * R * (W + 1);
     const long total = NP * C8;
@@ -288,8 +308,9 @@ int h2_pack_rows_launch(const float* x, long x_bstride, long x_rstride, int ldx,
     if (!x || !amax0 || !planes || !a_inv) return fail(SAGEN_ERR_NULL, "h2_pack_rows: null argument");
     if (C % 16 || ldx % 4 || ((uintptr_t)x % 16)) return fail(SAGEN_ERR_UNSUPPORTED, "h2_pack_rows: C %% 16, ldx %% 4 and a 16-byte aligned tensor are required");
     const long total = (long)B * R * (W + 1) * (C / 8);
-    hipLaunchKernelGGL(h2_pack_rows_kernel, dim3((int)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, s, x, x_bstride, x_rstride, ldx, row0,
-                       B, R, W, C, amax0, amax1, (char*)planes, a_inv, sat_count);
+    const GroupInfo gi = cur_group();
+    hipLaunchKernelGGL(h2_pack_rows_kernel, dim3((int)std::min<long>(cdiv(total, 256), 2048), 1, gi.G), dim3(256), 0, s, x, x_bstride, x_rstride, ldx, row0,
+                       B, R, W, C, amax0, amax1, (char*)planes, a_inv, sat_count, gi);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -370,6 +391,7 @@ int p3_maxpool_launch(const float* x, const float* scale, const float* shift, co
     const int pth = std::max((Ho - 1) * 2 + 3 - H, 0), ptw = std::max((Wo - 1) * 2 + 3 - W, 0);
     const long total = (long)B * Ho * (Wo + 1) * (C / 8);
     if (fmt == 1 && p3 && !(h2 && h2->a_inv)) return fail(SAGEN_ERR_NULL, "p3_maxpool: the fp16x2 format needs a slot for its scale");
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "p3_maxpool: no grouped launch (the grouped forward runs the fused stem kernels)");
     if (fmt == 1)
         hipLaunchKernelGGL(p3_maxpool_kernel<true>, dim3(aligned_grid(total, C / 8)), dim3(256), 0, s, x, scale, shift, bn, y, (char*)p3, B, H,
                            W, C, Ho, Wo, pth / 2, ptw / 2, *h2);

@@ -46,8 +46,12 @@ size_t stem8_plane_bytes(int B) { return (size_t)B * S8_UH * S8_UW * 8; }
 
 // uint8 frames [B,224,448,3] -> the centred plane [B,229,456,4] bf16: u - 128 inside, -0.5 (= x 0) in the border, 0 in channel 3
 template <bool HALF>      // HALF: the plane is fp16 (stem8pool_kernel MODE 2) instead of bf16 - the values are exact in both
-__global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __restrict__ x, u32x2* __restrict__ plane, int B,
-                                                         float* __restrict__ zero_ptr, long zero_n) {
+__global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __restrict__ x_, u32x2* __restrict__ plane_, int B,
+                                                         float* __restrict__ zero_ptr_, long zero_n, const GroupInfo gi) {
+    // grouped launch (common.h): the caller's frames hold the groups back to back; the plane and the accumulators are per group
+    const unsigned char* __restrict__ x = x_ + (size_t)blockIdx.z * ((size_t)B * 224 * 448 * 3);
+    u32x2* __restrict__ plane = SAGEN_GRP(plane_);
+    float* __restrict__ zero_ptr = SAGEN_GRP(zero_ptr_);
     const long total = (long)B * S8_UH * S8_UW;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero_ptr[i] = 0.f;     // (instead of a fill launch)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -85,11 +89,17 @@ __global__ __launch_bounds__(256) void stem8_prep_kernel(const unsigned char* __
 // OUT 0: pooled raw output; 1: the raw output itself (into `pooled`); 2: both - raw into `raw2`, pooled raw into `pooled` (the training
 // step: the backward keeps the raw tensor, and the pool no longer re-reads its 205 MB in a pass of its own)
 template <int OUT, int MODE = 0>
-__global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane, const float* __restrict__ wf32,
+__global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __restrict__ plane_, const float* __restrict__ wf32,
                                                                   const char* __restrict__ wplanes, const float* __restrict__ gamma,
-                                                                  float* __restrict__ pooled, double* __restrict__ stats, int B,
-                                                                  long plane_stride, const float* __restrict__ a_inv, const float* __restrict__ w_inv,
-                                                                  float* __restrict__ raw2) {
+                                                                  float* __restrict__ pooled_, double* __restrict__ stats_, int B,
+                                                                  long plane_stride, const float* __restrict__ a_inv_, const float* __restrict__ w_inv_,
+                                                                  float* __restrict__ raw2_, const GroupInfo gi) {
+    const char* __restrict__ plane = SAGEN_GRP(plane_);               // grouped launch (common.h): group = blockIdx.z
+    float* __restrict__ pooled = SAGEN_GRP(pooled_);
+    double* __restrict__ stats = SAGEN_GRP(stats_);
+    const float* __restrict__ a_inv = SAGEN_GRP(a_inv_);
+    const float* __restrict__ w_inv = SAGEN_GRP(w_inv_);
+    float* __restrict__ raw2 = SAGEN_GRP(raw2_);
     constexpr bool F16 = MODE != 0;
     constexpr int NPLA = MODE == 1 ? 2 : 1, NPLW = MODE == 0 ? 3 : 2;             // operand planes: activation, filter
     constexpr int W_BYTES = 14 * NPLW * S8_NH * 32;
@@ -284,8 +294,9 @@ int stem8_prep_launch(const unsigned char* x, void* plane, int B, hipStream_t s,
     if (!x || !plane) return fail(SAGEN_ERR_NULL, "stem8_prep: null argument");
     const long total = (long)B * S8_UH * S8_UW;
     const int grid = (int)std::min<long>(cdiv(total, 256), 256L * 16);
-    if (half) hipLaunchKernelGGL(stem8_prep_kernel<true>, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L);
-    else hipLaunchKernelGGL(stem8_prep_kernel<false>, dim3(grid), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L);
+    const GroupInfo gi = cur_group();
+    if (half) hipLaunchKernelGGL(stem8_prep_kernel<true>, dim3(grid, 1, gi.G), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L, gi);
+    else hipLaunchKernelGGL(stem8_prep_kernel<false>, dim3(grid, 1, gi.G), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(plane), B, zero_ptr, zero_ptr ? zero_n : 0L, gi);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -301,8 +312,8 @@ int stem8pool_launch(const void* plane, const float* wp, const float* gamma, flo
     }
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel<0>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
-                       pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(stem8pool_kernel<0>, dim3(2 * std::min(npatch, 256), 1, cur_group().G), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes, gamma,
+                       pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, cur_group());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -317,8 +328,8 @@ int stem8pool_h2_launch(const void* plane, const float* wp, const void* wh2, con
         attr_set = true;
     }
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL((stem8pool_kernel<0, 2>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp,
-                       reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, 0L, (const float*)nullptr, w_inv, (float*)nullptr);
+    hipLaunchKernelGGL((stem8pool_kernel<0, 2>), dim3(2 * std::min(npatch, 256), 1, cur_group().G), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp,
+                       reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, 0L, (const float*)nullptr, w_inv, (float*)nullptr, cur_group());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -333,8 +344,8 @@ int stem8raw_launch(const void* plane, const float* wp, float* y0, double* stats
     }
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel<1>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
-                       (const float*)nullptr, y0, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(stem8pool_kernel<1>, dim3(2 * std::min(npatch, 256), 1, cur_group().G), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
+                       (const float*)nullptr, y0, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, cur_group());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -349,15 +360,18 @@ int stem8rawpool_launch(const void* plane, const float* wp, const float* gamma, 
     }
     const char* planes = reinterpret_cast<const char*>(wp + 64 * 224);
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL(stem8pool_kernel<2>, dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
-                       gamma, pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, y0);
+    hipLaunchKernelGGL(stem8pool_kernel<2>, dim3(2 * std::min(npatch, 256), 1, cur_group().G), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(plane), wp, planes,
+                       gamma, pooled, stats, B, 0L, (const float*)nullptr, (const float*)nullptr, y0, cur_group());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
 
 // ---- float frames (F16 variant): the batch's exact maximum, then the two fp16 planes ----
 constexpr int S16_PARTS = 1024;                   // per-workgroup partial maxima (no atomics, nothing to clear)
-__global__ __launch_bounds__(256) void stem16_amax_kernel(const float* __restrict__ x, long n4, float* __restrict__ part, float* __restrict__ zero_ptr, long zero_n) {
+__global__ __launch_bounds__(256) void stem16_amax_kernel(const float* __restrict__ x_, long n4, float* __restrict__ part_, float* __restrict__ zero_ptr_, long zero_n, const GroupInfo gi) {
+    const float* __restrict__ x = x_ + (size_t)blockIdx.z * (size_t)n4 * 4;        // grouped launch: the caller's frames hold the groups back to back
+    float* __restrict__ part = SAGEN_GRP(part_);
+    float* __restrict__ zero_ptr = SAGEN_GRP(zero_ptr_);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero_ptr[i] = 0.f;     // (the trunk's batch-norm accumulators)
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -372,8 +386,13 @@ __global__ __launch_bounds__(256) void stem16_amax_kernel(const float* __restric
 }
 // float frames [B,224,448,3] -> planes hi / lo [B,229,456,4] fp16 of x * 2^ka (max |x| * 2^ka in [512, 1024): exact bound), zero border,
 // zero channel 3; 2^-ka -> a_inv[0]
-__global__ __launch_bounds__(256) void stem16_prep_kernel(const float* __restrict__ x, u32x2* __restrict__ hi, u32x2* __restrict__ lo, int B,
-                                                          const float* __restrict__ part, float* __restrict__ a_inv) {
+__global__ __launch_bounds__(256) void stem16_prep_kernel(const float* __restrict__ x_, u32x2* __restrict__ hi_, u32x2* __restrict__ lo_, int B,
+                                                          const float* __restrict__ part_, float* __restrict__ a_inv_, const GroupInfo gi) {
+    const float* __restrict__ x = x_ + (size_t)blockIdx.z * ((size_t)B * 224 * 448 * 3);
+    u32x2* __restrict__ hi = SAGEN_GRP(hi_);
+    u32x2* __restrict__ lo = SAGEN_GRP(lo_);
+    const float* __restrict__ part = SAGEN_GRP(part_);
+    float* __restrict__ a_inv = SAGEN_GRP(a_inv_);
     float m = 0.f;
     for (int i = threadIdx.x & 63; i < S16_PARTS; i += 64) m = fmaxf(m, part[i]);
     m = wave_max_f(m);
@@ -407,11 +426,12 @@ int stem16_prep_launch(const float* x, void* planes, float* part, float* a_inv, 
     if (!x || !planes || !part || !a_inv) return fail(SAGEN_ERR_NULL, "stem16_prep: null argument");
     const long n = (long)B * 224 * 448 * 3;
     if (n % 4 || ((uintptr_t)x % 16)) return fail(SAGEN_ERR_UNSUPPORTED, "stem16_prep: the frames must be 16-byte aligned");
-    hipLaunchKernelGGL(stem16_amax_kernel, dim3(S16_PARTS), dim3(256), 0, s, x, n / 4, part, zero_ptr, zero_ptr ? zero_n : 0L);
+    const GroupInfo gi = cur_group();
+    hipLaunchKernelGGL(stem16_amax_kernel, dim3(S16_PARTS, 1, gi.G), dim3(256), 0, s, x, n / 4, part, zero_ptr, zero_ptr ? zero_n : 0L, gi);
     const long total = (long)B * S8_UH * S8_UW;
     char* p = reinterpret_cast<char*>(planes);
-    hipLaunchKernelGGL(stem16_prep_kernel, dim3((int)std::min<long>(cdiv(total, 256), 256L * 16)), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(p),
-                       reinterpret_cast<u32x2*>(p + stem8_plane_bytes(B)), B, part, a_inv);
+    hipLaunchKernelGGL(stem16_prep_kernel, dim3((int)std::min<long>(cdiv(total, 256), 256L * 16), 1, gi.G), dim3(256), 0, s, x, reinterpret_cast<u32x2*>(p),
+                       reinterpret_cast<u32x2*>(p + stem8_plane_bytes(B)), B, part, a_inv, gi);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }
@@ -426,8 +446,8 @@ int stem16pool_launch(const void* planes, const void* wh2, const float* gamma, f
         attr_set = true;
     }
     const int npatch = B * 7 * 16;
-    hipLaunchKernelGGL((stem8pool_kernel<0, 1>), dim3(2 * std::min(npatch, 256)), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
-                       (const float*)nullptr, reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, (long)stem8_plane_bytes(B), a_inv, w_inv, (float*)nullptr);
+    hipLaunchKernelGGL((stem8pool_kernel<0, 1>), dim3(2 * std::min(npatch, 256), 1, cur_group().G), dim3(S8_THREADS), S8_LDS, s, reinterpret_cast<const char*>(planes),
+                       (const float*)nullptr, reinterpret_cast<const char*>(wh2), gamma, pooled, stats, B, (long)stem8_plane_bytes(B), a_inv, w_inv, (float*)nullptr, cur_group());
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;
 }

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stempool_kernel(const float* __
 
 // xpad: zero-bordered [B,229,454,4]; wp: the stem's packed filter (fp32 [64][224] followed by its bf16x3 planes); pooled [B,56,112,64]
 int stempool_launch(const float* xpad, const float* wp, const float* gamma, float* pooled, double* stats, int B, hipStream_t s) {
+    if (cur_group().G > 1) return fail(SAGEN_ERR_UNSUPPORTED, "%s: no grouped launch (common.h: GroupInfo)", __func__);
     if (!xpad || !wp || !gamma || !pooled || !stats) return fail(SAGEN_ERR_NULL, "stempool: null argument");
     static bool attr_set = false;
     if (!attr_set) {

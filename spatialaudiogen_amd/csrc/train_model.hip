@@ -741,6 +741,7 @@ int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, 
                           size_t tws_bytes, hipStream_t s) {
     if (!c || !grads || !tws) return fail(SAGEN_ERR_NULL, "sagen_train_bind: null argument");
     if (!c->bound) return fail(SAGEN_ERR_WEIGHTS, "sagen_train_bind: bind the weights first");
+    if (c->G != 1) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_train_bind: a grouped context (sagen_create_grouped) runs inference only");
     if (!c->freq_mask) return fail(SAGEN_ERR_UNSUPPORTED, "the training step implements separation 'unet_mask' (the configuration train.py trains)");
     train_carve(c);
     if (tws_bytes < c->tws_floats * sizeof(float))

@@ -34,10 +34,14 @@ class SptAudioGenParams(object):
 class _Ctx(object):
     """One native context = one batch size (the TF graph is also built for a fixed batch)."""
 
-    def __init__(self, cfg, variables, device):
+    def __init__(self, cfg, variables, device, groups=1):
         l = _lib.lib()
         self.handle = C.c_void_p()
-        check(l.sagen_create(C.byref(self.handle), C.byref(cfg)))
+        self.groups = int(groups)
+        if self.groups > 1:             # `groups` independent batches per forward, one launch per layer (include/sagen.h: grouped launch)
+            check(l.sagen_create_grouped(C.byref(self.handle), C.byref(cfg), self.groups))
+        else:
+            check(l.sagen_create(C.byref(self.handle), C.byref(cfg)))
         self.batch = cfg.batch
         nbytes = int(l.sagen_workspace_bytes(self.handle))
         self.workspace = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
@@ -105,7 +109,7 @@ class _Ctx(object):
 
 class SptAudioGen(object):
     def __init__(self, ambi_order, audio_rate=48000, video_rate=10, context=1., sample_duration=0.1,
-                 encoders=None, separation='none', params=None, device=None):
+                 encoders=None, separation='none', params=None, device=None, groups=1):
         if params is None:              # defaults: 32 separated tracks; the mono-only decoder has exactly one (deploy.py:62-63 passes 1)
             params = SptAudioGenParams(sep_num_tracks=1) if separation == NO_SEPARATION else SptAudioGenParams()
         if separation == NO_SEPARATION and params.sep_num_tracks != 1:
@@ -133,6 +137,13 @@ class SptAudioGen(object):
             if torch.cuda.is_available() else None
         self._variables = None
         self._ctx = {}
+        # groups > 1: every forward carries `groups` INDEPENDENT batches (inputs [groups * B, ...], the batches back to back), run as
+        # one launch per layer by a grouped native context (include/sagen.h: sagen_create_grouped) - each batch keeps its own
+        # batch-norm statistics and its output is bit-identical to a forward of that batch alone; `batch` arguments of the plan /
+        # profile / option methods stay the size of ONE batch
+        self.groups = int(groups)
+        if self.groups < 1:
+            raise ValueError('groups must be >= 1')
 
     # ---- weights (tf.train.Saver.restore, deploy.py:79-87) ---------------------------------
     def variable_specs(self):
@@ -176,7 +187,7 @@ class SptAudioGen(object):
         if self._variables is None:
             raise RuntimeError('load_variables() first')
         if batch not in self._ctx:
-            self._ctx[batch] = _Ctx(self._config(batch), self._variables, self.device)
+            self._ctx[batch] = _Ctx(self._config(batch), self._variables, self.device, groups=self.groups)
         return self._ctx[batch]
 
     # ---- the hot path ------------------------------------------------------------------------
@@ -208,14 +219,27 @@ class SptAudioGen(object):
             raise ValueError('video encoder enabled but no video given')
         if FLOW in self.encoders and flow is None:
             raise ValueError('flow encoder enabled but no flow given')
-        B = audio.shape[0]
+        N = audio.shape[0]
+        for t, nm in ((video, 'video'), (flow, 'flow')):
+            if t is not None and t.shape[0] != N:
+                raise ValueError('%s holds %d windows, audio %d' % (nm, t.shape[0], N))
+        if N % self.groups:
+            raise ValueError('%d windows do not make %d groups of equal batches' % (N, self.groups))
+        B = N // self.groups
         ctx = self.context_for(B)
         if out is None:
-            out = torch.empty(B, self.snd_dur, self.geom.num_out, dtype=torch.float32, device=self.device)
+            out = torch.empty(N, self.snd_dur, self.geom.num_out, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (N, self.snd_dur, self.geom.num_out) or not out.is_contiguous():
+            raise ValueError('out must be a contiguous [%d, %d, %d] tensor' % (N, self.snd_dur, self.geom.num_out))
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        fwd = _lib.lib().sagen_forward_u8 if video_u8 else _lib.lib().sagen_forward
-        check(fwd(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
+        L = _lib.lib()
+        if self.groups > 1:
+            fwd = L.sagen_forward_grouped_u8 if video_u8 else L.sagen_forward_grouped
+            check(fwd(ctx.handle, self.groups, p(audio), p(video), p(flow), p(out), stream))
+        else:
+            fwd = L.sagen_forward_u8 if video_u8 else L.sagen_forward
+            check(fwd(ctx.handle, p(audio), p(video), p(flow), p(out), stream))
         return out
 
     def inference_ops_checked(self, audio, video=None, flow=None, on_saturation='rerun', out=None):
@@ -228,7 +252,7 @@ class SptAudioGen(object):
         bf16 planes (fp32's exponent range, nothing to saturate; `on_saturation='rerun'`) or the call raises (`'raise'`).
         `self.saturation_events` = [(batch size, clamped elements)] of every batch that was re-run."""
         y = self.inference_ops(audio, video, flow, out=out)
-        B = y.shape[0]
+        B = y.shape[0] // self.groups
         ctx = self.context_for(B)
         if not hasattr(self, 'saturation_events'):
             self.saturation_events = []
@@ -239,7 +263,7 @@ class SptAudioGen(object):
         ctx.sat_seen = now
         if clamped <= 0:
             return y
-        if on_saturation == 'raise':
+        if on_saturation == 'raise' or self.groups > 1:          # (a grouped context has no bf16-plane path to re-run on)
             raise FloatingPointError('fp16x2 activation planes saturated (%d elements clamped in this batch): run with '
                                      "set_option(batch, 'fp16x2', 0) / SAGEN_NO_H2=1" % clamped)
         import warnings
@@ -313,7 +337,7 @@ class SptAudioGen(object):
         """Time every (tile, split-K) candidate of every contraction on these inputs and keep the fastest
         (stored per batch size).  Returns the plan as [(layer, tile, splitk, microseconds)]."""
         out = self.inference_ops(audio, video, flow)            # validates / stages the inputs, creates the ctx
-        B = out.shape[0]
+        B = out.shape[0] // self.groups
         ctx = self.context_for(B)
         def to_dev(t, tail):
             if t is None:

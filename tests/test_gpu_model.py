@@ -240,7 +240,7 @@ def test_dh_split_of_every_conv3h_tile(T, tile_name, B):
     net.load_variables(P)
     net.inference_ops(inp['audio'], inp['video'])
     tid = SptAudioGen.tile_names().index(tile_name)
-    trunk = [n[:-len('/weights')] for n in variable_specs(enc) if n.endswith('/weights') and '_encoder/conv' in n and '/conv1/' not in n
+    trunk = [n[:-len('/weights')] for n in variable_specs(enc) if n.endswith('/weights') and n.startswith('video_encoder/conv') and '/conv1/' not in n
              and 'shortcut' not in n and not n.endswith(('3_1/conv_1/weights', '4_1/conv_1/weights', '5_1/conv_1/weights'))]
     assert len(trunk) == 13
     outs = {}
