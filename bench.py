@@ -65,8 +65,22 @@ SUSTAINED_NOTE = ('achieved / 290 TFLOP/s = the fp32-equivalent rate a pure v_mf
                   'normally distributed operands (1.66-1.81 PFLOP/s bf16: profiles/r03_mfma_sustained.txt); `frac` above is against the data-sheet peak')
 
 
-DEFAULT_GROUP = 1
-DEFAULT_IN_FLIGHT = 3
+DEFAULT_GROUP = 0          # 0 = auto: the largest divisor of K (the steps of the timed region) up to MAX_AUTO_GROUP, see pick_group
+DEFAULT_IN_FLIGHT = 0      # 0 = auto: two contexts in flight with grouped launches, three with one batch per call (measured below)
+MAX_AUTO_GROUP = 10
+
+
+def pick_group(steps, asked, cap=MAX_AUTO_GROUP):
+    """Batches per grouped launch.  Measured on one box (tools/ab_group2.sh, configs[1], ambisonic-s/s, first region / median of the repeats;
+    K = 20 | 30 steps): 1 x 3 contexts 2 631 / 2 685 | 2 667 / 2 700; 2 x 2: 2 720 / 2 790 | 2 786 / 2 823; 4 x 2: 2 839 / 2 908 | 2 861 / 2 950;
+    5 x 2: 2 848 / 2 960 | 2 919 / 2 990; 5 x 3: 2 808 / 2 940 | 2 936 / 3 030; 6 x 2: - | 2 959 / 3 025; 10 x 2: 2 986 / 3 075 | 2 967 / 3 015;
+    10 x 1: 2 881 / 2 920 | 2 907 / 2 935 - the fixed cost of a launch is paid once per group, and two grouped contexts still fill each
+    other's tails.  Auto: the largest divisor of K up to 10 (no remainder call in the timed region); a K without a divisor of at least 4
+    takes min(K, 10) and runs the remainder as one smaller call."""
+    if asked > 0:
+        return asked
+    best = max(g for g in range(1, cap + 1) if steps % g == 0) if steps > 0 else 1
+    return best if best >= 4 or best == steps else max(1, min(cap, steps))
 
 
 def parse():
@@ -417,7 +431,7 @@ def pmc_traffic_in_run(args, net, batch, dom):
         for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(tmp, ctr)
             cmd = [prof, '--pmc', ctr, '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__), '--pmc-child',
-                   '--config', args.config, '--in-flight', '1', '--group', str(args.group), '--plan-file', plan_fn, '--no-cpu-baseline', '--no-other-configs'] + \
+                   '--config', args.config, '--in-flight', '1', '--group', str(pick_group(args.steps, args.group)), '--steps', str(args.steps), '--plan-file', plan_fn, '--no-cpu-baseline', '--no-other-configs'] + \
                   (['--float-frames'] if args.float_frames else [])
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=240)
             fs = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
@@ -458,7 +472,7 @@ def main():
     if args.config == 'train':
         return main_train(args, cfg)
 
-    if args.in_flight > 1:
+    if args.in_flight != 1:
         # several batches in flight: each context stays on its caller's stream (the other batch is the overlap)
         if not os.environ.get('BENCH_TWO_STREAM_CONTEXTS'):      # (experiment switch: keep each context's own second stream as well)
             os.environ['SAGEN_ONE_STREAM'] = '1'
@@ -480,7 +494,7 @@ def main():
     # eval: a pool of distinct synthetic windows stands in for the 9216 windows of the clip set (window w of the global order
     # uses pool entry w % pool); the other configurations: each rank owns one batch of its own windows
     # (the other configurations cycle over three distinct batches of this rank's own windows: no step re-reads the inputs of the one before)
-    G = 1 if is_eval else max(1, args.group)            # batches per grouped call (eval keeps one: its metrics run per batch)
+    G = 1 if is_eval else pick_group(args.steps, args.group)     # batches per grouped call (eval keeps one: its metrics run per batch)
     CALLB = G * BATCH                                   # windows per forward call
     NPOOL = 4 if is_eval else (3 if G == 1 else 2 * G)  # resident batches (G > 1: two distinct input sets per call, alternated)
     POOL = NPOOL * BATCH
@@ -489,7 +503,7 @@ def main():
     # i % NF (each context has its own workspace and its own second stream).  Every step is still one full forward of
     # one batch; the kernels of neighbouring steps fill each other's launch tails.  Outputs are bit-identical to
     # strictly sequential execution (tests/test_gpu_streams.py, tools/two_in_flight.py).
-    NF = max(1, args.in_flight)
+    NF = args.in_flight if args.in_flight > 0 else (2 if G > 1 else 3)
     nets = [SptAudioGen(1, encoders=ENCODERS, separation='unet_mask', groups=G) for _ in range(NF)]
     for n in nets:
         n.load_variables(P)
@@ -628,14 +642,19 @@ def main():
             net.inference_ops(*a0, out=outs[0])
         torch.cuda.synchronize()
         return
+    # untimed set-up that is NOT a step first (the metric reduction loads the torch kernels it uses - hundreds of milliseconds of an idle
+    # GPU on a fresh process), THEN the W warm-up steps, so that they directly precede the timed region: with the reduction between
+    # them the chip had idled back to its low clocks when the K timed steps began (first region 4-6 % below the repeats behind it)
+    step()
+    reduce_metric()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_calls)]
     for _ in range((args.warmup + G - 1) // G):
         step()
-    reduce_metric()                     # also loads the torch kernels it uses before the timed region
+    torch.cuda.synchronize()
     for e in eval_sums:
         e.zero_()
     counter[0] = 0
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_calls)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

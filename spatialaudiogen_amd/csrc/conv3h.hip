@@ -77,7 +77,8 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
 
     const int tid = threadIdx.x;
 #ifdef SAGEN_TRACE      // debug builds (tools/trace_conv3h.py): life of every workgroup - entry, K loop entered, K loop left, epilogue done
-    unsigned long long* const trc = d.trace ? (unsigned long long*)d.trace + (size_t)blockIdx.x * 8 : nullptr;
+    const size_t trc_wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;       // (dh-split / grouped launches: every workgroup its own record)
+    unsigned long long* const trc = (d.trace && trc_wg < 8192) ? (unsigned long long*)d.trace + trc_wg * 8 : nullptr;
 #define C3H_TRC(k) do { if (trc && tid == 0) trc[k] = __builtin_amdgcn_s_memtime(); } while (0)
     if (trc && tid == 0) {
         trc[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: wave / simd / cu / sh / se
@@ -87,7 +88,7 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
     C3H_TRC(0);
     // ... and the phases of every group of two workgroups (an early and a late one): top, tiles landed, barrier passed, first
     // fragments in registers, last MFMA issued - [2][64 groups][8] behind the per-workgroup records
-    const int gsel = (int)blockIdx.x == 8 ? 0 : ((int)blockIdx.x == (int)gridDim.x - 64 ? 1 : -1);
+    const int gsel = (blockIdx.y | blockIdx.z) ? -1 : ((int)blockIdx.x == 8 ? 0 : ((int)blockIdx.x == (int)gridDim.x - 64 ? 1 : -1));
     unsigned long long* const gtr = (d.trace && gsel >= 0) ? (unsigned long long*)d.trace + (size_t)8192 * 8 + (size_t)gsel * 64 * 8 : nullptr;
     int g_idx = 0;
 #define C3H_GTRC(k) do { if (gtr && tid == 0 && g_idx < 64) gtr[g_idx * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)

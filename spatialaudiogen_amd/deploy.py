@@ -131,6 +131,10 @@ class W2XYZ(object):
     batch_size = 10            # deploy.py:50
     duration = 0.1             # deploy.py:49
     on_saturation = 'rerun'    # fp16x2 guard (SptAudioGen.inference_ops_checked): 'rerun' on bf16 planes | 'raise'
+    # batches per forward call (round 6, include/sagen.h: grouped launch): `groups` consecutive batches of 10 windows run as ONE launch per
+    # layer, each batch with its own batch-norm statistics - the output is bit-identical to groups = 1 (deploy.py:141 runs one batch
+    # per sess.run); batches that do not fill a group (the clip's tail, a zero-padded partial batch) run one at a time
+    groups = 1
 
     def __init__(self, model_dir=None, params=None, variables=None, device=None):
         if params is None:
@@ -217,16 +221,46 @@ class W2XYZ(object):
                             out[key] = x
                 yield out
 
-        src = BatchPrefetcher(batches(), depth=2, pin=True) if prefetch else batches()
+        src = BatchPrefetcher(batches(), depth=2 * max(1, self.groups), pin=True) if prefetch else batches()
         outs = []
-        for b in src:
-            to_dev = lambda k: torch.as_tensor(b[k]).to(m.device, non_blocking=True) if k in b else None
-            a_dev = to_dev('audio')
+        G = max(1, int(self.groups))
+        mg = self._grouped_model(G) if G > 1 else None
+
+        def run(net, bs):               # one forward call over the batches `bs` (len(bs) == net.groups), results appended in order
+            cat = lambda k: torch.cat([torch.as_tensor(b[k]) for b in bs], 0).to(m.device, non_blocking=True) if k in bs[0] else None
+            a_dev = cat('audio')
             # deploy.py:141 - with the fp16x2 guard: a batch whose trunk planes clamped anything is re-run on bf16 planes
-            pred = m.inference_ops_checked(a_dev, to_dev('video'), to_dev('flow'), on_saturation=self.on_saturation)
+            pred = net.inference_ops_checked(a_dev, cat('video'), cat('flow'), on_saturation=self.on_saturation)
             wyzx = ops.assemble_wyzx(a_dev[:, :, 0].contiguous(), pred, m.snd_contx)   # deploy.py:143-152
-            outs.append(wyzx[:b['n']].reshape(b['n'] * m.snd_dur, 4).cpu().numpy())
+            for i, b in enumerate(bs):
+                outs.append(wyzx[i * self.batch_size:i * self.batch_size + b['n']].reshape(b['n'] * m.snd_dur, 4).cpu().numpy())
+
+        pending = []
+        groupable = lambda b: b['n'] == self.batch_size and all(b[k].dtype == pending[0][k].dtype for k in ('video', 'flow') if k in b)
+        for b in src:
+            if G > 1 and (not pending or groupable(b)):
+                pending.append(b)
+                if len(pending) == G:
+                    run(mg, pending)
+                    pending = []
+                continue
+            for q in pending:           # a batch that cannot join the group (partial / other frame type): everything in order, singly
+                run(m, [q])
+            pending = []
+            run(m, [b])
+        for q in pending:
+            run(m, [q])
         return np.concatenate(outs, 0)
+
+    def _grouped_model(self, G):
+        """A second facade over the SAME device variables whose native contexts carry G batches per call (SptAudioGen(groups=G))."""
+        if getattr(self, '_mg', None) is None or self._mg.groups != G:
+            m = self.model
+            self._mg = SptAudioGen(ambi_order=m.ambi_order, audio_rate=m.snd_rate, video_rate=m.vid_rate, context=m.context,
+                                   sample_duration=m.duration, encoders=m.encoders, separation=m.separation, params=m.params,
+                                   device=m.device, groups=G)
+            self._mg.load_variables(m._variables)
+        return self._mg
 
 
 def parse_arguments(argv=None):
@@ -239,6 +273,9 @@ def parse_arguments(argv=None):
     parser.add_argument('--deploy_duration', default=10., type=float)
     parser.add_argument('--output_fn', default='output.wav', help='Output 4-channel (W,Y,Z,X) wav.')
     parser.add_argument('--gpu', type=int, default=0, help='GPU id')
+    parser.add_argument('--groups', type=int, default=1,
+                        help='batches of 10 windows per forward call (grouped launch: one launch per layer for all of them, each batch with '
+                             'its own batch-norm statistics; output bit-identical to 1)')
     args = parser.parse_args(argv)
     if args.deploy_duration <= 0:
         args.deploy_duration = None
@@ -252,6 +289,7 @@ def main(argv=None):
     args = parse_arguments(argv)
     torch.cuda.set_device(args.gpu)
     model = W2XYZ(args.model_dir)
+    model.groups = max(1, args.groups)
     ambi_pred = model.deploy(args.input_folder, args.deploy_start, args.deploy_duration)
     save_wav(args.output_fn, ambi_pred, model.params.audio_rate)
     print('wrote %s: %d samples x 4 channels (ACN W,Y,Z,X / SN3D)' % (args.output_fn, ambi_pred.shape[0]))

@@ -56,6 +56,27 @@ def test_deploy_matches_oracle(encoders, secs, duration):
     assert err <= 1e-4 and err <= 1e-3 * rms(ref[:, 1:])
 
 
+@pytest.mark.parametrize('encoders,secs,groups', [(['audio'], 12, 3), (['audio', 'video'], 5, 2)])
+def test_grouped_deploy_is_bit_identical_to_one_batch_per_call(encoders, secs, groups):
+    """W2XYZ.groups > 1 (round 6): consecutive batches of 10 windows as one grouped forward call - own batch-norm statistics per batch,
+    so the wav must not change by a bit; the zero-padded partial batch and the batches that do not fill a group run singly."""
+    import torch
+    assert torch.cuda.is_available()
+    ensure_lib()
+    from spatialaudiogen_amd.deploy import W2XYZ, ClipArrays
+    r = rng(secs + 40)
+    audio = (0.3 * r.normal(size=(secs * 48000, 4))).astype(np.float32)
+    video = r.integers(0, 256, size=(secs * 10, 224, 448, 3)).astype(np.uint8) if 'video' in encoders else None      # decoded frames
+    P = init_weights(variable_specs(encoders), seed=5, mode='test')
+    model = W2XYZ(params=Params(encoders), variables=P)
+    want = model.deploy(ClipArrays(audio, video), 0., 10.)
+    model.groups = groups
+    got = model.deploy(ClipArrays(audio, video), 0., 10.)
+    assert got.shape == want.shape and got.shape[0] >= 35 * 4800
+    assert np.array_equal(got, want)
+    assert model._mg.groups == groups and model._mg._ctx            # the grouped contexts really ran
+
+
 def test_deploy_cli_from_disk(tmp_path):
     """model_dir (train-params.txt + a TF tensor bundle ASSEMBLED BY HAND, tests/bundle_by_hand.py - not by the product's writer) and a
     clip folder in the scraping/preprocess.py layout, through the deploy CLI: checkpoint reader -> feeder -> HIP path -> wav, against

@@ -7,8 +7,9 @@ from spatialaudiogen_amd.model import SptAudioGen
 enc = sys.argv[1].split(',') if len(sys.argv) > 1 else ['audio', 'video']
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 P = init_weights(variable_specs(enc), seed=0, mode='bench')
-inp = synth_inputs(B, enc, seed=1234)
-net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+GROUPS = int(os.environ.get('GROUPS', '1'))       # grouped launch: GROUPS batches of B per forward call (times below are per CALL)
+inp = synth_inputs(B * GROUPS, enc, seed=1234)
+net = SptAudioGen(1, encoders=enc, separation='unet_mask', groups=GROUPS)
 net.load_variables(P)
 a = torch.as_tensor(inp['audio']).cuda(); v = torch.as_tensor(inp['video']).cuda() if 'video' in inp else None
 if v is not None and os.environ.get('U8', '1') == '1':        # frames as decoded (uint8): the default entry point of deploy / evaluate / bench
@@ -23,7 +24,7 @@ for item in filter(None, os.environ.get('FORCE', '').split(',')):
     tid_, sub = item.split(':')
     for name in variable_specs(enc):
         if name.endswith('/weights') and sub in name:
-            net.plan_set(B, name[:-len('/weights')], int(tid_), 1)
+            net.plan_set(B, name[:-len('/weights')], int(tid_), int(os.environ.get('FORCE_SK', '1')))
 net.profile_enable(B, True)
 acc = None
 N = 5
@@ -35,10 +36,10 @@ for _ in range(N):
 tot = sum(r[2] for r in acc)
 print('%-34s %-40s %9s %8s %7s' % ('kernel', 'layer', 'us', 'TFLOP/s', '%'))
 for k, l, us, fl in acc:
-    print('%-34s %-40s %9.1f %8.1f %6.1f%%' % (k, l, us, fl / us / 1e6 if fl else 0, 100 * us / tot))
+    print('%-34s %-40s %9.1f %8.1f %6.1f%%' % (k, l, us, GROUPS * fl / us / 1e6 if fl else 0, 100 * us / tot))
 print('total %.1f us' % tot)
 by = {}
 for k, l, us, fl in acc:
     b = by.setdefault(k, [0, 0.0, 0.0]); b[0] += 1; b[1] += us; b[2] += fl
 for k, (n, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-    print('%-34s n=%3d %9.1f us %6.1f%% %8.1f TFLOP/s' % (k, n, us, 100 * us / tot, fl / us / 1e6 if fl else 0))
+    print('%-34s n=%3d %9.1f us %6.1f%% %8.1f TFLOP/s' % (k, n, us, 100 * us / tot, GROUPS * fl / us / 1e6 if fl else 0))

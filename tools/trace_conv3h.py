@@ -15,7 +15,9 @@ enc = ['audio', 'video']
 B = int(os.environ.get('B', '32'))
 P = init_weights(variable_specs(enc), seed=0, mode='bench')
 inp = synth_inputs(B, enc, seed=1234)
-net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+GROUPS = int(os.environ.get('GROUPS', '1'))       # grouped launch: GROUPS batches of B per forward call (round 6)
+inp = synth_inputs(B * GROUPS, enc, seed=1234)
+net = SptAudioGen(1, encoders=enc, separation='unet_mask', groups=GROUPS)
 net.load_variables(P)
 a = torch.as_tensor(inp['audio']).cuda()
 v = torch.round((torch.as_tensor(inp['video']).cuda().double() + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
@@ -24,7 +26,7 @@ if os.environ.get('TUNE', '1') == '1': net.autotune(a, v)
 for item in filter(None, os.environ.get('FORCE', '').split(',')):
     tid_, sub = item.split(':')
     for name in variable_specs(enc):
-        if name.endswith('/weights') and sub in name: net.plan_set(B, name[:-len('/weights')], int(tid_), 1)
+        if name.endswith('/weights') and sub in name: net.plan_set(B, name[:-len('/weights')], int(tid_), int(os.environ.get('FORCE_SK', '1')))
 for _ in range(2): net.inference_ops(a, v)
 L = _lib.lib()
 L.sagen_debug_trace_conv3h.argtypes = [C.c_void_p, C.c_int]
