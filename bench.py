@@ -351,7 +351,7 @@ def main_train(args, cfg):
         'fp16x2_families_us_per_step': round(sum(a[1] for k, a in agg.items() if k.startswith(('conv3h', 'wgrad3h')) or (k.startswith('conv3g') and k.rstrip('>').endswith('true'))) / nprof, 1),
         'bf16x3_families_us_per_step': round(sum(a[1] for k, a in agg.items() if k.startswith(('igemm3', 'conv3p', 'wgrad3_', 'wgrad3r')) or (k.startswith('conv3g') and not k.rstrip('>').endswith('true'))) / nprof, 1),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        'launches_per_step': round(n_l / nprof / G, 2), 'batches_per_launch': G, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
+        'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2), 'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
         'share_of_step_time': round(us_l / total_us, 3),
         'phases_us_per_step': {k: round(v[0] / nprof, 1) for k, v in sorted(by_phase.items())},
         'phases_tflops': {k: round(v[1] / (v[0] * 1e-6) / 1e12, 1) for k, v in sorted(by_phase.items()) if v[1] > 0},
@@ -494,9 +494,18 @@ def main():
     # eval: a pool of distinct synthetic windows stands in for the 9216 windows of the clip set (window w of the global order
     # uses pool entry w % pool); the other configurations: each rank owns one batch of its own windows
     # (the other configurations cycle over three distinct batches of this rank's own windows: no step re-reads the inputs of the one before)
-    G = 1 if is_eval else pick_group(args.steps, args.group)     # batches per grouped call (eval keeps one: its metrics run per batch)
+    # which batches does this rank run?  eval: its whole-batch shard of the global order; otherwise its own batches, repeated
+    if is_eval:
+        from spatialaudiogen_amd.evaluate import batch_shard
+        lo_b, hi_b, n_batches = batch_shard(EVAL_CLIPS * EVAL_WINDOWS_PER_CLIP, rank, world, 'drop')
+        eval_batches = list(range(lo_b, hi_b))
+        eval_steps = min(args.steps, len(eval_batches)) if args.steps > 0 else len(eval_batches)
+        # eval: consecutive batches of the shard per call, a divisor of the step count only (no remainder call: the metrics follow the batches)
+        G = args.group if args.group > 0 and eval_steps % args.group == 0 else max(g for g in range(1, 9) if eval_steps % g == 0)
+    else:
+        G = pick_group(args.steps, args.group)          # batches per grouped call
     CALLB = G * BATCH                                   # windows per forward call
-    NPOOL = 4 if is_eval else (3 if G == 1 else 2 * G)  # resident batches (G > 1: two distinct input sets per call, alternated)
+    NPOOL = max(4, G) if is_eval else (3 if G == 1 else 2 * G)  # resident batches (G > 1: two distinct input sets per call, alternated)
     POOL = NPOOL * BATCH
     inp = synth_inputs(POOL, ENCODERS, seed=1234 + (0 if is_eval else rank))
     # Steps are independent batches, so NF of them are kept in flight: step i runs on native context i % NF and stream
@@ -510,6 +519,8 @@ def main():
     net = nets[0]
     streams = []                        # created after the contexts (below): ROCm maps HIP streams to hardware queues in creation order
     dev_in = {k: torch.as_tensor(v).cuda() for k, v in inp.items()}
+    if is_eval:     # window w of the global order uses pool entry w % POOL: the pool twice in a row makes any run of <= POOL windows one slice
+        dev_in = {k: torch.cat([v, v], 0) for k, v in dev_in.items()}
     names_in = ['audio'] + [k for k in ('video', 'flow') if k in dev_in]
     # Video frames are resident the way the JPEG decoder produced them: uint8 (feeder.py reads .jpg; myutils.py:88-89 normalises with
     # x / 255 - 0.5).  sagen_forward_u8 applies that normalisation on the device; the synthetic frames are exact images of uint8 values
@@ -523,8 +534,8 @@ def main():
         dev_in['video'] = u8
         frames_note = 'uint8 as decoded (x / 255 - 0.5 applied on the device), sagen_forward_u8'
 
-    def batch_inputs(b):                # device views of the windows of (global) batch b - of call b's G batches when grouped
-        lo = (b * CALLB) % POOL
+    def batch_inputs(b):                # device views of the windows of call b's G batches (eval: of the G batches from global batch b on)
+        lo = (b * (BATCH if is_eval else CALLB)) % POOL
         return [dev_in[k][lo:lo + CALLB] for k in names_in]
 
     outs = [torch.empty(CALLB, 4800, 3, device='cuda') for _ in range(NF)]
@@ -532,12 +543,8 @@ def main():
     eval_sums = [torch.zeros(12, dtype=torch.float64, device='cuda') for _ in range(NF)]
     counter = [0]
 
-    # which batches does this rank run?  eval: its whole-batch shard of the global order; otherwise its own batch, repeated
     if is_eval:
-        from spatialaudiogen_amd.evaluate import batch_shard
-        lo_b, hi_b, n_batches = batch_shard(EVAL_CLIPS * EVAL_WINDOWS_PER_CLIP, rank, world, 'drop')
-        my_batches = list(range(lo_b, hi_b))
-        steps = min(args.steps, len(my_batches)) if args.steps > 0 else len(my_batches)
+        my_batches, steps = eval_batches[::G], eval_steps             # (the first batch of every call)
     else:
         my_batches, steps = list(range(NPOOL // G)), args.steps
     n_calls, rem = steps // G, steps % G                # K steps (batches) = n_calls grouped calls + one call of the `rem` left over
@@ -829,7 +836,7 @@ def main():
                        'dense bf16 MFMA peak 2500 TF / 6 products per fp32 multiply (bf16x3 kernel); algorithmic fp32 FLOPs'
                        if b3 else 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'),
         'achieved_over_fp32_mfma_peak': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-        'launches_per_step': n_l // nprof, 'avg_launch_us': round(us_l / n_l, 2),
+        'launches_per_step': round(n_l / nprof / G, 2), 'batches_per_launch': G, 'avg_launch_us': round(us_l / n_l, 2),
         'gflop_per_launch': round(fl_l / n_l / 1e9, 3),
         'share_of_step_time': round(us_l / total_us, 3),
         'largest_hbm_bound_kernel': None if hbm_dom is None else {'kernel': hbm_dom, 'launches_per_step': agg[hbm_dom][0] // nprof,

@@ -106,3 +106,19 @@ def test_metric_reducer_keeps_the_reference_mean_and_reports_the_finite_one():
     vals, n = red.reduce()
     assert n == 3 and vals['a'] == 3.0 and np.isnan(vals['b']) and np.isinf(vals['c'])
     assert red.finite_means == {'a': 3.0, 'b': 5.0, 'c': 3.0} and red.finite_counts == {'a': 3, 'b': 2, 'c': 2}
+
+
+def test_bench_picks_a_group_size_that_divides_the_timed_steps():
+    """bench.py --group 0 (auto): the largest divisor of K up to 10, so that the K timed steps are whole grouped calls; a K without a
+    divisor of at least 4 takes min(K, 10) and a smaller call for the remainder; an explicit --group wins."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.pick_group(20, 0) == 10 and b.pick_group(30, 0) == 10 and b.pick_group(50, 0) == 10
+    assert b.pick_group(4, 0) == 4 and b.pick_group(2, 0) == 2 and b.pick_group(1, 0) == 1 and b.pick_group(3, 0) == 3
+    assert b.pick_group(14, 0) == 7 and b.pick_group(17, 0) == 10 and b.pick_group(22, 0) == 10      # 17 = 10 + 7, 22 = 2 x 10 + 2
+    assert b.pick_group(20, 3) == 3 and b.pick_group(300, 0) == 10 and b.pick_group(40, 0) == 10
+    for k in range(1, 64):
+        g = b.pick_group(k, 0)
+        assert 1 <= g <= min(k, 10)
