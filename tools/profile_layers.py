@@ -7,7 +7,7 @@ from spatialaudiogen_amd.model import SptAudioGen
 enc = sys.argv[1].split(',') if len(sys.argv) > 1 else ['audio', 'video']
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 P = init_weights(variable_specs(enc), seed=0, mode='bench')
-GROUPS = int(os.environ.get('GROUPS', '1'))       # grouped launch: GROUPS batches of B per forward call (times below are per CALL)
+GROUPS = int(os.environ.get('NGROUPS', '1'))       # (NGROUPS: bash ignores assignments to GROUPS) grouped launch: GROUPS batches of B per forward call (times below are per CALL)
 inp = synth_inputs(B * GROUPS, enc, seed=1234)
 net = SptAudioGen(1, encoders=enc, separation='unet_mask', groups=GROUPS)
 net.load_variables(P)

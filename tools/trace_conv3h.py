@@ -15,7 +15,7 @@ enc = ['audio', 'video']
 B = int(os.environ.get('B', '32'))
 P = init_weights(variable_specs(enc), seed=0, mode='bench')
 inp = synth_inputs(B, enc, seed=1234)
-GROUPS = int(os.environ.get('GROUPS', '1'))       # grouped launch: GROUPS batches of B per forward call (round 6)
+GROUPS = int(os.environ.get('NGROUPS', '1'))       # (NGROUPS: bash ignores assignments to GROUPS) grouped launch: GROUPS batches of B per forward call (round 6)
 inp = synth_inputs(B * GROUPS, enc, seed=1234)
 net = SptAudioGen(1, encoders=enc, separation='unet_mask', groups=GROUPS)
 net.load_variables(P)
