@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
         const int mrow = m0 + wm * WM + 4 * kk;                      // first output row of this lane
         const unsigned rbase = (unsigned)mrow * ldy4;
         float bias_j[NT], cs[NT], cq[NT];
+        float amax = 0.f;
         unsigned col4[NT];                                           // byte offset of the lane's column, OOB beyond N
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -297,13 +298,17 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
                             cq[j] = __builtin_fmaf(v, v, cq[j]);
                             v += bias_j[j];
                             if (d.relu_out) v = fmaxf(v, 0.f);
+                            amax = fmaxf(amax, (off & OOB) ? 0.f : fabsf(v));       // (IgemmDesc::amax_out: what is STORED only)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off, 0, 0);
                         }
                     }
                 }
         };
-        if (plain && n0 + BN <= d.N) epilogue(std::true_type{});
+        // exact max |y| of what this launch stores (round 6: the audio encoder's convs on planes publish the maximum of their half of the
+        // concat buffer like the register-staged kernels' epilogues do); only the general form carries it
+        if (plain && n0 + BN <= d.N && d.amax_out == nullptr) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        if (d.amax_out != nullptr) igemm_publish_amax(d.amax_out, amax);           // (uniform condition: every lane of every wave arrives)
         if (d.stats != nullptr) {                 // per-channel (sum, sumsq) of the raw output -> fp64 accumulators [2][N]
             lds_barrier();                        // every wave is done with the last group's fragments: the ring is free
             float* const red = reinterpret_cast<float*>(smem);               // [WAVES_M * 2 (lane halves)][2][BN]

@@ -121,6 +121,7 @@ struct sagen_ctx {
     bool train_h2 = true;                  // the training step's forward also runs the trunk's stride-1 3x3 convs on the fp16x2 planes (SAGEN_TRAIN_NO_H2=1: bf16x3)
     bool use_h2 = true;                    // inference: the planes of the trunk are two fp16 planes (conv3h.hip: three products per multiply) instead of three bf16 planes; SAGEN_NO_H2=1 / sagen_set_option("fp16x2", 0)
     bool train_h2d = true;                 // ... and its backward runs the stride-1 3x3 data gradients on fp16x2 planes of dy, written by the batch-norm backward (SAGEN_TRAIN_NO_H2D=1: bf16x3 on fp32 dy)
+    bool no_aud_planes = false;            // SAGEN_NO_AUDIO_PLANES=1: conv2 .. conv5 of the audio encoder stay on the register-staged kernels (fp32 operand, in-loop split) instead of conv3g_kernel on fp16x2 planes of cat_l's encoder half (round 6)
     bool no_dh_split = false;              // SAGEN_NO_DH_SPLIT=1: the tuner does not consider conv3h_kernel's dh-split (one filter row per workgroup, round 6)
     bool sk_fused = false;                 // SAGEN_SK_FUSED=1: split-K partials are combined inside the contraction (last-arriver, igemm_epilogue) instead of by a reducer launch - bit-identical, measured no faster
     bool train_h2w = true;                 // ... and the weight gradients of those layers run on the planes too (wgrad3h.hip): the forward retains its activation planes (SAGEN_TRAIN_NO_H2W=1: bf16x3 on the fp32 tensors)
@@ -224,6 +225,11 @@ static inline void add_resnet_vars(sagen_ctx* c, const std::string& scope) {
             cin = cout;
         }
     }
+}
+
+// can conv3g_kernel run this conv given planes of its Cin-channel input?  (igemm_launch fills the fields conv3g_ok reads only later)
+static inline bool conv3g_ok_desc(const IgemmDesc& d, int cin) {
+    return cin % 16 == 0 && d.Kpad == d.K && d.in_scale == nullptr && d.bn_in.acc == nullptr && d.dsh * d.dsw == 1;
 }
 
 static inline size_t packed_floats(long N, long K) { return (size_t)N * ((K + 15) / 16 * 16); }

@@ -51,6 +51,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups) {
     c->train_h2w = getenv("SAGEN_TRAIN_NO_H2W") == nullptr;
     c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
     c->no_dh_split = getenv("SAGEN_NO_DH_SPLIT") != nullptr;
+    c->no_aud_planes = getenv("SAGEN_NO_AUDIO_PLANES") != nullptr;
     c->no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
     c->train_bands = getenv("SAGEN_TRAIN_NO_BANDS") == nullptr;
     c->train_rawpool = getenv("SAGEN_TRAIN_NO_RAWPOOL") == nullptr;
@@ -163,7 +164,8 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups) {
         // ... and deconv1 of the mask decoder (conv3g_kernel with the fused decoder tail on planes of cat1: sagen_forward_impl)
         if ((vs.ndim == 4 && ((vs.shape[0] == 3 && vs.shape[1] == 3) || (vs.shape[0] == 1 && vs.shape[1] == 1)) && vs.shape[2] % 16 == 0 &&
              vs.name.find("_encoder/conv") != std::string::npos) || vs.name == "separation/deconv1/weights" ||
-            (vs.ndim == 4 && vs.shape[2] == 3 && vs.name.find("_encoder/conv1/conv/weights") != std::string::npos)) {      // ... and the stem, for float frames (stem8.hip, F16)
+            (vs.ndim == 4 && vs.shape[2] == 3 && vs.name.find("_encoder/conv1/conv/weights") != std::string::npos) ||      // ... and the stem, for float frames (stem8.hip, F16)
+            (vs.ndim == 4 && vs.shape[2] % 16 == 0 && vs.name.compare(0, 18, "audio_encoder/conv") == 0)) {                 // ... and conv2 .. conv5 of the audio encoder (round 6: conv3g_kernel on planes of cat_l's encoder half)
             c->alloc("pkh:" + vs.name, n);
             h2_pack_blocks += n / 1024 + 1;
             c->h2_slot[vs.name.substr(0, vs.name.size() - 8)] = -1;
@@ -224,6 +226,11 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups) {
             size_t mx = 0;
             for (int l = 2; l <= 5; ++l) mx = std::max(mx, p3h_bytes(B, c->enc_h[l], c->enc_w[l], 2 * c->enc_c[l]));
             c->alloc("catp", (mx + 3) / 4 + 64);
+        }
+        {   // round 6: the encoder half of cat_l (l = 1..4) as fp16x2 planes, the operand of the audio encoder's conv(l+1) on conv3g_kernel
+            size_t mx = 0;
+            for (int l = 1; l <= 4; ++l) mx = std::max(mx, p3h_bytes(B, c->enc_h[l], c->enc_w[l], c->enc_c[l]));
+            c->alloc("aencp", (mx + 3) / 4 + 64);
         }
         c->alloc("amax", 10 * H2_AMAX_FLOATS + 64);       // [cat_l: l = 1..5][decoder half, encoder half][H2_AMAX_FLOATS], then 2^-ka of the planes of cat_l at [.. + l]
         c->alloc("dmask", (size_t)B * 23 * 1024 * c->nsep);
@@ -563,6 +570,32 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         d.relu_out = 1;
         if (want_amax) d.amax_out = g.cat_amax(l + 1, 1);        // max |conv(l+1)| = the encoder half of cat_(l+1)
         g.layer = name;
+        // Round 6: conv2 .. conv5 on fp16x2 planes of cat_l's encoder half (conv3g_kernel: three products per multiply, no operand split in
+        // the K loop) - the planes' scale is that half's EXACT maximum, published by conv_l's epilogue (as for the decoder, round 5).  With
+        // several batches per launch these layers were the register-staged family's largest share (40 - 76 TFLOP/s: 11 % of a grouped call)
+        bool aud_planes = l >= 1 && want_amax && !c->no_aud_planes && f.h2() && c->bufs.count("aencp") != 0 && c->h2_slot.count(name) != 0 &&
+                          conv3g_ok_desc(d, c->enc_c[l]);
+        if (aud_planes && !c->tuning) {             // a plan that names a register-staged tile keeps the fp32 operand (no pack pass)
+            auto it = c->plan.find(name);
+            if (it != c->plan.end() ? !igemm_tile_p3((IgemmTile)it->second.tile)
+                                    : B * c->G < 128)      // untuned: the plane-fed kernel cannot split K - it needs the rows of a grouped call (or a large batch) to fill the chip
+                aud_planes = false;
+        }
+        if (aud_planes) {
+            const int cp = c->enc_c[l], Hl = c->enc_h[l], Wl = c->enc_w[l];
+            float* const a_inv = c->p("amax") + (size_t)10 * H2_AMAX_FLOATS + 8 + l;
+            g.layer = name + "/planes";
+            g.timed("h2_pack_rows_kernel", 0.0, [&] {
+                return h2_pack_rows_launch(c->p("cat" + std::to_string(l)) + cp, (long)Hl * Wl * 2 * cp, (long)Wl * 2 * cp, 2 * cp, 0, B, Hl, Wl, cp,
+                                           g.cat_amax(l, 1), nullptr, c->p("aencp"), a_inv, reinterpret_cast<unsigned*>(c->p("h2s") + 7), g.s); });
+            g.layer = name;
+            d.xp3 = c->p("aencp"); d.xp3_fmt = 1; d.xp3_row0 = 0; d.xp3_rows = 0;
+            d.p3_np = B * Hl * (Wl + 1);
+            d.xp3_cstride = (unsigned)((size_t)d.p3_np * 64);
+            d.xp3_bytes = (unsigned)((size_t)d.xp3_cstride * (cp / 16));
+            d.wh2 = c->p("pkh:" + name + "/weights"); d.wh2_bytes = (unsigned)((size_t)d.N * d.Kpad * 4);
+            d.h2_a_inv = a_inv; d.h2_w_inv = c->p("h2s") + c->h2_slot.at(name);
+        }
         g.gemm(d);
     }
 

@@ -70,6 +70,41 @@ def test_audio_only_intermediates_and_output(T):
     assert np.array_equal(got3, got)
 
 
+@pytest.mark.parametrize('tile_name', ['conv3g_kernel<128,64,64,32,3,true>', 'conv3g_kernel<64,64,32,32,4,true>',
+                                       'conv3g_kernel<128,128,64,64,2,true>', 'conv3g_kernel<64,128,32,64,3,true>'])
+@pytest.mark.parametrize('B', [2, 5])
+def test_audio_encoder_convs_on_planes_of_the_concat_buffers(T, tile_name, B):
+    """Round 6: conv2 .. conv5 of the audio encoder (model.py:161-187: VALID 3x7 / 3x5 convs, strides (2,4) (2,2) (1,1) (1,1)) on
+    conv3g_kernel over fp16x2 planes of cat_l's encoder half, scaled by that half's EXACT maximum (published by conv_l's epilogue; conv3g's
+    own epilogue publishes the next one).  Every conv3g tile forced on them: the layers really run it, their outputs and the network's
+    hold the oracle's bars and agree with the register-staged kernels (fp32 operand, six products) to rounding."""
+    from spatialaudiogen_amd.model import SptAudioGen
+    enc = ['audio']
+    P = init_weights(variable_specs(enc), seed=21, mode='test')
+    inp = synth_inputs(B, enc, seed=55)
+    orc = SptAudioGenOracle(encoders=enc)
+    ref = orc.inference_ops(inp['audio'], P)
+    net = SptAudioGen(1, encoders=enc, separation='unet_mask')
+    net.load_variables(P)
+    base = net.inference_ops(inp['audio']).cpu().numpy()          # untuned small batch: the register-staged kernels
+    tid = SptAudioGen.tile_names().index(tile_name)
+    layers = ['audio_encoder/conv%d' % l for l in range(2, 6)]
+    for name in layers:
+        net.plan_set(B, name, tid, 1)
+    net.profile_enable(B, True)
+    got = net.inference_ops(inp['audio']).cpu().numpy()
+    rows = net.profile_report(B)
+    net.profile_enable(B, False)
+    for name in layers:
+        assert [k for k, layer, _, _ in rows if layer == name] == [tile_name], (name, [k for k, layer, _, _ in rows if layer == name])
+        assert [k for k, layer, _, _ in rows if layer == name + '/planes'] == ['h2_pack_rows_kernel']
+        g = net.intermediate(B, name).cpu().numpy()
+        assert rel_rms_err(g, orc.ends[name].reshape(g.shape)) < 5e-5, name
+    check_out(got, ref)
+    assert rel_rms_err(got, base) < 2e-5, rel_rms_err(got, base)
+    assert net.counter(B, 'fp16x2_saturations') == 0
+
+
 def test_audio_video(T):
     net, orc, got, ref = run_pair(T, ['audio', 'video'])
     g = net.intermediate(2, 'bottleneck').cpu().numpy()
