@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256, conv3g_wgs_per_cu(BM, BN, KS, H2)) void conv3g
                                              : __builtin_amdgcn_make_buffer_rsrc((void*)(d.w + (size_t)d.N * d.Kpad), 0, d.w_bytes / 2 * 3, 0x00020000);
 
     // block -> tile: XCD x owns a contiguous run of M tiles (neighbouring tiles share input rows in one L2)
-    const int xcd = blockIdx.x & 7;
+    // (grouped launch: group g rotates the owner by g, so that the XCD a short tile list leaves without tiles - 14 tiles of 256 rows at
+    //  stage 5 are 2 + 2 + .. + 0 - is another one for every group; a workgroup's physical XCD stays blockIdx.x & 7: the grid is a
+    //  multiple of 8 wide, and all tiles of one owner still run on one XCD)
+    const int xcd = (blockIdx.x + blockIdx.z) & 7;
     const int per = (nM + 7) >> 3;
     const int t_run = blockIdx.x >> 3;
     const int my_tiles = max(min((xcd + 1) * per, nM) - xcd * per, 0) * nN;

@@ -115,7 +115,10 @@ __device__ __forceinline__ void conv3h_body(const IgemmDesc& d) {
     const float osc = d.h2_a_inv[0] * d.h2_w_inv[0];      // (read here: two dependent-latency loads the epilogue would otherwise wait for)
 
     // block -> tile: XCD x owns M tiles [x*per, (x+1)*per) (vertically neighbouring tiles share input rows in one L2)
-    const int xcd = blockIdx.x & 7;
+    // (grouped launch: group g rotates the owner by g, so that the XCD a short tile list leaves without tiles - 14 tiles of 256 rows at
+    //  stage 5 are 2 + 2 + .. + 0 - is another one for every group; a workgroup's physical XCD stays blockIdx.x & 7: the grid is a
+    //  multiple of 8 wide, and all tiles of one owner still run on one XCD)
+    const int xcd = (blockIdx.x + blockIdx.z) & 7;
     const int per = (nM + 7) >> 3;
     const int t_run = blockIdx.x >> 3;
     const int my_tiles = max(min((xcd + 1) * per, nM) - xcd * per, 0) * nN;

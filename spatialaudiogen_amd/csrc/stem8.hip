@@ -135,6 +135,26 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     bool use_min[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) use_min[k] = OUT == 1 ? false : gamma[nh * S8_NH + 4 * pch4 + k] < 0.f;
+    // Round 6 (the kernel's way out was VALU-bound: 11 VALU per MFMA, matrix pipe 39 % busy).  Inference (OUT 0) stages the raw tile
+    // SIGN-FLIPPED where gamma < 0: -fma(a, s, t) = fma(a, -s, -t) exactly, min(a, b) = -max(-a, -b) exactly, so the pool is a plain
+    // max (one instruction per element instead of min + max + select) and the pooled value is flipped back once; the channel sums
+    // are taken of the flipped values and the sum's sign restored at the end (the squares do not care).  Bit-identical results.
+    constexpr bool SGN = OUT == 0;
+    float sgn4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sgn4[k] = (SGN && use_min[k]) ? -1.f : 1.f;
+    const float sgn_l = (SGN && gamma[nh * S8_NH + li] < 0.f) ? -1.f : 1.f;      // of this lane's channel (epilogue)
+    // ... and the nine LDS offsets of a pooling thread's window are the same for every patch that does not touch the image's last row /
+    // column (pr < 6 and pc < 15): computed once
+    int poff[9];
+    {
+        const int p = tid >> 3;
+        const int pr_l = p / S8_PW, pc_l = p - pr_l * S8_PW;
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) poff[dr * 3 + dc] = s8_slot((2 * pr_l + dr) * S8_RW + 2 * pc_l + dc) * S8_NH + 4 * pch4;
+    }
     // statistics straight from the accumulators: which of this lane's 16 tile rows are pixels the patch OWNS (16 x 14 of the 17 x 15;
     // the halo row / column belongs to the neighbour) - the same for every patch
     unsigned own = 0;
@@ -146,7 +166,8 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
     }
     float ssum = 0.f, ssq = 0.f;
     __syncthreads();
-    const float cbl = cb[li];
+    const float cbl = cb[li] * sgn_l;
+    const float osc_l = osc * sgn_l;
 
     // The patch of the plane a tile needs - 39 rows x 36 pixels x 8 B = 11 KB - goes through LDS: every input pixel is fetched from
     // global memory ONCE per workgroup (each is used by ~10 (row, tap) pairs: with per-lane fragment loads straight from global
@@ -232,7 +253,7 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
         // C/D layout of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float v = fmaf(acc[0][e] + acc[1][e], osc, cbl);
+            const float v = fmaf(acc[0][e] + acc[1][e], osc_l, cbl);       // (sign-flipped where gamma < 0 at inference, see above)
             ct[s8_slot(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * S8_NH + li] = v;
             const float vo = ((own >> e) & 1u) ? v : 0.f;
             ssum += vo;
@@ -254,26 +275,40 @@ __global__ __launch_bounds__(S8_THREADS, 2) void stem8pool_kernel(const char* __
             const int p = tid >> 3;
             const int pr_l = p / S8_PW, pc_l = p - pr_l * S8_PW;
             float4 v[9];
+            if (pr < 6 && pc < 15) {                 // (uniform) interior patch: the precomputed window
 #pragma unroll
-            for (int dr = 0; dr < 3; ++dr)
+                for (int k = 0; k < 9; ++k) v[k] = *reinterpret_cast<const float4*>(ct + poff[k]);
+            } else {
 #pragma unroll
-                for (int dc = 0; dc < 3; ++dc) {
-                    // (rows / columns past the image edge are clamped to the window's first row / column: max / min is unchanged by a duplicate)
-                    const int rr = (R0 + 2 * pr_l + dr >= 112) ? 2 * pr_l : 2 * pr_l + dr;
-                    const int cc = (C0 + 2 * pc_l + dc >= 224) ? 2 * pc_l : 2 * pc_l + dc;
-                    v[dr * 3 + dc] = *reinterpret_cast<const float4*>(ct + s8_slot(rr * S8_RW + cc) * S8_NH + 4 * pch4);
-                }
+                for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) {
+                        // (rows / columns past the image edge are clamped to the window's first row / column: max / min is unchanged by a duplicate)
+                        const int rr = (R0 + 2 * pr_l + dr >= 112) ? 2 * pr_l : 2 * pr_l + dr;
+                        const int cc = (C0 + 2 * pc_l + dc >= 224) ? 2 * pc_l : 2 * pc_l + dc;
+                        v[dr * 3 + dc] = *reinterpret_cast<const float4*>(ct + s8_slot(rr * S8_RW + cc) * S8_NH + 4 * pch4);
+                    }
+            }
             float4 ext = v[0];
+            if constexpr (SGN) {                     // the staged values are flipped where the pool is a min: a plain max, flipped back
 #pragma unroll
-            for (int k = 1; k < 9; ++k) {
-                ext.x = use_min[0] ? fminf(ext.x, v[k].x) : fmaxf(ext.x, v[k].x); ext.y = use_min[1] ? fminf(ext.y, v[k].y) : fmaxf(ext.y, v[k].y);
-                ext.z = use_min[2] ? fminf(ext.z, v[k].z) : fmaxf(ext.z, v[k].z); ext.w = use_min[3] ? fminf(ext.w, v[k].w) : fmaxf(ext.w, v[k].w);
+                for (int k = 1; k < 9; ++k) {
+                    ext.x = fmaxf(ext.x, v[k].x); ext.y = fmaxf(ext.y, v[k].y); ext.z = fmaxf(ext.z, v[k].z); ext.w = fmaxf(ext.w, v[k].w);
+                }
+                ext.x *= sgn4[0]; ext.y *= sgn4[1]; ext.z *= sgn4[2]; ext.w *= sgn4[3];
+            } else {
+#pragma unroll
+                for (int k = 1; k < 9; ++k) {
+                    ext.x = use_min[0] ? fminf(ext.x, v[k].x) : fmaxf(ext.x, v[k].x); ext.y = use_min[1] ? fminf(ext.y, v[k].y) : fmaxf(ext.y, v[k].y);
+                    ext.z = use_min[2] ? fminf(ext.z, v[k].z) : fmaxf(ext.z, v[k].z); ext.w = use_min[3] ? fminf(ext.w, v[k].w) : fmaxf(ext.w, v[k].w);
+                }
             }
             *reinterpret_cast<float4*>(pooled + (((long)b * 56 + 8 * pr + pr_l) * 112 + 7 * pc + pc_l) * 64 + nh * S8_NH + 4 * pch4) = ext;
         }
         __syncthreads();                       // the raw tile is overwritten by the next patch
     }
     // per-channel (sum, sumsq): the two lane halves of a wave hold the same channel, then the eight waves
+    ssum *= sgn_l;                                   // (the sums were taken of the sign-flipped values)
     ssum = wave_xor_add<32>(ssum);
     ssq = wave_xor_add<32>(ssq);
     if (g == 0) {
