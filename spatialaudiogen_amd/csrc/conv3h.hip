@@ -430,7 +430,9 @@ __global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC, 2)) void conv3h_
 }
 // ... with the three-deep activation ring
 template <int BM, int BN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC, 3)) void conv3hr_kernel(const IgemmDesc d) {
+__global__ __launch_bounds__(256, conv3h_wgs_per_cu(BM, BN, KC, 3)) void conv3hr_kernel(const IgemmDesc d_in) {
+    IgemmDesc d = d_in;
+    if (d.grp.G > 1) igemm_relocate(d, (int)blockIdx.z);              // grouped launch (common.h)
     conv3h_body<BM, BN, WM, WN, KC, 3>(d);
 }
 
@@ -440,8 +442,8 @@ static int launch_conv3h(const IgemmDesc& d, hipStream_t s) {
     const int per = (cdiv(d.p3_np, BM - 2) + 7) / 8;
     const int grid = 8 * per * cdiv(d.N, BN);
     if constexpr (AR == 3) {
-        if (d.splitk != 1 || d.grp.G != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3hr: no dh-split (the three-deep ring needs three groups) and no grouped launch");
-        hipLaunchKernelGGL((conv3hr_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, d);
+        if (d.splitk != 1) return fail(SAGEN_ERR_UNSUPPORTED, "conv3hr: no dh-split (the three-deep ring needs three groups)");
+        hipLaunchKernelGGL((conv3hr_kernel<BM, BN, WM, WN, KC>), dim3(grid, 1, d.grp.G), dim3(256), 0, s, d);
     } else hipLaunchKernelGGL((conv3h_kernel<BM, BN, WM, WN, KC>), dim3(grid, d.splitk, d.grp.G), dim3(256), 0, s, d);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;

@@ -372,13 +372,13 @@ const char* igemm_tile_name(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kT
 static bool uniform_taps_for(const IgemmDesc& d, int bk) {
     return (d.ntaps > 1 ? (d.Cin % bk == 0) : true) && (d.K % bk == 0);
 }
-// kernels that take the group index of a grouped launch from their grid (common.h): igemm_kernel, igemm3_kernel, conv3h_kernel, conv3g_kernel
+// kernels that take the group index of a grouped launch from their grid (common.h): igemm_kernel, igemm3_kernel, conv3h_kernel, conv3hr_kernel, conv3g_kernel
 bool igemm_tile_grouped(IgemmTile t) {
     if (t < 0 || t >= TILE_AUTO) return false;
     const TileCfg& k = kTiles[t];
     if (k.s2 || (k.dw3 && !k.p3)) return false;                       // igemm3s2_kernel, igemm3dw_kernel
     if (k.p3 && !k.h && !k.g) return false;                            // conv3p_kernel / conv3pp_kernel
-    return t != TILE_P3HR_256x64 && t != TILE_P3HR_128x64 && t != TILE_P3HR_64x64_C2;
+    return true;
 }
 bool igemm_tile_ok(const IgemmDesc& d, IgemmTile t) {
     if (t < 0 || t >= TILE_AUTO) return false;
