@@ -73,6 +73,18 @@ class Evaluator(object):
         self.maps = []                    # per sample (pred map, gt map) [7,12] each (eval.py:190: ang_res=30)
         self._sh = None
 
+    def run_batches(self, batches, grouped_net):
+        """`len(batches)` FULL batches (each (ids, ambix [16,52799,4], video, flow, masks), frames of one dtype) as ONE grouped forward
+        call (round 6: SptAudioGen(groups=G): a launch per layer for all of them, every batch with its own batch-norm statistics - the
+        predictions are bit-identical to run_batch's) followed by ONE metrics launch over all their windows (per-sample values)."""
+        import torch
+        dev = self.net.device
+        cat = lambda k: None if batches[0][k] is None else torch.cat([torch.as_tensor(b[k]) for b in batches], 0).to(dev)
+        a = cat(1)
+        pred = grouped_net.inference_ops_checked(a[:, :, :1].contiguous(), cat(2), cat(3), on_saturation='raise')
+        m = torch.as_tensor(np.concatenate([b[4].astype(np.float32) for b in batches], 0)).to(dev)
+        self._finish([i for b in batches for i in b[0]], a, pred, m, a.shape[0])
+
     def run_batch(self, ids, ambix, video, flow, masks):
         """ambix [n<=16, 52799, 4]; masks [n, 4].  n < 16 only for the optional zero-padded final batch: its padded
         windows are dropped from the metrics but do enter the batch-norm statistics."""
@@ -86,8 +98,13 @@ class Evaluator(object):
         a = torch.as_tensor(pad(ambix)).to(dev)
         # (fp16x2 guard: a batch whose trunk planes clamped anything is re-run on bf16 planes - SptAudioGen.inference_ops_checked)
         pred = self.net.inference_ops_checked(a[:, :, :1].contiguous(), pad(video), pad(flow))
-        target = a[:, self.ss:self.ss + self.t, 1:].contiguous()
         m = torch.as_tensor(pad(masks.astype(np.float32))).to(dev)
+        self._finish(ids, a, pred, m, n)
+
+    def _finish(self, ids, a, pred, m, n):
+        """metrics + rows of the first n windows of a forward's worth of windows (a [N,52799,4] on the device, pred [N,4800,3], m [N,4])"""
+        import torch
+        target = a[:, self.ss:self.ss + self.t, 1:].contiguous()
         _, stft_ps, lsd_ps, mse_ps, snr_ps = self.net.evaluation_ops(pred, target, None, m[:, 1:])
         amp_p = pred.abs().amax(dim=(1, 2)); amp_g = target.abs().amax(dim=(1, 2))
         per = torch.stack([amp_p, amp_g], 1).cpu().numpy()
@@ -135,7 +152,7 @@ class _ReaderCache(object):
 
 
 def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None, params=None, overwrite=True,
-             partial_batch='drop', power_maps=False):
+             partial_batch='drop', power_maps=False, groups=1):
     import torch
     from .deploy import load_params, W2XYZ
     from .feeder import SampleReader
@@ -156,6 +173,19 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
         return_flow=FLOW in params.encoders, skip_silence_thr=None, shuffle=False, random_rotations=False,
         skip_rate=SKIP_RATE))                                              # feeder.py:373-396 (for_eval)
     ev = Evaluator(net, params, power_maps=power_maps)
+    # groups > 1 (round 6): `groups` consecutive FULL batches of the rank's shard per forward call (W2XYZ._grouped_model: the same
+    # device variables, grouped native contexts) - per-sample rows unchanged; a zero-padded partial batch and the shard's tail run singly
+    w2.groups = max(1, int(groups))
+    gnet = w2._grouped_model(w2.groups) if w2.groups > 1 else None
+    pending = []
+
+    def flush(force_single=False):
+        if pending and (force_single or len(pending) < w2.groups):
+            for q in pending:
+                ev.run_batch(*q)
+        elif pending:
+            ev.run_batches(pending, gnet)
+        del pending[:]
     for b in range(lo, hi):
         wins = plan[b * BATCH_SIZE:(b + 1) * BATCH_SIZE]
         samples = [readers.get(yid).sample_at(t) for yid, t in wins]
@@ -164,8 +194,17 @@ def evaluate(model_dir, db_dir, subset_fn=None, layouts_fn=None, variables=None,
                 return None
             x = np.stack([smp[k] for smp in samples], 0)
             return x if (k == 'video' and x.dtype == np.uint8) else x.astype(np.float32)
-        ev.run_batch([smp['id'] for smp in samples], stack('ambix'), stack('video'), stack('flow'),
-                     np.stack([layouts.get(yid, np.ones(4)) for yid, _ in wins], 0))
+        item = ([smp['id'] for smp in samples], stack('ambix'), stack('video'), stack('flow'),
+                np.stack([layouts.get(yid, np.ones(4)) for yid, _ in wins], 0))
+        full = len(samples) == BATCH_SIZE and (item[2] is None or item[2].dtype == np.uint8)
+        if gnet is None or not full:
+            flush(force_single=True)
+            ev.run_batch(*item)
+            continue
+        pending.append(item)
+        if len(pending) == w2.groups:
+            flush()
+    flush(force_single=True)
 
     # global means (np.mean over every sample, eval.py:223): ONE all-reduce of per-key sums (+ finite-only sums / counts) + sample count
     red = MetricReducer(METRIC_KEYS, device=net.device if world > 1 and torch.cuda.is_available() and
@@ -211,6 +250,8 @@ def main(argv=None):
     ap.add_argument('--subset_fn', default=None)
     ap.add_argument('--layouts_fn', default='meta/audio_layouts.txt')
     ap.add_argument('--overwrite', action='store_true')
+    ap.add_argument('--groups', type=int, default=1,
+                    help='batches of 16 windows per forward call (grouped launch: one launch per layer for all of them, own batch-norm statistics per batch; rows unchanged)')
     ap.add_argument('--partial_batch', choices=['drop', 'pad'], default='drop',
                     help="trailing windows that do not fill a batch of 16: 'drop' (the reference's queue never dequeues them) or 'pad' with zero windows")
     ap.add_argument('--power_maps', action='store_true',
@@ -218,7 +259,7 @@ def main(argv=None):
                          "reference's EMD metric, eval.py:188-191) and save this rank's maps to <model_dir>/eval-powermaps-rank<r>.npz")
     args = ap.parse_args(argv)
     means, count = evaluate(args.model_dir, args.db_dir, args.subset_fn, args.layouts_fn, overwrite=args.overwrite,
-                            partial_batch=args.partial_batch, power_maps=args.power_maps)
+                            partial_batch=args.partial_batch, power_maps=args.power_maps, groups=args.groups)
     if args.power_maps and evaluate.last_maps:
         maps = evaluate.last_maps                      # [pred, gt, pred, gt, ...] per batch, each [n, 7, 12]
         np.savez(os.path.join(args.model_dir, 'eval-powermaps-rank%d.npz' % int(os.environ.get('RANK', 0))),

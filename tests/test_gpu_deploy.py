@@ -217,6 +217,13 @@ def test_evaluate_is_identical_for_one_and_two_ranks(tmp_path):
         outs[world] = _run_eval_cli(root, str(model_dir), str(db), world, port)
     log1, rows1 = outs[1]
     log2, rows2 = outs[2]
+    # ... and with --groups 2 (round 6: two batches per grouped forward call, own batch-norm statistics each; the third batch runs singly)
+    model_dir = tmp_path / 'model_g'; model_dir.mkdir()
+    _write_model_dir(str(model_dir), P, enc)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    logg, rowsg = _run_eval_cli(root, str(model_dir), str(db), 1, port, extra=('--groups', '2'))
+    assert rowsg == rows1, 'grouped evaluation changed the per-sample rows'
+    assert [l for l in logg.splitlines() if l.startswith('EVAL | \t')] == [l for l in log1.splitlines() if l.startswith('EVAL | \t')]
     assert rows1 == rows2 and len(rows1.splitlines()) == 1 + 48
     means = lambda log: [l for l in log.splitlines() if l.startswith('EVAL | \t')]
     assert means(log1) == means(log2) and len(means(log1)) == 18
