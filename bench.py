@@ -562,11 +562,6 @@ def main():
             ps, _ = ctx_nets[j].evaluation_ps(ctx_outs[j], tgt.contiguous())
             eval_sums[j] += ps.double().sum(1).reshape(-1)
 
-    # experiment switch: the first call of a region on the SECOND context starts this many GPU clock ticks late (torch.cuda._sleep on its
-    # stream), so that the two contexts run out of phase - one in its matrix-bound convs while the other is in its HBM-bound plane passes
-    stagger = int(os.environ.get('BENCH_STAGGER_CYCLES', '0'))
-    stagger_due = [True]
-
     def step():
         i = counter[0]
         j = i % NF
@@ -576,9 +571,6 @@ def main():
             run_step(0, b, nets, outs)
         else:
             with torch.cuda.stream(streams[j]):
-                if stagger and j == 1 and stagger_due[0]:
-                    torch.cuda._sleep(stagger)
-                    stagger_due[0] = False
                 run_step(j, b, nets, outs)
         return j
 
@@ -646,15 +638,11 @@ def main():
         tail.inference_ops(*tail_in, out=tail_out)
 
     def region():                       # K steps: n_calls grouped calls rotating over the contexts in flight, then the remainder
-        stagger_due[0] = True
         for _ in range(n_calls):
             step()
         if tail is not None:
             with torch.cuda.stream(streams[0] if NF > 1 else torch.cuda.current_stream()):
                 tail.inference_ops(*tail_in, out=tail_out)
-    if os.environ.get('BENCH_FOLLOW') and NF >= 2:         # experiment switch: context j trails context j - 1 by one kernel (sagen_follow)
-        for j in range(1, NF):
-            nets[j].follow(BATCH, nets[j - 1])
     torch.cuda.synchronize()
     if args.pmc_child:                  # under rocprofv3 --pmc: a few forwards of the replayed plan on ONE context, nothing else
         for _ in range(3):
@@ -676,7 +664,6 @@ def main():
     counter[0] = 0
     barrier()
     torch.cuda.synchronize()
-    stagger_due[0] = True
     t0 = time.perf_counter()
     for i in range(n_calls):
         st = streams[counter[0] % NF] if NF > 1 else torch.cuda.current_stream()

@@ -161,11 +161,6 @@ int    sagen_profile_enable(sagen_ctx* ctx, int on);
  * application as two kernels so that the logits exist in the workspace ("separation/deconv1" of sagen_get_intermediate); 0 lets the
  * forward fold sigmoid + track mix into the deconvolution's epilogue (same result, 94 MB less HBM traffic per batch of 32). */
 int    sagen_set_option(sagen_ctx* ctx, const char* name, int value);
-/* Two contexts in flight, out of phase (round 6): after sagen_follow(ctx, leader) every launch k of ctx's forward waits (on the device,
- * hipStreamWaitEvent) for launch k of the forward `leader` enqueued most recently BEFORE it, so that ctx trails the leader by one kernel -
- * one of them in a matrix-bound convolution while the other is in an HBM-bound plane pass.  Timing only: results do not change.  The host
- * must enqueue leader's forward first, then ctx's.  leader = NULL ends it.  Both contexts must outlive the link. */
-int    sagen_follow(sagen_ctx* ctx, sagen_ctx* leader);
 /* Further switches: "fp16x2" (default 1: the ResNet trunk's convs - resnet.py:141-236 - run on two fp16 planes per operand, three matrix
  * products per multiply; 0: three bf16 planes, six products), "plane_gather", "u8_fast_stem", "planes_from_stage" (INTEGRATION.md 5).
  * sagen_counter reads a diagnostic counter of the context after synchronising `stream`: "fp16x2_saturations" = activation elements the

@@ -55,7 +55,6 @@ SIGNATURES = {
     'sagen_plan_describe': (C.c_int, [_P, C.c_char_p, _SZ]),
     'sagen_profile_enable': (C.c_int, [_P, _I]),
     'sagen_set_option': (C.c_int, [_P, C.c_char_p, _I]),
-    'sagen_follow': (C.c_int, [_P, _P]),
     'sagen_counter': (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64), _P]),
     'sagen_profile_report': (C.c_int, [_P, C.c_char_p, _SZ]),
     'sagen_stft_mag': (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),

@@ -23,7 +23,6 @@ int sagen_profile_report_impl(sagen_ctx* c, char* buf, size_t buflen);
 int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const float** data, int32_t* ndim, int64_t shape[4],
                                 int64_t* pixel_stride);
 int sagen_set_option_impl(sagen_ctx* c, const char* name, int value);
-int sagen_follow_impl(sagen_ctx* c, sagen_ctx* leader);
 int sagen_counter_impl(sagen_ctx* c, const char* name, uint64_t* value, hipStream_t s);
 size_t sagen_train_workspace_bytes_impl(sagen_ctx* c);
 int sagen_train_bind_impl(sagen_ctx* c, const sagen_tensor* grads, int n_grads, const sagen_tensor* moving, int n_moving, void* tws,
@@ -130,10 +129,6 @@ int sagen_get_intermediate(const sagen_ctx* ctx, const char* name, const float**
 int sagen_counter(sagen_ctx* ctx, const char* name, uint64_t* value, void* stream) {
     if (!ctx || !name || !value) return fail(SAGEN_ERR_NULL, "sagen_counter: null argument");
     return guarded([&] { return sagen_counter_impl(ctx, name, value, (hipStream_t)stream); });
-}
-int sagen_follow(sagen_ctx* ctx, sagen_ctx* leader) {
-    if (!ctx) return fail(SAGEN_ERR_NULL, "sagen_follow: null ctx");
-    return guarded([&] { return sagen_follow_impl(ctx, leader); });
 }
 int sagen_set_option(sagen_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return fail(SAGEN_ERR_NULL, "sagen_set_option: null argument");

@@ -102,11 +102,6 @@ struct sagen_ctx {
         }
         return gi;
     }
-    // sagen_follow (include/sagen.h): a leader records one event behind every launch of its forward; its follower's launch k waits for event k
-    bool record_steps = false;             // some context follows this one
-    sagen_ctx* leader = nullptr;
-    std::vector<hipEvent_t> step_events;   // (disable-timing events, grown on demand)
-    size_t steps_recorded = 0, steps_seen = 0;     // launches of this context's current forward / of the follower's
     // workspace
     size_t ws_floats = 0;
     float* ws = nullptr;
@@ -283,25 +278,10 @@ struct Fwd {
         return c->event_pool[c->events_used++];
     }
     // time one launch (or launch group) with a pair of events on the launch stream
-    // out-of-phase pair (sagen_follow): wait for the leader's launch of the same index, record this context's own
-    void follow_before() {
-        if (c->leader && !c->tuning && c->steps_seen < c->leader->steps_recorded)
-            (void)hipStreamWaitEvent(s, c->leader->step_events[c->steps_seen], 0);
-        ++c->steps_seen;
-    }
-    void follow_after() {
-        if (!c->record_steps || c->tuning) return;
-        if (c->steps_recorded == c->step_events.size()) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
-            c->step_events.push_back(e);
-        }
-        (void)hipEventRecord(c->step_events[c->steps_recorded++], s);
-    }
     template <class F>
     void timed(const char* kernel, double flops, F&& launch) {
         if (rc) return;
-        if (!c->profiling) { follow_before(); rc = launch(); follow_after(); return; }
+        if (!c->profiling) { rc = launch(); return; }
         ProfRec r;
         r.kernel = kernel; r.layer = layer; r.flops = flops;
         r.e0 = next_event(); r.e1 = next_event();

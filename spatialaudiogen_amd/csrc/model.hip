@@ -474,8 +474,6 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     const int B = c->B;
     c->events_used = 0;
     c->prof.clear();
-    c->steps_recorded = 0;
-    c->steps_seen = 0;
     // grouped context: every launch of this call carries the group dimension (common.h); the launchers read it from cur_group()
     struct GroupScope {
         GroupInfo saved;
@@ -811,15 +809,8 @@ int sagen_forward_u8_impl(sagen_ctx* c, const float* audio, const uint8_t* video
     c->video_u8 = false;
     return rc;
 }
-int sagen_follow_impl(sagen_ctx* c, sagen_ctx* leader) {
-    if (leader == c) return fail(SAGEN_ERR_UNSUPPORTED, "sagen_follow: a context cannot follow itself");
-    c->leader = leader;
-    if (leader) leader->record_steps = true;
-    return SAGEN_OK;
-}
 void sagen_destroy_impl(sagen_ctx* c) {
     if (!c) return;
-    for (hipEvent_t e : c->step_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->tune_e0) { (void)hipEventDestroy(c->tune_e0); (void)hipEventDestroy(c->tune_e1); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

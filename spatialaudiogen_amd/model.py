@@ -327,12 +327,6 @@ class SptAudioGen(object):
         """'fp16x2_saturations': activation elements the fp16x2 plane passes had to clamp since the weights were bound (expected: 0)."""
         return self.context_for(batch).counter(name)
 
-    def follow(self, batch, leader):
-        """Out-of-phase pair (sagen_follow): every launch of THIS net's forward at `batch` waits for the same launch of `leader`'s forward
-        enqueued just before it - the two contexts then trail each other by one kernel.  leader = None ends it."""
-        h = leader.context_for(batch).handle if leader is not None else None
-        check(_lib.lib().sagen_follow(self.context_for(batch).handle, h))
-
     def set_option(self, batch, name, value):
         """'materialize_mask' = 1: the next forwards keep the mask logits ('separation/deconv1') instead of folding the mask into the
         last deconvolution's epilogue."""

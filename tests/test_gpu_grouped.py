@@ -125,38 +125,3 @@ def test_grouped_contexts_refuse_what_they_cannot_run(T):
     none.load_variables(init_weights(none.variable_specs(), seed=1, mode='test'))
     with pytest.raises(SagenError, match='FREQ_MASK'):
         none.inference_ops(a)
-
-
-def test_a_following_context_computes_the_same_thing(T):
-    """sagen_follow (round 6): launch k of the follower's forward waits on the device for launch k of the leader's forward enqueued just
-    before it - the pair runs out of phase.  Timing only: both outputs are bit-identical to unlinked runs, on two streams, repeatedly,
-    with a leader call that has no follower call behind it, and after the link is cut."""
-    from spatialaudiogen_amd.model import SptAudioGen
-    enc, B, G = ['audio', 'video'], 3, 2
-    P = init_weights(variable_specs(enc), seed=14, mode='test')
-    inp = synth_inputs(2 * G * B, enc, seed=80)
-    a, v = T.as_tensor(inp['audio']).cuda(), _u8(T, inp['video']).cuda()
-    xa, xb = (a[:G * B], v[:G * B]), (a[G * B:], v[G * B:])
-    lead = SptAudioGen(1, encoders=enc, separation='unet_mask', groups=G)
-    foll = SptAudioGen(1, encoders=enc, separation='unet_mask', groups=G)
-    for n in (lead, foll):
-        n.load_variables(P)
-    want_a, want_b = lead.inference_ops(*xa).clone(), foll.inference_ops(*xb).clone()
-    foll.follow(B, lead)
-    s1, s2 = T.cuda.Stream(), T.cuda.Stream()
-    T.cuda.synchronize()
-    for _ in range(3):
-        with T.cuda.stream(s1):
-            ya = lead.inference_ops(*xa)
-        with T.cuda.stream(s2):
-            yb = foll.inference_ops(*xb)
-        with T.cuda.stream(s1):
-            ya2 = lead.inference_ops(*xa)              # a leader call with no follower call behind it
-        T.cuda.synchronize()
-        assert T.equal(ya, want_a) and T.equal(yb, want_b) and T.equal(ya2, want_a)
-    with T.cuda.stream(s2):                            # the follower alone, after the leader went on: waits on completed events only
-        yb = foll.inference_ops(*xb)
-    T.cuda.synchronize()
-    assert T.equal(yb, want_b)
-    foll.follow(B, None)
-    assert T.equal(foll.inference_ops(*xb), want_b)
