@@ -501,7 +501,7 @@ def main():
         eval_batches = list(range(lo_b, hi_b))
         eval_steps = min(args.steps, len(eval_batches)) if args.steps > 0 else len(eval_batches)
         # eval: consecutive batches of the shard per call, a divisor of the step count only (no remainder call: the metrics follow the batches)
-        G = args.group if args.group > 0 and eval_steps % args.group == 0 else max(g for g in range(1, 9) if eval_steps % g == 0)
+        G = args.group if args.group > 0 and eval_steps % args.group == 0 else max(g for g in range(1, MAX_AUTO_GROUP + 1) if eval_steps % g == 0)
     else:
         G = pick_group(args.steps, args.group)          # batches per grouped call
     CALLB = G * BATCH                                   # windows per forward call
@@ -656,7 +656,11 @@ def main():
     reduce_metric()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_calls)]
-    for _ in range((args.warmup + G - 1) // G):
+    # (grouped calls: W is rounded UP to whole calls, the same number on every context in flight - a context whose last call lies before the
+    #  metric reduction above starts the timed region cold: K = 20, same box: first region 3 092 - 3 110 with one warm-up call, 3 123 - 3 168
+    #  with one per context, 3 168 - 3 176 with two, against 3 155 - 3 185 for the regions behind it)
+    warm_calls = NF * ((max(args.warmup, 1) + G * NF - 1) // (G * NF))
+    for _ in range(warm_calls):
         step()
     torch.cuda.synchronize()
     for e in eval_sums:
@@ -866,7 +870,7 @@ def main():
                    'weights': 'random init (Xavier / BN identity), same replica on every rank',
                    'launch_plan': 'autotuned per layer (%d contractions)' % len(plan) if plan else 'shape heuristics',
                    'video_frames': frames_note if 'video' in dev_in else None,
-                   'batches_in_flight': NF * G, 'contexts_in_flight': NF, 'batches_per_grouped_launch': G,
+                   'batches_in_flight': NF * G, 'contexts_in_flight': NF, 'batches_per_grouped_launch': G, 'warmup_steps_run': warm_calls * G,
                    'grouped_launch': None if G == 1 else
                    ('every forward call carries %d INDEPENDENT batches of %d windows as one launch per layer (sagen_forward_grouped: the group is a grid '
                     'dimension; own batch-norm statistics / plane scales per batch, outputs bit-identical to one call per batch - '
