@@ -68,6 +68,7 @@ SUSTAINED_NOTE = ('achieved / 290 TFLOP/s = the fp32-equivalent rate a pure v_mf
 DEFAULT_GROUP = 0          # 0 = auto: the largest divisor of K (the steps of the timed region) up to MAX_AUTO_GROUP, see pick_group
 DEFAULT_IN_FLIGHT = 0      # 0 = auto: two contexts in flight with grouped launches, three with one batch per call (measured below)
 MAX_AUTO_GROUP = 10
+MAX_PAIRED_GROUP = 16      # (the native limit of sagen_create_grouped)
 
 
 def pick_group(steps, asked, cap=MAX_AUTO_GROUP):
@@ -79,7 +80,14 @@ def pick_group(steps, asked, cap=MAX_AUTO_GROUP):
     takes min(K, 10) and runs the remainder as one smaller call."""
     if asked > 0:
         return asked
-    best = max(g for g in range(1, cap + 1) if steps % g == 0) if steps > 0 else 1
+    if steps <= 0:
+        return 1
+    # two contexts in flight want an EVEN number of calls (an unpaired last call runs without a partner), and larger groups keep paying
+    # (K = 30, same box: 10 per call x 3 calls 3 133 - 3 150, 15 x 2 calls 3 279 - 3 286; K = 32: 16 x 2 3 251 - 3 272): up to 16 per call then
+    paired = [g for g in range(8, MAX_PAIRED_GROUP + 1) if steps % g == 0 and (steps // g) % 2 == 0]
+    if paired:
+        return max(paired)
+    best = max(g for g in range(1, cap + 1) if steps % g == 0)
     return best if best >= 4 or best == steps else max(1, min(cap, steps))
 
 

@@ -115,10 +115,13 @@ def test_bench_picks_a_group_size_that_divides_the_timed_steps():
     spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    assert b.pick_group(20, 0) == 10 and b.pick_group(30, 0) == 10 and b.pick_group(50, 0) == 10
-    assert b.pick_group(4, 0) == 4 and b.pick_group(2, 0) == 2 and b.pick_group(1, 0) == 1 and b.pick_group(3, 0) == 3
-    assert b.pick_group(14, 0) == 7 and b.pick_group(17, 0) == 10 and b.pick_group(22, 0) == 10      # 17 = 10 + 7, 22 = 2 x 10 + 2
-    assert b.pick_group(20, 3) == 3 and b.pick_group(300, 0) == 10 and b.pick_group(40, 0) == 10
+    # an even number of calls of 8 .. 16 batches where K allows it (two contexts in flight) ...
+    assert b.pick_group(20, 0) == 10 and b.pick_group(30, 0) == 15 and b.pick_group(32, 0) == 16 and b.pick_group(40, 0) == 10
+    assert b.pick_group(300, 0) == 15 and b.pick_group(24, 0) == 12 and b.pick_group(16, 0) == 8
+    # ... else the largest divisor up to 10, and a remainder call where K has none worth having
+    assert b.pick_group(50, 0) == 10 and b.pick_group(4, 0) == 4 and b.pick_group(2, 0) == 2 and b.pick_group(1, 0) == 1 and b.pick_group(3, 0) == 3
+    assert b.pick_group(14, 0) == 7 and b.pick_group(17, 0) == 10 and b.pick_group(22, 0) == 11 and b.pick_group(23, 0) == 10      # 17 = 10 + 7, 22 = 2 x 11, 23 = 2 x 10 + 3
+    assert b.pick_group(20, 3) == 3
     for k in range(1, 64):
         g = b.pick_group(k, 0)
-        assert 1 <= g <= min(k, 10)
+        assert 1 <= g <= min(k, 16)
