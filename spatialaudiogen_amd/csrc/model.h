@@ -43,6 +43,8 @@ static const int AENC_S[5][2] = {{4, 8}, {2, 4}, {2, 2}, {1, 1}, {1, 1}};
 
 using namespace sagen;
 
+constexpr int SAGEN_MAX_GROUPS = 32;      // batches per grouped launch (sagen_create_grouped)
+
 struct ProfRec {
     std::string kernel, layer;
     double flops = 0.0;

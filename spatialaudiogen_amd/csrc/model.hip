@@ -10,7 +10,7 @@ void sagen_destroy_impl(sagen_ctx* c);
 int sagen_groups_impl(const sagen_ctx* c) { return c->G; }
 int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups) {
     if (!out || !cfg) return fail(SAGEN_ERR_NULL, "sagen_create: null argument");
-    if (groups < 1 || groups > 16) return fail(SAGEN_ERR_SHAPE, "sagen_create_grouped: groups=%d (1..16)", groups);
+    if (groups < 1 || groups > SAGEN_MAX_GROUPS) return fail(SAGEN_ERR_SHAPE, "sagen_create_grouped: groups=%d (1..%d)", groups, SAGEN_MAX_GROUPS);
     if (groups > 1 && cfg->separation != SAGEN_SEP_FREQ_MASK)
         return fail(SAGEN_ERR_UNSUPPORTED, "sagen_create_grouped: the grouped launch covers the FREQ_MASK path only");
     if (cfg->batch <= 0) return fail(SAGEN_ERR_SHAPE, "sagen_create: batch=%d", cfg->batch);
@@ -923,7 +923,7 @@ int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
 int sagen_counter_impl(sagen_ctx* c, const char* name, uint64_t* value, hipStream_t s) {
     if (!c->ws) return fail(SAGEN_ERR_WORKSPACE, "no workspace bound");
     if (std::string(name) != "fp16x2_saturations") return fail(SAGEN_ERR_UNSUPPORTED, "sagen_counter: unknown counter %s", name);
-    unsigned v[16] = {0};                    // one counter per group
+    unsigned v[SAGEN_MAX_GROUPS] = {0};      // one counter per group
     for (int g = 0; g < c->G; ++g)
         SAGEN_HIP_CHECK(hipMemcpyAsync(&v[g], c->p("h2s") + (size_t)g * c->grp_floats + 7, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     SAGEN_HIP_CHECK(hipStreamSynchronize(s));
