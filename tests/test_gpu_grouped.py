@@ -33,7 +33,9 @@ def _u8(T, v):
     (['audio', 'video'], 5, 2, 'float'),
     (['audio', 'video', 'flow'], 2, 3, 'u8'),
     (['audio'], 10, 3, None),
-    (['audio', 'video'], 32, 3, 'u8'),            # BASELINE configs[1]'s batch, three of them per launch (what bench.py --group 3 runs)
+    (['audio', 'video'], 32, 3, 'u8'),            # BASELINE configs[1]'s batch, three of them per launch
+    (['audio', 'video'], 2, 16, 'u8'),            # many groups: what bench.py's auto mode reaches (10 - 16 per call) ...
+    (['audio'], 3, 32, None),                     # ... and the native limit
 ])
 def test_every_group_equals_the_single_batch_forward_bit_for_bit(T, enc, B, G, frames):
     from spatialaudiogen_amd.model import SptAudioGen
