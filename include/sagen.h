@@ -115,7 +115,7 @@ int    sagen_forward_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video
  * windows OF a batch (model.py:197, resnet.py:123: is_training=True), so a batch is the unit of work.  A grouped context runs
  * `groups` INDEPENDENT batches of cfg->batch windows as ONE launch per layer (the group is a grid dimension of every kernel): each
  * batch keeps its own batch-norm statistics, plane scales and maxima, and its output is bit-identical to what sagen_forward[_u8] of
- * an ungrouped context gives for that batch alone - the semantics per batch are untouched, the fixed cost of a launch is paid once
+ * an ungrouped context (running the same launch plan: sagen_plan_set / none) gives for that batch alone - the semantics per batch are untouched, the fixed cost of a launch is paid once
  * per `groups` batches.  sagen_create_grouped: as sagen_create; sagen_workspace_bytes then covers `groups` copies of the per-batch
  * region (the packed filters are shared).  sagen_forward_grouped[_u8]: audio [groups*B, snd_size], video / flow [groups*B,224,448,3],
  * ambi_yzx [groups*B, snd_dur, 3] - the batches back to back; `groups` must be the context's.  FREQ_MASK separation and the default

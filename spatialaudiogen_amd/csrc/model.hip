@@ -578,7 +578,8 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
         if (aud_planes && !c->tuning) {             // a plan that names a register-staged tile keeps the fp32 operand (no pack pass)
             auto it = c->plan.find(name);
             if (it != c->plan.end() ? !igemm_tile_p3((IgemmTile)it->second.tile)
-                                    : B * c->G < 128)      // untuned: the plane-fed kernel cannot split K - it needs the rows of a grouped call (or a large batch) to fill the chip
+                                    : B < 128)             // untuned: the plane-fed kernel cannot split K and needs many rows to fill the chip - decided by the
+                                                           // batch size alone, NOT by the groups, so that a grouped and an ungrouped context without a plan compute bit-identically
                 aud_planes = false;
         }
         if (aud_planes) {

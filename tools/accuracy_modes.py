@@ -29,6 +29,10 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
                 more = synth_inputs(4 * (G - 1), enc, seed=900 + seed)
                 inp = {k: np.concatenate([inp[k], more[k]], 0) for k in inp}
             out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow'))[:4]
+            if G > 1:         # the audio encoder's conv2 .. conv5 on planes: what a tuned grouped context runs (untuned, only from batch 128 on)
+                tid = SptAudioGen.tile_names().index('conv3g_kernel<128,128,64,64,2,true>')
+                for l in range(2, 6):
+                    net.plan_set(4, 'audio_encoder/conv%d' % l, tid, 1)
             if os.environ.get('ACC_DECODER_PLANES'):
                 net.set_option(4, 'decoder_planes', 1)
                 out = net.inference_ops(inp['audio'], inp.get('video'), inp.get('flow'))[:4]
