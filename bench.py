@@ -65,10 +65,10 @@ SUSTAINED_NOTE = ('achieved / 290 TFLOP/s = the fp32-equivalent rate a pure v_mf
                   'normally distributed operands (1.66-1.81 PFLOP/s bf16: profiles/r03_mfma_sustained.txt); `frac` above is against the data-sheet peak')
 
 
-DEFAULT_GROUP = 0          # 0 = auto: the largest divisor of K (the steps of the timed region) up to MAX_AUTO_GROUP, see pick_group
+DEFAULT_GROUP = 0          # 0 = auto: see pick_group (8 .. 16 batches per call in an even number of calls, else the largest divisor of K up to 10)
 DEFAULT_IN_FLIGHT = 0      # 0 = auto: two contexts in flight with grouped launches, three with one batch per call (measured below)
 MAX_AUTO_GROUP = 10
-MAX_PAIRED_GROUP = 16      # (the native limit of sagen_create_grouped)
+MAX_PAIRED_GROUP = 16      # (larger groups measured no further gain; the native limit of sagen_create_grouped is 32)
 
 
 def pick_group(steps, asked, cap=MAX_AUTO_GROUP):
@@ -76,8 +76,8 @@ def pick_group(steps, asked, cap=MAX_AUTO_GROUP):
     K = 20 | 30 steps): 1 x 3 contexts 2 631 / 2 685 | 2 667 / 2 700; 2 x 2: 2 720 / 2 790 | 2 786 / 2 823; 4 x 2: 2 839 / 2 908 | 2 861 / 2 950;
     5 x 2: 2 848 / 2 960 | 2 919 / 2 990; 5 x 3: 2 808 / 2 940 | 2 936 / 3 030; 6 x 2: - | 2 959 / 3 025; 10 x 2: 2 986 / 3 075 | 2 967 / 3 015;
     10 x 1: 2 881 / 2 920 | 2 907 / 2 935 - the fixed cost of a launch is paid once per group, and two grouped contexts still fill each
-    other's tails.  Auto: the largest divisor of K up to 10 (no remainder call in the timed region); a K without a divisor of at least 4
-    takes min(K, 10) and runs the remainder as one smaller call."""
+    other's tails.  Auto: the largest G in 8 .. 16 that splits K into an EVEN number of calls (below); else the largest divisor of K up to 10
+    (no remainder call in the timed region); a K without a divisor of at least 4 takes min(K, 10) and runs the remainder as one smaller call."""
     if asked > 0:
         return asked
     if steps <= 0:
