@@ -11,11 +11,17 @@ BENCH="python $R/bench.py --no-cpu-baseline --no-other-configs --config $CFG --p
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH --steps 20 --warmup 5 > $O/trace.log 2>&1
 if [ "$CFG" = train ]; then
   SAGEN_BWD_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- $BENCH --steps 20 --warmup 5 > $O/trace1.log 2>&1
+  PMC="$BENCH --steps 2 --warmup 1"
+else
+  # round 6 (grouped launches): a second trace with ONE context in flight (a launch's duration is then its own), and the counter passes on the
+  # SAME launch shapes - ten batches per call - so that bytes / duration and MFMA-busy / duration are statements about one launch
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- $BENCH --group 10 --in-flight 1 --steps 20 --warmup 5 > $O/trace1.log 2>&1
+  PMC="$BENCH --group 10 --in-flight 1 --steps 10 --warmup 1"
 fi
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $BENCH --steps 2 --warmup 1 > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $BENCH --steps 2 --warmup 1 > $O/write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- $BENCH --steps 2 --warmup 1 > $O/sq.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $O/sq2 -- $BENCH --steps 2 --warmup 1 > $O/sq2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $PMC > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $PMC > $O/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- $PMC > $O/sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $O/sq2 -- $PMC > $O/sq2.log 2>&1
 grep -h '"metric"' $O/trace.log | tail -1 > $O/bench_under_trace.json
 # digest on the box, ship only the summaries (raw traces exceed gpurun's copy-back limit)
 python $R/tools/summarize_profiles.py $TAG $R/gpurun_out/profiles_$TAG > $O/summary.txt 2>&1

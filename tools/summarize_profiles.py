@@ -27,7 +27,7 @@ with open(os.path.join(dst, tag + '_kernel_stats.csv'), 'w') as f:
 one = glob.glob(os.path.join(src, 'trace1', '*', '*_kernel_stats.csv'))
 if one:
     rows1 = [r for r in csv.DictReader(open(one[0])) if not r['Name'].startswith('Cijk_')]
-    with open(os.path.join(dst, tag + '_kernel_stats_one_stream.csv'), 'w') as f:
+    with open(os.path.join(dst, tag + ('_kernel_stats_one_stream.csv' if any(r['Name'].find('wgrad') >= 0 for r in rows1) else '_kernel_stats_one_context.csv')), 'w') as f:
         w = csv.writer(f)
         w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'pct', 'min_ns', 'max_ns'])
         for r in rows1[:45]:
@@ -88,6 +88,20 @@ json.dump(label, open(os.path.join(dst, 'pmc_traffic_train.json' if is_train els
 b = os.path.join(src, 'bench_under_trace.json')
 if os.path.exists(b):
     open(os.path.join(dst, tag + '_bench_under_rocprof.json'), 'w').write(open(b).read())
+# 4. (round 6, inference) per kernel of the one-context trace: duration of its own, HBM bytes per launch by the counters, GB/s against the 8 TB/s
+#    peak (6.3 achievable), matrix-pipe busy share = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) - the same launch shapes in all passes
+if one and not is_train:
+    dur = {short(r['Name']): (float(r['AverageNs']), int(r['Calls'])) for r in rows1}
+    with open(os.path.join(dst, tag + '_roofline_table.txt'), 'w') as f:
+        f.write('# one grouped context alone (10 batches per launch); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)\n')
+        f.write('%-46s %6s %10s %10s %9s %10s\n' % ('kernel', 'calls', 'avg us', 'MB/launch', 'GB/s', 'MFMA busy'))
+        for k, (ns, calls) in sorted(dur.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:28]:
+            v = keep.get(k) or {}
+            byts = (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0 if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v else None
+            busy = v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * v['SQ_BUSY_CU_CYCLES']) if v.get('SQ_BUSY_CU_CYCLES') else None
+            f.write('%-46s %6d %10.1f %10s %9s %10s\n' % (k[:46], calls, ns / 1e3, '%.1f' % (byts / 1e6) if byts else '-',
+                                                        '%.0f' % (byts / ns) if byts else '-', '%.0f %%' % (100 * busy) if busy is not None else '-'))
+    print(open(os.path.join(dst, tag + '_roofline_table.txt')).read())
 print(open(os.path.join(dst, tag + '_kernel_stats.csv')).read())
 for k, v in sorted(keep.items()):
     if 'igemm' in k or 'conv3' in k or 'p3_' in k or 'stem8' in k or 'wgrad' in k or 'bwd' in k:
