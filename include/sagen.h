@@ -120,7 +120,8 @@ int    sagen_forward_u8(sagen_ctx* ctx, const float* audio, const uint8_t* video
  * region (the packed filters are shared).  sagen_forward_grouped[_u8]: audio [groups*B, snd_size], video / flow [groups*B,224,448,3],
  * ambi_yzx [groups*B, snd_dur, 3] - the batches back to back; `groups` must be the context's.  FREQ_MASK separation and the default
  * arithmetic only (sagen_set_option values that leave it are refused at the next forward); sagen_forward[_u8] on a grouped context
- * (groups > 1) is an error, as is the training step.  sagen_get_intermediate returns group 0's tensors. */
+ * (groups > 1) is an error, as is the training step.  sagen_get_intermediate returns the tensors of group
+ * sagen_set_option(ctx, "intermediate_group", g) (default 0). */
 int    sagen_create_grouped(sagen_ctx** out, const sagen_config* cfg, int groups);
 int    sagen_forward_grouped(sagen_ctx* ctx, int groups, const float* audio, const float* video, const float* flow,
                              float* ambi_yzx, void* stream);

@@ -93,6 +93,7 @@ struct sagen_ctx {
     // [shared: packed filters, job tables][per-batch region of group 0][... of group 1] ...: `grp_off` floats of shared buffers, then
     // G copies of `grp_floats` floats; bufs / p() describe group 0, group g's copy of a per-batch buffer lies g * grp_floats further on
     int G = 1;
+    int inter_group = 0;                   // sagen_set_option("intermediate_group"): the group sagen_get_intermediate reads
     size_t grp_off = 0, grp_floats = 0;
     GroupInfo group_info() const {
         GroupInfo gi;

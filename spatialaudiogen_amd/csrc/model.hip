@@ -909,6 +909,11 @@ int sagen_variable_spec_impl(const sagen_ctx* c, int i, const char** name, int32
 int sagen_set_option_impl(sagen_ctx* c, const char* name, int value) {
     const std::string n = name;
     if (n == "materialize_mask") { c->materialize_mask = value != 0; return SAGEN_OK; }
+    if (n == "intermediate_group") {        // grouped contexts: which group's tensors sagen_get_intermediate returns (default 0)
+        if (value < 0 || value >= c->G) return fail(SAGEN_ERR_SHAPE, "intermediate_group=%d of %d groups", value, c->G);
+        c->inter_group = value;
+        return SAGEN_OK;
+    }
     if (n == "u8_fast_stem") { c->stem8 = value != 0; return SAGEN_OK; }
     if (n == "f16_fast_stem") { c->stem16 = value != 0; return SAGEN_OK; }
     if (n == "u8_stem_h2") { c->stem8h = value != 0; return SAGEN_OK; }
@@ -943,7 +948,7 @@ int sagen_get_intermediate_impl(const sagen_ctx* c, const char* name, const floa
     if (c->mask_fused_last && std::string(name) == "separation/deconv1")
         return fail(SAGEN_ERR_UNSUPPORTED, "separation/deconv1: the last forward fused the mask into the deconvolution's epilogue - "
                     "sagen_set_option(ctx, \"materialize_mask\", 1) keeps the logits");
-    *data = c->ws + nm.buf.off + nm.extra_off;
+    *data = c->ws + nm.buf.off + nm.extra_off + (size_t)c->inter_group * c->grp_floats;
     *ndim = nm.ndim;
     for (int k = 0; k < 4; ++k) shape[k] = nm.shape[k];
     *pixel_stride = nm.pixel_stride;

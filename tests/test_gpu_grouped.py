@@ -66,6 +66,13 @@ def test_every_group_equals_the_single_batch_forward_bit_for_bit(T, enc, B, G, f
     grp.inference_ops(T.flip(a, [0]), None if v is None else T.flip(v, [0]), None if f is None else T.flip(f, [0]))
     assert T.equal(grp.inference_ops(a, v, f), want)
     assert grp.counter(B, 'fp16x2_saturations') == 0
+    if B <= 5 and G <= 3:                        # the groups' intermediates too (sagen_set_option "intermediate_group")
+        for g in range(G):
+            one.inference_ops(sl(a, g), sl(v, g), sl(f, g))
+            grp.set_option(B, 'intermediate_group', g)
+            for name in ['bottleneck', 'audio_encoder/conv5'] + (['video_encoder/conv5_2'] if v is not None else []):
+                assert T.equal(grp.intermediate(B, name), one.intermediate(B, name)), (g, name)
+        grp.set_option(B, 'intermediate_group', 0)
     if B <= 5:                                   # against the oracle too (group 1: neither the first nor the default slot)
         k = {'audio': inp['audio'][B:2 * B]}
         if v is not None:
