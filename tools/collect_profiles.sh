@@ -6,7 +6,7 @@ CFG=${2:-av}          # bench configuration: av (headline) | train | ...
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 # tune once OUTSIDE the profiler, then replay the saved plan so the traces hold steady-state launches only
-python $R/bench.py --no-cpu-baseline --no-other-configs --config $CFG --steps 2 --warmup 1 --plan-file $O/plan.json > $O/tune.log 2>&1
+python $R/bench.py --no-cpu-baseline --no-other-configs --no-extra-legs --no-repeats --no-pmc --config $CFG --steps 20 --warmup 5 --plan-file $O/plan.json > $O/tune.log 2>&1      # (tuned on the launch shapes the passes below replay: 20 steps = ten batches per call)
 BENCH="python $R/bench.py --no-cpu-baseline --no-other-configs --config $CFG --plan-file $O/plan.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH --steps 20 --warmup 5 > $O/trace.log 2>&1
 if [ "$CFG" = train ]; then
