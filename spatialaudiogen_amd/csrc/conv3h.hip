@@ -489,6 +489,7 @@ int conv3h_dispatch(const IgemmDesc& d_in, IgemmTile tile, hipStream_t s) {
         case TILE_P3HR_256x64: return launch_conv3h<256, 64, 64, 64, 1, 3>(d, s);
         case TILE_P3HR_128x64: return launch_conv3h<128, 64, 64, 32, 1, 3>(d, s);
         case TILE_P3HR_64x64_C2: return launch_conv3h<64, 64, 32, 32, 2, 3>(d, s);
+        case TILE_P3HR_128x128: return launch_conv3h<128, 128, 64, 64, 1, 3>(d, s);
         default: return fail(SAGEN_ERR_UNSUPPORTED, "conv3h: bad tile id %d", (int)tile);
     }
 }

@@ -341,6 +341,7 @@ static const TileCfg kTiles[TILE_AUTO] = {
     {128, 128, 16, "conv3g_kernel<128,128,64,64,2,true,1>", true, false, false, true, true, true}, {128, 256, 16, "conv3g_kernel<128,256,64,128,2,true,1>", true, false, false, true, true, true},
     {256, 64, 16, "conv3hr_kernel<256,64,64,64,1>", true, true, false, true, false, true}, {128, 64, 16, "conv3hr_kernel<128,64,64,32,1>", true, true, false, true, false, true},
     {64, 64, 32, "conv3hr_kernel<64,64,32,32,2>", true, true, false, true, false, true},
+    {128, 128, 16, "conv3hr_kernel<128,128,64,64,1>", true, true, false, true, false, true},
 };
 // igemm3s2_kernel: the 7x(7->8)x4 stride-2 stem over a pre-padded dense image
 static bool s2_ok(const IgemmDesc& d) {
@@ -359,7 +360,7 @@ bool igemm_tile_split(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t]
 bool igemm_tile_p3(IgemmTile t) { return t >= 0 && t < TILE_AUTO && kTiles[t].p3; }
 // conv3h_kernel tiles can split K by the filter row (dh-split, split-K = 3 exactly); the three-deep-ring variant cannot
 bool igemm_tile_dh_split(IgemmTile t) {
-    return t >= 0 && t < TILE_AUTO && kTiles[t].p3 && kTiles[t].h && !kTiles[t].g && t != TILE_P3HR_256x64 && t != TILE_P3HR_128x64 && t != TILE_P3HR_64x64_C2;
+    return t >= 0 && t < TILE_AUTO && kTiles[t].p3 && kTiles[t].h && !kTiles[t].g && t != TILE_P3HR_256x64 && t != TILE_P3HR_128x64 && t != TILE_P3HR_64x64_C2 && t != TILE_P3HR_128x128;
 }
 bool igemm_p3_eligible(const IgemmDesc& d) { return dw3_ok(d) && d.w_split && d.dsh * d.dsw == 1 && d.Cin <= MAX_BN_C; }
 static int tile_bm(IgemmTile t) { return (t >= 0 && t < TILE_AUTO) ? kTiles[t].bm : 0; }

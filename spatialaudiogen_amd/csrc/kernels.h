@@ -147,6 +147,7 @@ enum IgemmTile {
     TILE_P3GH_MM_64x128_K2, TILE_P3GH_MM_64x128_K4, TILE_P3GH_MM_128x128_K2, TILE_P3GH_MM_128x256_K2,
     // conv3hr_kernel: conv3h_kernel with a three-deep ring of activation images beside the two filter stages (conv3h.hip)
     TILE_P3HR_256x64, TILE_P3HR_128x64, TILE_P3HR_64x64_C2,
+    TILE_P3HR_128x128,         // (round 6: the 128x128 tile with the three-deep activation ring - 72 KB of LDS, two workgroups per CU)
     TILE_AUTO
 };
 

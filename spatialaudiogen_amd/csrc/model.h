@@ -394,7 +394,7 @@ struct Fwd {
             static const bool p3hr = getenv("SAGEN_P3HR") != nullptr;
             // (round 6: with ten batches per launch the wait for the activation images is no longer hidden - tools/trace_conv3h.py: 500 - 1 400 of a
             //  2 000 - 3 000-cycle group - and the deeper ring measures 0 - 2 % ahead on the headline, same box: a candidate of grouped contexts)
-            if (!p3hr && c->G == 1 && (tile == TILE_P3HR_256x64 || tile == TILE_P3HR_128x64 || tile == TILE_P3HR_64x64_C2)) continue;
+            if (!p3hr && c->G == 1 && (tile == TILE_P3HR_256x64 || tile == TILE_P3HR_128x64 || tile == TILE_P3HR_64x64_C2 || tile == TILE_P3HR_128x128)) continue;
             const int nk = d.Kpad / igemm_tile_bk(tile);
             if (bn > 32 && bn >= 2 * d.N) continue;                     // mostly-empty N tile
             if (bm > 32 && bm >= 4 * d.M) continue;
