@@ -525,6 +525,11 @@ def main():
     for n in nets:
         n.load_variables(P)
     net = nets[0]
+    if G > 1 and BATCH < 16 and not os.environ.get('BENCH_NO_SMALL_BATCH_DECODER_PLANES'):
+        # the scatter-form decoder contracts fp16x2 planes from batch 16 on (a single batch of 10 does not pay for the four pack launches:
+        # DESIGN.md 3.2); inside a grouped call the packs are amortised over the groups, so the small-batch configuration takes the planes too
+        for n in nets:
+            n.set_option(BATCH, 'decoder_planes', 1)
     streams = []                        # created after the contexts (below): ROCm maps HIP streams to hardware queues in creation order
     dev_in = {k: torch.as_tensor(v).cuda() for k, v in inp.items()}
     if is_eval:     # window w of the global order uses pool entry w % POOL: the pool twice in a row makes any run of <= POOL windows one slice
