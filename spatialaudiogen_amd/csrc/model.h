@@ -93,6 +93,7 @@ struct sagen_ctx {
     // [shared: packed filters, job tables][per-batch region of group 0][... of group 1] ...: `grp_off` floats of shared buffers, then
     // G copies of `grp_floats` floats; bufs / p() describe group 0, group g's copy of a per-batch buffer lies g * grp_floats further on
     int G = 1;
+    int tune_groups = 0;                   // groups a tuning pass launches per candidate (SAGEN_TUNE_GROUPS; 0 = all, the default: same box, 15 per call: tuned on all 3 153 - 3 160 ambisonic-s/s in a 14 s process, on 4 groups 3 122 - 3 136 in 10 s, on 2 3 063 - 3 073)
     int inter_group = 0;                   // sagen_set_option("intermediate_group"): the group sagen_get_intermediate reads
     size_t grp_off = 0, grp_floats = 0;
     GroupInfo group_info() const {
@@ -375,6 +376,14 @@ struct Fwd {
     // over all candidates, then a playoff of the three fastest (8 interleaved runs each, median) - single timings of
     // ~10 us launches are too noisy to separate close candidates
     Choice tune(const IgemmDesc& d, int rep, bool allow_split) {
+        // grouped contexts: with SAGEN_TUNE_GROUPS=n the candidates are timed on the first n groups only (the launchers read the group
+        // count from cur_group()) - a shorter tuning pass; the default times the launches the forward will run (the choice between
+        // tiles does depend on the group count: see sagen_ctx::tune_groups)
+        struct FewerGroups {
+            GroupInfo& g; int saved;
+            explicit FewerGroups(int n) : g(cur_group()), saved(g.G) { if (n > 0 && g.G > n) g.G = n; }
+            ~FewerGroups() { g.G = saved; }
+        } fewer(c->tune_groups);
         Choice top[3];
         for (auto& t : top) { t = heuristic(d, rep, allow_split); t.us = 1e30f; }
         const bool dense = dense_out(d);

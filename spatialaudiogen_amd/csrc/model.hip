@@ -52,6 +52,7 @@ int sagen_create_impl(sagen_ctx** out, const sagen_config* cfg, int groups) {
     c->sk_fused = getenv("SAGEN_SK_FUSED") != nullptr;
     c->no_dh_split = getenv("SAGEN_NO_DH_SPLIT") != nullptr;
     c->no_aud_planes = getenv("SAGEN_NO_AUDIO_PLANES") != nullptr;
+    if (const char* e = getenv("SAGEN_TUNE_GROUPS")) c->tune_groups = atoi(e);
     c->no_scatter = getenv("SAGEN_NO_DECONV_SCATTER") != nullptr;
     c->train_bands = getenv("SAGEN_TRAIN_NO_BANDS") == nullptr;
     c->train_rawpool = getenv("SAGEN_TRAIN_NO_RAWPOOL") == nullptr;
