@@ -524,8 +524,11 @@ int sagen_forward_impl(sagen_ctx* c, const float* audio, const float* video, con
     // ... and deconv5 .. deconv2 (scatter form) on planes of the band of cat_(l+1) they contract, the same way
     const bool no_decp = c->dec_planes_min_batch > (1 << 29);
     // (from 16 windows on: at deploy.py's batch of 10 the four pack launches cost what the plane-fed GEMMs save - 6 450 against 6 630 ambisonic-s/s)
-    const bool dec_planes = !no_decp && c->B >= c->dec_planes_min_batch && !c->sk_fused && c->freq_mask && !c->train_mode && !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 &&
-                            !c->no_scatter;
+    // (the training step's forward too, on its live bands - its backward reads the fp32 concat buffers the gather passes write either way;
+    //  SAGEN_TRAIN_NO_DEC_PLANES=1: the register-staged kernels on fp32 operands, as up to round 5)
+    static const bool train_no_decp = getenv("SAGEN_TRAIN_NO_DEC_PLANES") != nullptr;
+    const bool dec_planes = !no_decp && c->B >= c->dec_planes_min_batch && !c->sk_fused && c->freq_mask && !(c->train_mode && (train_no_decp || !c->train_bands)) &&
+                            !c->fp32_only && f.h2() && c->bufs.count("catp") != 0 && !c->no_scatter;
     const bool want_amax = d1_planes || dec_planes;
     // (the words are cleared by the STFT launch below - the first kernel of the stream that carries the audio chain - not by a fill)
 

@@ -126,9 +126,14 @@ class AdamBuckets(object):
             w.wait()
         self._pending = []
 
-    def apply(self):
+    def apply(self, events=None, opt_stream=None):
         """One optimiser step on every bucket: lr from the staircase schedule at the current global step, gradients averaged
-        over the ranks (the all-reduce summed them)."""
+        over the ranks (the all-reduce summed them).
+        events + opt_stream (one rank): bucket b is updated on `opt_stream` behind events[b] - which the native step records once
+        the bucket's last gradient AND every reader of its variables in this step's backward have been enqueued (a variable is read
+        by the backward of its own layer only, and the milestones are flushed at block ends: train_model.hip ms_flush) - last bucket
+        first, i.e. under the rest of the still running backward instead of behind it; the caller's stream joins `opt_stream`.
+        The update is elementwise: the result does not depend on where it runs."""
         import torch
         import torch.distributed as dist
         from . import _lib
@@ -138,13 +143,21 @@ class AdamBuckets(object):
         lr = learning_rate(self.step, self.lr, self.lr_iters, self.lr_decay)
         self.step += 1
         lr_t = adam_lr_t(self.step, lr)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.params and self.params[0].is_cuda else None
-        for p, g, m, v in zip(self.params, self.grads, self.m, self.v):
+        early = events is not None and opt_stream is not None
+        on = opt_stream if early else torch.cuda.current_stream()
+        stream = C.c_void_p(on.cuda_stream) if self.params and self.params[0].is_cuda else None
+        order = reversed(range(len(self.params))) if early else range(len(self.params))
+        for b in order:
+            p, g, m, v = self.params[b], self.grads[b], self.m[b], self.v[b]
             if not p.is_cuda:
                 raise RuntimeError('AdamBuckets.apply needs device buckets: the optimiser kernel has no CPU implementation')
+            if early:
+                opt_stream.wait_event(events[b])
             check(_lib.lib().sagen_adam_update(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                                C.c_void_p(v.data_ptr()), p.numel(), lr_t, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON,
                                                1.0 / world, stream))
+        if early:
+            torch.cuda.current_stream().wait_stream(opt_stream)
         return lr
 
 
@@ -192,16 +205,24 @@ class Trainer(object):
     The parameters live in `self.opt.params` (flat buckets); the native context is bound to views of them, so the fused Adam
     update is visible to the next step without a copy (the step re-packs the filters, as the variables changed)."""
 
-    def __init__(self, net, batch, lr=1e-4, lr_iters=10000, lr_decay=1.0, bucket_bytes=None, variables=None, overlap=None):
+    def __init__(self, net, batch, lr=1e-4, lr_iters=10000, lr_decay=1.0, bucket_bytes=None, variables=None, overlap=None, early_adam=None):
         """overlap: start each gradient bucket's all-reduce as soon as the backward has produced it (None: when there is more than
-        one rank; SAGEN_NO_OVERLAP=1 forces the exchange after the backward).  bucket_bytes (None): 64 MiB on one rank (three Adam
-        launches), 16 MiB with several: ten buckets, of which nine (108 of 123 MB) are complete 2.2 ms before the backward ends
-        (tools/bucket_events.py) - the first bucket holds the stem and completes last whatever its size."""
+        one rank; SAGEN_NO_OVERLAP=1 forces the exchange after the backward).  early_adam (round 6, one rank; None: only with
+        SAGEN_EARLY_ADAM=1): update each bucket on a second stream as soon as the backward is done with it (AdamBuckets.apply)
+        instead of three launches (145 us of a 6.1 ms step) behind it.  OPT-IN, a recorded negative result: same box, alternating,
+        548 - 550 ambisonic-s/s trained without it, 546 - 549 with it - the updates take from the backward's kernels the bandwidth
+        they no longer use at the end (tools/ab_train_env.sh, tools/train_timeline.sh).
+        bucket_bytes (None): 64 MiB on one rank (three Adam launches); 16 MiB with several ranks or early_adam - ten buckets, of
+        which nine (108 of 123 MB) are complete 2.2 ms before the backward ends (tools/bucket_events.py; the first bucket holds the
+        stem and completes last whatever its size)."""
         import torch
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if early_adam is None:
+            early_adam = not multi and bool(os.environ.get('SAGEN_EARLY_ADAM'))
+        self.early_adam = bool(early_adam) and not multi
         if bucket_bytes is None:
-            bucket_bytes = (16 << 20) if multi else (64 << 20)
+            bucket_bytes = (16 << 20) if (multi or self.early_adam) else (64 << 20)
         from . import _lib
         from ._lib import check, SagenTensor
         from .model import _Ctx
@@ -250,7 +271,7 @@ class Trainer(object):
         if overlap is None:
             overlap = multi and not os.environ.get('SAGEN_NO_OVERLAP')
         self.bucket_events, self.comm_stream = None, None
-        if overlap:
+        if overlap or self.early_adam:
             self._enable_overlap()
 
     def _enable_overlap(self, timing=False):
@@ -313,6 +334,8 @@ class Trainer(object):
             t_begin.record(torch.cuda.current_stream(self.device))
             self.comm_stream.wait_event(t_begin)
         loss = self.forward_backward(audio, video, flow, target, mask)
+        if self.early_adam and self.bucket_events is not None:       # one rank: nothing to exchange, the optimiser follows the milestones
+            return loss, self.opt.apply(self.bucket_events, self.comm_stream)
         if self.bucket_events is not None:
             self.opt.all_reduce_after(self.bucket_events, self.comm_stream, timing)      # under the rest of the (still running) backward
             if timing is not None:                                # the optimiser (current stream) consumes what the exchange produced

@@ -245,8 +245,9 @@ RELU_DISAGREE_BAR = 1e-4
 FREE_RUNNING_BAR = 3e-2           # measured: audio+video B = 4: median 8e-3, max 1.1e-2 (= sqrt of 7e-5 .. 1.2e-4 switched elements)
 
 
-@pytest.mark.parametrize('encoders,B,seed', [(('audio',), 2, 3), (('audio', 'video'), 4, 0), (('audio', 'video', 'flow'), 2, 1)])
-def test_every_variable_gradient_matches_fp64_autograd(T, encoders, B, seed):
+@pytest.mark.parametrize('encoders,B,seed,dec_planes', [(('audio',), 2, 3, 0), (('audio', 'video'), 4, 0, 0), (('audio', 'video', 'flow'), 2, 1, 0),
+                                                        (('audio',), 3, 4, 1), (('audio', 'video'), 2, 5, 1)])
+def test_every_variable_gradient_matches_fp64_autograd(T, encoders, B, seed, dec_planes):
     """dL/dvariable for every trainable variable (88 for audio+video, 146 with flow) vs fp64 autograd of the independent torch-CPU
     graph, evaluated with the device's ReLU switching pattern in the trunk (TorchRef.relu_masks says why).  Bar: relative RMS
     error <= 1e-4 per variable (measured: median 1e-5, max 3.6e-5 for audio+video at B = 4; 1e-6 for audio only), median <= 3e-5; the loss to 1e-4; the two tensors of the decoder adjoint to 1e-4."""
@@ -255,6 +256,8 @@ def test_every_variable_gradient_matches_fp64_autograd(T, encoders, B, seed):
     mask = np.ones((B, 4), np.float32)
     mask[0, 2] = 0.0                                              # a WXY-only clip: no Z target (feeder.py:312-314)
     tr = Trainer(net, batch=B)
+    if dec_planes:        # round 6: the training forward's deconv5 .. deconv2 contract fp16x2 planes of their concat bands, as inference does from 16
+        tr.ctx.set_option('decoder_planes', 1)       # windows on (the step at B = 32 takes this path by itself); the backward reads the same fp32 buffers
     loss = tr.forward_backward(inp['audio'], inp.get('video'), inp.get('flow'), target, mask, update_moving=False)
     T.cuda.synchronize()
     dev_masks = _device_relu_masks(tr, net, list(encoders), B)

@@ -107,6 +107,29 @@ def test_gradient_bucket_events_fire_under_the_backward(T):
         assert T.equal(g, r)
 
 
+def test_early_adam_on_a_second_stream_is_bit_identical(T):
+    """Round 6 (opt-in, Trainer(early_adam=True) / SAGEN_EARLY_ADAM=1): on one rank each 16 MiB bucket is updated on a second stream
+    as soon as the native step's milestone says the backward is done with it (AdamBuckets.apply(events, stream)), instead of three
+    launches behind the backward.  Elementwise update, ordered by events: variables and Adam slots must equal those of the sequential
+    optimiser bit for bit, step after step."""
+    from spatialaudiogen_amd.train import synthetic_batches
+    enc, B = ['audio', 'video'], 4
+    tr_e, _ = _trainer(T, enc, B, lr=2e-4, early_adam=True)
+    tr_l, _ = _trainer(T, enc, B, lr=2e-4)
+    assert tr_e.early_adam and tr_e.bucket_events is not None and len(tr_e.opt.params) >= 6
+    assert not tr_l.early_adam and tr_l.bucket_events is None and len(tr_l.opt.params) <= 3
+    it = synthetic_batches(enc, B, seed=11, pool=2)
+    for _ in range(4):
+        a, v, f, t, m = next(it)
+        le, lre = tr_e.step(a, v, f, t, m)
+        ll, lrl = tr_l.step(a, v, f, t, m)
+        assert abs(float(le) - float(ll)) <= 1e-12 * abs(float(ll)) and lre == lrl       # (the loss is an fp64 sum by atomics: its last bit depends on their order)
+    T.cuda.synchronize()
+    for which in ('params', 'm', 'v'):
+        for k in tr_e.opt.layout:
+            assert T.equal(tr_e.opt.view(which, k), tr_l.opt.view(which, k)), (which, k)
+
+
 def test_nan_guard_stops_the_loop_and_still_saves(T, tmp_path):
     from spatialaudiogen_amd.train import synthetic_batches, train_loop
 

@@ -37,3 +37,14 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print('train step: host enqueue %.3f ms per call, GPU-complete %.3f ms per call' % ((t1 - t0) / N * 1e3, (t2 - t0) / N * 1e3))
+# from an idle queue: how far ahead of the GPU does the host get within ONE step?
+hs, gs = [], []
+for _ in range(8):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.step(a, v, None, tgt)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    hs.append((t1 - t0) * 1e3); gs.append((t2 - t0) * 1e3)
+print('train step from an idle queue: host returns after %.3f ms (median), GPU done after %.3f ms' % (sorted(hs)[4], sorted(gs)[4]))
