@@ -32,7 +32,12 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 // per-channel partials, part[block][NV][C]; partials_finish_kernel then adds the rows in a fixed order in fp64 (deterministic,
 // and no same-address atomic chains: 4096 workgroups x 128 fp64 atomics on 128 addresses took 300 us per batch-norm layer).
 // Requires 256 % C4 == 0 (thread t owns channels 4*(t % C4)).
-constexpr int RED_MAX_BLOCKS = 512;
+constexpr int RED_MAX_BLOCKS = 1024;              // capacity of the partial rows (scratch, t:mxpart); the launches use red_blocks() of them
+// (SAGEN_RED_BLOCKS: A/B of the reductions' parallelism - 512 workgroups = two per CU)
+static int red_blocks() {
+    static const int n = getenv("SAGEN_RED_BLOCKS") ? std::min(RED_MAX_BLOCKS, std::max(64, atoi(getenv("SAGEN_RED_BLOCKS")))) : 512;
+    return n;
+}
 template <int NV>
 __device__ __forceinline__ void channel_partials(const float4 (&v)[NV], int C4, float* part) {
     __shared__ float4 red[NV][256];
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void partials_finish_kernel(const float* __res
 }
 
 static int reduce_grid(long n4, int C4) {
-    long g = std::min<long>(cdiv(n4, 256 * 8), RED_MAX_BLOCKS);
+    long g = std::min<long>(cdiv(n4, 256 * 8), red_blocks());
     g = std::max<long>(g, 1);
     if ((g * 256) % C4) {
         long a = 256, b = C4;

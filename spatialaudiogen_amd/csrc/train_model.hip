@@ -135,7 +135,7 @@ static void train_carve(sagen_ctx* c) {
         if (h2d_on(c)) {                   // dy of a stride-1 3x3 conv as fp16x2 planes (largest: stage 2) + the reduce pass's per-workgroup maxima
             // (double-buffered over the block parity like the fp32 dy: the weight gradients on the second stream read them too)
             for (const char* nm : {"t:DPc0", "t:DPc1", "t:DPd0", "t:DPd1"}) c->talloc(nm + x, p3h_bytes(B, 56, 112, 64) / sizeof(float));
-            c->talloc("t:mxpart" + x, 2 * 512);
+            c->talloc("t:mxpart" + x, 2 * 1024);
         }
         if (h2w_on(c)) {                   // retained activation planes: the input of every stride-1 3x3 conv (model.h: resnet_train)
             for (int k = 0; k < 8; ++k) {
