@@ -649,8 +649,7 @@ int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, co
 
 // x0 = maxpool(relu(bn0(y0))): gradient at y0 and at gamma / beta from the gradient at x0 (ga + gb), dz0 never materialised
 int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dy0, int B,
-                          int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s, const float* pooled_raw,
-                          int apply_b0, int apply_nb) {
+                          int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s, const float* pooled_raw) {
     if (int rc = maxpool_bwd_check(y0, bn, pooled, ga, dy0, C)) return rc;
     if (!acc || !scratch) return fail(SAGEN_ERR_NULL, "maxpool_bn_bwd: null accumulator / scratch");
     if (256 % (C / 4)) return fail(SAGEN_ERR_UNSUPPORTED, "maxpool_bn_bwd: C=%d must be 4 * a divisor of 256", C);
@@ -661,11 +660,6 @@ int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled,
     // (gather-heavy: more, shorter workgroups than the streaming reductions; rows of 2C floats)
     static const int gmax = getenv("SAGEN_POOLBWD_GRID") ? atoi(getenv("SAGEN_POOLBWD_GRID")) : 2048;
     int grid = (int)std::max<long>(1, std::min<long>(cdiv(total, 256 * 4), gmax));
-    // apply_nb > 0: ONLY the second pass, over batch elements [apply_b0, apply_b0 + apply_nb) (the sums are in `acc`: a call with
-    // apply_nb < 0 ran the first pass alone) - the caller pipelines the halves of the batch against the stem's weight gradient
-    const bool sums = apply_nb <= 0, apply = apply_nb >= 0;
-    if (apply_nb > 0 && (apply_b0 < 0 || apply_b0 + apply_nb > B)) return fail(SAGEN_ERR_SHAPE, "maxpool_bn_bwd: batch range out of bounds");
-    if (sums) {
     if (pooled_raw) {                                  // the sums over the pooled grid (the forward kept each window's raw extremum)
         const long ptotal = (long)B * Ho * Wo * (C / 4);
         grid = reduce_grid(ptotal, C / 4);
@@ -678,12 +672,8 @@ int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled,
     SAGEN_LAUNCH_CHECK();
     hipLaunchKernelGGL(partials_finish_kernel, dim3(cdiv(2 * C, 8)), dim3(256), 0, s, scratch, grid, 2 * C, acc, (float*)nullptr);
     SAGEN_LAUNCH_CHECK();
-    }
-    if (!apply) return SAGEN_OK;
-    const int b0 = apply_nb > 0 ? apply_b0 : 0, nb = apply_nb > 0 ? apply_nb : B;
-    const long off = (long)b0 * H * W * C, poff = (long)b0 * Ho * Wo * C, ntot = (long)nb * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3(aligned_grid(ntot, C / 4)), dim3(256), 0, s, (const float4*)(y0 + off), bn, (const float4*)(pooled + poff),
-                       (const float4*)(ga + poff), (const float4*)(gb ? gb + poff : nullptr), (float4*)(dy0 + off), nb, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, (float*)nullptr,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3(aligned_grid(total, C / 4)), dim3(256), 0, s, (const float4*)y0, bn, (const float4*)pooled,
+                       (const float4*)ga, (const float4*)gb, (float4*)dy0, B, H, W, C / 4, Ho, Wo, pth / 2, ptw / 2, (float*)nullptr,
                        (const double*)acc, dgamma, dbeta);
     SAGEN_LAUNCH_CHECK();
     return SAGEN_OK;

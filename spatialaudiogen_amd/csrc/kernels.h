@@ -423,8 +423,7 @@ int maxpool_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, co
 // acc: fp64 [2][C] (overwritten), scratch >= reduce_scratch_floats(1024) floats (4096 partial rows of 2C, C <= 128)
 int maxpool_bn_bwd_launch(const float* y0, const BnRef& bn, const float* pooled, const float* ga, const float* gb, float* dy0, int B,
                           int H, int W, int C, double* acc, float* scratch, float* dgamma, float* dbeta, hipStream_t s,
-                          const float* pooled_raw = nullptr,       // pooled_raw: each window's raw extremum (stem8rawpool_launch) - the sums then run over the pooled grid
-                          int apply_b0 = 0, int apply_nb = 0);     // apply_nb < 0: the sums only; > 0: only the second pass, over batch elements [b0, b0 + nb)
+                          const float* pooled_raw = nullptr);      // pooled_raw: each window's raw extremum (stem8rawpool_launch) - the sums then run over the pooled grid
 // out[m][c] = sum_{r < rep} (ina[(m*rep + r)*lda + c] + inb[(m*rep + r)*ldb + c]); inb nullable (backward of tf.tile / concat fan-in)
 int sum_rows_launch(const float* ina, int lda, const float* inb, int ldb, int rep, long M, int C, float* out, int ldo, hipStream_t s);
 int acc_to_f32_launch(const double* acc, float* dst, int n, hipStream_t s);

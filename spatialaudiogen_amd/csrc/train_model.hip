@@ -540,54 +540,10 @@ struct Bwd : Fwd {
             timed("maxpool_bwd_kernel", 0.0, [&] { return maxpool_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, s); });
             bn_bwd(name, 0, dz0, nullptr, nullptr, c->p("y0" + sfx), (long)B * 112 * 224, 64, dz0, nullptr);       // (in place: elementwise)
         } else {
-            // SAGEN_STEM_TAIL_HALVES=1 (round 6, opt-in): the second pass and the stem's weight gradient by halves of the batch - the
-            // weight gradient of the first half (second stream) beside the second pass of the second half (the step ends on
-            // a serial tail, pool + BN backward 157 us -> stem weight gradient 236 us, one kernel at a time)
-            static const bool halves_env = getenv("SAGEN_STEM_TAIL_HALVES") != nullptr;
-            const bool halves = halves_env && wg != nullptr && B >= 2;
-            const float* praw = c->rawpool_last && scope == "video_encoder" ? c->p("rx0" + sfx) : nullptr;
-            float* dgm = grad(name + "/bn/gamma"); float* dbt = grad(name + "/bn/beta");
             timed("maxpool_bn_bwd_kernels", 0.0, [&] {
                 return maxpool_bn_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, bnb_acc(0), c->p(redws),
-                                             dgm, dbt, s, praw, 0, halves ? -1 : 0); });
-            if (halves && !rc) {
-                const WgradDesc w0 = wdesc(c->p("xpad" + sfx), 229, 454, 4, 32, dz0, 112, 224, 64, 64, 7, 1, 2, 2, 0, 0);
-                const size_t per = (size_t)w0.TH * w0.TW * w0.Cg * w0.Cd;
-                float* const ws = c->p("t:wgws");
-                const size_t cap_f = c->cap("t:wgws");
-                int sk_done = 0;
-                WgradDesc last = w0;
-                for (int h = 0; h < 2 && !rc; ++h) {
-                    const int b0 = h == 0 ? 0 : B / 2, nb = h == 0 ? B / 2 : B - B / 2;
-                    layer = "poolbwd:" + scope;
-                    timed("maxpool_bn_bwd_kernels", 0.0, [&] {
-                        return maxpool_bn_bwd_launch(c->p("y0" + sfx), bn0, c->p("t:x0" + sfx), ga, gb, dz0, B, 112, 224, 64, bnb_acc(0), c->p(redws),
-                                                     dgm, dbt, s, praw, b0, nb); });
-                    hipEvent_t e = next_event();
-                    if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(wg->s, e, 0) != hipSuccess) { rc = fail(SAGEN_ERR_HIP, "stream fork failed"); break; }
-                    WgradDesc d = w0;
-                    d.B = nb; d.g = w0.g + (size_t)b0 * w0.g_bstride; d.d = w0.d + (size_t)b0 * w0.d_bstride;
-                    d.out = c->p("t:stemtmp" + sfx);
-                    d.ws = ws + (size_t)sk_done * per;
-                    d.splitk = std::max(2, wgrad_pick_splitk(d, (cap_f - (size_t)sk_done * per) / (h == 0 ? 2 : 1)));      // (room for both halves' partials)
-                    if ((size_t)(sk_done + d.splitk) * per > cap_f) { rc = fail(SAGEN_ERR_WORKSPACE, "stem weight gradient by halves: partials exceed t:wgws"); break; }
-                    d.defer_reduce = 1;
-                    wg->layer = "wgrad:" + name;
-                    const double flops = 2.0 * d.B * d.Hd * d.Wd * d.TH * d.TW * d.Cg * d.Cd;
-                    wg->timed(wgrad_kernel_name(d), flops, [&] { return wgrad_launch(d, wg->s); });
-                    if (wg->rc) { rc = wg->rc; break; }
-                    sk_done += d.splitk;
-                    last = d;
-                }
-                if (!rc) {
-                    last.ws = ws; last.splitk = sk_done;
-                    wg->timed("splitk_reduce_kernel", 0.0, [&] { return wgrad_reduce_launch(last, wg->s); });
-                    wg->timed("stem_wgrad_unpack_kernel", 0.0, [&] { return stem_wgrad_unpack_launch(c->p("t:stemtmp" + sfx), grad(name + "/weights"), wg->s); });
-                    if (wg->rc) rc = wg->rc;
-                }
-                ms_flush();
-                return;
-            }
+                                             grad(name + "/bn/gamma"), grad(name + "/bn/beta"), s,
+                                             c->rawpool_last && scope == "video_encoder" ? c->p("rx0" + sfx) : nullptr); });
         }
         // 7x7/2 over the zero-bordered 4-channel frame: the 7 (+1 zero) horizontal taps x 4 channels are 32 contiguous floats
         WgradDesc w = wdesc(c->p("xpad" + sfx), 229, 454, 4, 32, dz0, 112, 224, 64, 64, 7, 1, 2, 2, 0, 0);
